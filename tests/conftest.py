@@ -1,0 +1,25 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+@pytest.fixture(scope='session')
+def synth_weights():
+    from rmem_ocu_amd.weights import synth_state_dict
+    return synth_state_dict(0)
+
+
+@pytest.fixture(scope='session')
+def golden_ops():
+    import numpy as np
+    return np.load(os.path.join(GOLDEN, 'ops.npz'))

@@ -1,0 +1,220 @@
+"""Generate the golden fixtures in this directory by running the REFERENCE itself.
+
+Container-only: needs /root/reference (read-only) and never runs on the GPU box.
+    python tests/golden/make_golden.py [ops|small|full|all]
+
+The reference is imported unmodified.  Three accommodations live only here
+(SURVEY.md §8c): in-memory ``sys.modules`` entries for ``timm.models.layers`` and
+``torchvision.transforms`` (the reference imports an init helper and an enum it never
+uses on this path); the config is composed the way configs/pre_vost.py:16 +
+tools/eval.py:134-135 would (``pre_vost`` itself cannot import in this fork); and
+``torch.zeros(device=cuda)`` is mapped to CPU for aot_engine.py:209-213.
+
+Weights come from rmem_ocu_amd.weights.synth_state_dict (no checkpoint exists
+offline); inputs from rmem_ocu_amd.synth.make_clip or seeded numpy streams, so the
+fixtures store only outputs plus the seeds/checksums of the inputs.
+"""
+from __future__ import annotations
+
+import hashlib
+import importlib
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+REF = '/root/reference/aot_plus'
+
+from rmem_ocu_amd.synth import make_clip  # noqa: E402
+from rmem_ocu_amd.weights import synth_state_dict  # noqa: E402
+
+
+def load_reference(former=1, latter=7):
+    sys.path.insert(0, REF)
+    tml = types.ModuleType('timm.models.layers')
+    tml.trunc_normal_ = lambda t, mean=0., std=1., a=-2., b=2.: torch.nn.init.trunc_normal_(t, mean=mean, std=std, a=a, b=b)
+    tml.DropPath = torch.nn.Identity
+    tml.to_2tuple = lambda x: (x, x)
+    tm = types.ModuleType('timm.models')
+    tm.layers = tml
+    timm = types.ModuleType('timm')
+    timm.models = tm
+    sys.modules.update({'timm': timm, 'timm.models': tm, 'timm.models.layers': tml})
+    tvf = types.ModuleType('torchvision.transforms.functional')
+    tvt = types.ModuleType('torchvision.transforms')
+    tvt.functional = tvf
+    tvt.InterpolationMode = type('InterpolationMode', (), {'BILINEAR': 'bilinear', 'NEAREST': 'nearest'})
+    tv = types.ModuleType('torchvision')
+    tv.transforms = tvt
+    sys.modules.update({'torchvision': tv, 'torchvision.transforms': tvt, 'torchvision.transforms.functional': tvf})
+
+    cfg = importlib.import_module('configs.default').EngineConfig('golden', 'r50_aotl')
+    cfg.MODEL_LINEAR_Q = False
+    cfg.FORMER_MEM_LEN, cfg.LATTER_MEM_LEN = former, latter
+
+    _zeros = torch.zeros
+
+    def zeros_cpu(*a, **k):
+        dev = k.get('device')
+        if dev is not None and torch.device(dev).type == 'cuda':
+            k['device'] = 'cpu'
+        return _zeros(*a, **k)
+    torch.zeros = zeros_cpu
+
+    from networks.models import build_vos_model
+    from networks.engines import build_engine
+    model = build_vos_model(cfg.MODEL_VOS, cfg).eval()
+    missing = model.load_state_dict(synth_state_dict(0), strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    return cfg, model, build_engine
+
+
+def sha(t: torch.Tensor) -> str:
+    return hashlib.sha256(t.contiguous().numpy().tobytes()).hexdigest()
+
+
+def seeded(seed, shape, scale=1.0):
+    rng = np.random.Generator(np.random.PCG64([seed, 0xC0FFEE]))
+    return torch.from_numpy(rng.standard_normal(shape).astype(np.float32) * np.float32(scale))
+
+
+# --------------------------------------------------------------------------
+def gen_ops(model):
+    """Op-level fixtures: the reference's own attention / LSTT-block modules on seeded inputs."""
+    out = {}
+    lstt = model.LSTT
+    blk = lstt.layers[0]
+    temporal = torch.cat((model.cur_pos_emb, model.mem_pos_emb), dim=0).detach()
+    h, w = 6, 7
+    L, C = h * w, 256
+    pos = model.pos_generator(torch.zeros(1, C, h, w)).view(1, C, L).permute(2, 0, 1).contiguous()
+    out['sine_pos_6x7'] = pos[:, 0].numpy()
+    big = model.pos_generator(torch.zeros(1, C, 31, 54)).view(1, C, 31 * 54).permute(2, 0, 1)
+    out['sine_pos_31x54_rows'] = big[[0, 53, 54, 800, 1673], 0].numpy()
+    with torch.no_grad():
+        for T in (1, 2, 4, 5, 8, 9, 12):
+            q = seeded(100 + T, (L, 1, C))
+            k = seeded(200 + T, (T * L, 1, C))
+            v = seeded(300 + T, (T * L, 1, C))
+            o, attn = blk.long_term_attn(q, k, v, is_return_attn_weight=True)
+            out[f'mha_T{T}_out'] = o[:, 0].numpy()
+            out[f'mha_T{T}_mass'] = attn.view(1, 8, L, T, L).mean(1)[0].sum(2).numpy()
+            # whole block, propagate mode (curr_id_emb None), with the temporal PE
+            tgt = seeded(400 + T, (L, 1, C))
+            long_mem = [seeded(500 + T, (T, L, 1, C)), seeded(600 + T, (T, L, 1, C))]
+            short_mem = [seeded(700 + T, (L, 1, C)), seeded(800 + T, (L, 1, C))]
+            y, mems = blk(tgt, long_mem, short_mem, curr_id_emb=None, self_pos=pos, size_2d=(h, w),
+                          temporal_encoding=temporal, save_atten_weights=True)
+            out[f'blk_T{T}_out'] = y[:, 0].numpy()
+            out[f'blk_T{T}_curK'] = mems[0][0][:, 0].numpy()
+            out[f'blk_T{T}_locK'] = mems[2][0][:, 0].numpy()
+            out[f'blk_T{T}_locV'] = mems[2][1][:, 0].numpy()
+            out[f'blk_T{T}_mass'] = blk.record_attn_weight.numpy()
+        # reference-frame mode (curr_id_emb given) -> SDPA paths
+        tgt = seeded(900, (L, 1, C))
+        idemb = seeded(901, (L, 1, C), 0.5)
+        y, mems = blk(tgt, None, None, curr_id_emb=idemb, self_pos=pos, size_2d=(h, w), temporal_encoding=temporal)
+        out['blk_ref_out'] = y[:, 0].numpy()
+        out['blk_ref_gV'] = mems[1][1][0, :, 0].numpy()
+        out['blk_ref_locV'] = mems[2][1][:, 0].numpy()
+        # cfg-2 sized memory read (HW = 1674, T = 8): sampled rows + the full mass matrix
+        L2, T = 1674, 8
+        q = seeded(1000, (L2, 1, C))
+        k = seeded(1001, (T * L2, 1, C))
+        v = seeded(1002, (T * L2, 1, C))
+        o, attn = blk.long_term_attn(q, k, v, is_return_attn_weight=True)
+        rows = np.arange(0, L2, 27)
+        out['mha_big_rows'] = rows
+        out['mha_big_out'] = o[rows, 0].numpy()
+        out['mha_big_mass'] = attn.view(1, 8, L2, T, L2).mean(1)[0].sum(2).numpy()
+        del attn
+        # temporal slot table as the reference computes it (transformer.py:606-621)
+        for T in range(2, 33):
+            pe = torch.arange(4, dtype=torch.float32).view(1, 1, 4)
+            if T <= 4:
+                s = F.interpolate(pe[:, :, :T], size=T, mode='linear', align_corners=True)
+            else:
+                s = torch.flip(F.interpolate(torch.flip(F.interpolate(pe, size=4, mode='linear', align_corners=True), dims=(-1,)), size=T, mode='nearest'), dims=(-1,))
+            out[f'slots_T{T}'] = s.view(-1).round().to(torch.int64).numpy()
+        # encoder / id-bank / decoder at a small size
+        img = seeded(1100, (1, 3, 97, 129))
+        xs = model.encode_image(img)
+        for i, x in enumerate(xs):
+            out[f'enc_x{i}'] = x[0, :, ::3, ::3].numpy() if i < 2 else x[0].numpy()
+        embs = [seeded(1200 + i, (7 * 9, 1, 256)) for i in range(3)]
+        out['dec_logits'] = model.decode_id_logits(embs, xs)[0].numpy()
+        mask = torch.zeros(1, 1, 97, 129, dtype=torch.int32)
+        mask[:, :, 10:50, 20:70] = 1
+        mask[:, :, 40:90, 60:120] = 3
+        oh = (mask == torch.arange(11).view(1, -1, 1, 1)).float()
+        oh = torch.cat((oh, torch.zeros(1, 1, 97, 129)), 1)
+        out['id_emb'] = model.get_id_emb(oh)[0].numpy()
+    return out
+
+
+def run_ref_clip(cfg, model, build_engine, frames, first_mask, out_hw, gap, sample_px):
+    """Drives the reference engine exactly as evaluator.py:385-441, 509-523 does."""
+    engine = build_engine(cfg.MODEL_ENGINE, phase='eval', aot_model=model, gpu_id=0, long_term_mem_gap=gap)
+    engine.eval()
+    engine.long_term_mem_gap = gap
+    labels, idx_trace, logit_samples = [], [], []
+    import contextlib
+    import io
+    with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+        engine.add_reference_frame(frames[0:1], first_mask, frame_step=0, obj_nums=[int(first_mask.max())])
+        for i in range(1, frames.shape[0]):
+            logit = engine.match_propogate_one_frame(frames[i:i + 1], output_size=out_hw)
+            prob = torch.softmax(logit, dim=1)
+            label = torch.argmax(prob, dim=1, keepdim=True).float()
+            engine.update_memory(F.interpolate(label, size=engine.input_size_2d, mode='nearest'))
+            labels.append(label[0, 0].to(torch.uint8).numpy())
+            idx_trace.append(list(engine.aot_engines[0].long_memories_indexes))
+            logit_samples.append(logit[0][:, sample_px[0], sample_px[1]].numpy().copy())
+    return np.stack(labels), idx_trace, np.stack(logit_samples)
+
+
+def pack_trace(trace, width):
+    arr = -np.ones((len(trace), width), dtype=np.int32)
+    for i, t in enumerate(trace):
+        arr[i, :len(t)] = t
+    return arr
+
+
+def gen_clip(tag, former, latter, n_frames, h, w, out_hw, gap, objs, seed):
+    cfg, model, build_engine = load_reference(former, latter)
+    frames, mask = make_clip(seed, n_frames, h, w, objs)
+    ys = np.linspace(2, out_hw[0] - 3, 12).astype(np.int64)
+    xs = np.linspace(2, out_hw[1] - 3, 12).astype(np.int64)
+    labels, trace, samples = run_ref_clip(cfg, model, build_engine, frames, mask, out_hw, gap, (ys, xs))
+    return {
+        'meta': np.array([former, latter, n_frames, h, w, out_hw[0], out_hw[1], gap, objs, seed], dtype=np.int64),
+        'frames_sha': np.array(sha(frames)), 'mask_sha': np.array(sha(mask)),
+        'labels': labels, 'indexes': pack_trace(trace, former + latter + 1),
+        'sample_y': ys, 'sample_x': xs, 'logit_samples': samples,
+    }
+
+
+if __name__ == '__main__':
+    what = sys.argv[1] if len(sys.argv) > 1 else 'all'
+    torch.set_num_threads(8)
+    if what in ('ops', 'all'):
+        _, model, _ = load_reference()
+        np.savez_compressed(os.path.join(HERE, 'ops.npz'), **gen_ops(model))
+    if what in ('small', 'all'):
+        # 161x193 -> 11x13 tokens; bank of 3 with gap 2 so ~20 evictions happen in 48 frames
+        np.savez_compressed(os.path.join(HERE, 'clip_small.npz'),
+                            **gen_clip('small', 1, 2, 48, 161, 193, (160, 192), 2, 3, 11))
+    if what in ('full', 'all'):
+        # cfg-2 geometry: 480x854 video at network size 481x849, bank N = 8, gap 2 so the bank fills
+        # by frame 14 and evicts from frame 16
+        np.savez_compressed(os.path.join(HERE, 'clip_full.npz'),
+                            **gen_clip('full', 1, 7, 30, 481, 849, (480, 854), 2, 3, 21))
+    for f in sorted(os.listdir(HERE)):
+        if f.endswith('.npz'):
+            print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, 'KiB')
