@@ -1,0 +1,144 @@
+/* librmem_hip.so -- C ABI of the MI355X (gfx950) space-time memory-reading engine.
+ *
+ * The reference (Bardli/RMem_ocu) has no FFI: its hot path is nn.Modules calling
+ * ATen/cuDNN kernels.  This header is the boundary one level below
+ * the reference's Python inference API; each entry point names the reference call
+ * site(s) whose vendor kernels it replaces (paths relative to aot_plus/).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller unless stated otherwise;
+ *   - `stream` is a hipStream_t passed as void*; calls only enqueue work and never
+ *     synchronise, so a caller may wrap any sequence of them in a hipGraph capture;
+ *   - return value: 0 on success, negative on error (rmem_last_error_string() says why);
+ *     no exception crosses the boundary; no global mutable state except the
+ *     thread-local error string;
+ *   - "bf16" = IEEE bfloat16 stored as uint16; feature maps are NHWC with N = 1, which
+ *     for the LSTT is the same memory as the reference's [L, B=1, C] token layout;
+ *   - leading dimensions (ld*) are in elements.
+ */
+#ifndef RMEM_H_
+#define RMEM_H_
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RMEM_ABI_VERSION 1
+
+int rmem_abi_version(void);
+const char* rmem_last_error_string(void);
+
+/* ------------------------------------------------------------------ convolution / linear
+ * Implicit-GEMM NHWC convolution, bf16 in, fp32 accumulate:
+ *   y = act(conv(x, w) + bias (+ residual)),  optional y2 = bf16(conv(x, w) + bias).
+ * Replaces: encoders/resnet.py:48-68, 179-195 (conv + FrozenBatchNorm2d folded into w/bias + ReLU
+ * + residual), models/aot.py:25-29, 133 (encoder_projector), models/aot.py:68-74, 112 (id bank),
+ * decoders/fpn.py:22-32 (ConvGN convs, adapters, conv_out), and every nn.Linear of
+ * layers/transformer.py:487-512 and layers/attention.py:19-25 (a 1x1 conv with H = rows, W = 1).
+ * w is [Cout][KH][KW][Cin] bf16; Cin must be a multiple of 8. */
+typedef struct rmem_conv_desc {
+  int H, W, Cin;      /* input feature map */
+  int Ho, Wo, Cout;   /* output feature map (checked against the geometry) */
+  int KH, KW, stride, pad;
+  int ldo;            /* y row stride  (>= Cout) */
+  int ldr;            /* residual row stride */
+  int ld2;            /* y2 row stride */
+  int relu;           /* 1: ReLU after bias/residual */
+  int out_f32;        /* 1: y is fp32, 0: bf16 */
+  int res_f32;        /* 1: residual is fp32, 0: bf16 */
+} rmem_conv_desc;
+
+int rmem_conv2d_nhwc(const rmem_conv_desc* desc, const void* x, const void* w, const float* bias,
+                     const void* residual, void* y, void* y2, void* stream);
+
+/* ------------------------------------------------------------------ memory-read attention
+ * out[q, 32h:32h+32] = softmax_k( (Q[q,h]+pe_cur[h]) . (K[k,h]+pe_mem[slot(k),h]) / sqrt(32) ) V[k,h]
+ * over the keys named by the chunk table, plus (optionally) the per-memory-frame probability mass
+ * mass[q, t] = mean_h sum_{k in frame t} p[h, q, k].
+ * Replaces: layers/attention.py:45-64 as called from layers/transformer.py:632-635 (long-term),
+ * the K + temporal-PE materialisation of transformer.py:594-626, and the attention-weight recording of
+ * transformer.py:636-643.  With chunks == NULL it is plain attention over one key frame of lk_single
+ * keys split into nchunks ranges (transformer.py:569 self-attention, 657-662 short-term attention).
+ * The output is pre-projection (attention.py:79 is a rmem_conv2d_nhwc call).
+ * Head dim is fixed at 32; heads <= 8. */
+typedef struct rmem_attn_chunk {
+  int slot;       /* bank slot: keys at k_bank + slot * slot_stride */
+  int key_begin;  /* first key (row) of the chunk inside the slot */
+  int key_count;  /* >= 1 */
+  int pe_slot;    /* row of pe_mem added to these keys, or -1 */
+  int t;          /* memory-frame index the chunk's probability mass is credited to */
+  int reserved[3];
+} rmem_attn_chunk;
+
+size_t rmem_attn_workspace_bytes(int Lq, int heads, int nchunks);
+
+int rmem_mem_read_attn(const void* q, int ldq,                     /* bf16 [Lq][ldq] */
+                       const void* k_bank, const void* v_bank,     /* bf16, rows [Lk][ldkv] per slot */
+                       long long slot_stride, int ldkv,
+                       const rmem_attn_chunk* chunks, int nchunks, /* device table, or NULL */
+                       int lk_single,                              /* keys when chunks == NULL */
+                       const float* pe_cur,                        /* fp32 [C] or NULL */
+                       const float* pe_mem,                        /* fp32 [4][C] or NULL */
+                       int Lq, int heads,
+                       void* out, int ldo,                         /* bf16 [Lq][ldo] */
+                       float* attn_mass, int T,                    /* fp32 [Lq][T] or NULL */
+                       void* workspace, void* stream);
+
+/* ------------------------------------------------------------------ normalisation / activation
+ * LayerNorm over 256 channels of (a [+ b]); writes any of: bf16 y, fp32 y, bf16 (y + pos).
+ * Replaces: layers/transformer.py:566-568 (norm1 and with_pos_embed), 574 (norm2), 659-660 (norm4 of a
+ * sum), 683 (norm3), 250-259 (decoder_norms). */
+int rmem_layernorm256(const void* a, int a_is_f32, int lda, const void* b, int b_is_f32, int ldb,
+                      const float* gamma, const float* beta, float eps, int M,
+                      void* y_bf16, int ldy, const float* pos, void* ypos_bf16, int ldyp,
+                      float* y_f32, int ldyf, void* stream);
+
+/* y = a + b (bf16).  Replaces the `curr_v + curr_id_emb` adds of layers/transformer.py:279-285. */
+int rmem_add_bf16(const void* a, const void* b, void* y, long long n, void* stream);
+
+/* GroupNorm on NHWC bf16 with fused activation (0 none, 1 ReLU, 2 exact GELU).
+ * Replaces: layers/basic.py:31-32 (GN(32)+GELU of the conv-FFN) and layers/basic.py:69-70 +
+ * decoders/fpn.py:44-64 (GN(8)+ReLU of the FPN head). */
+size_t rmem_groupnorm_workspace_bytes(int groups);
+int rmem_groupnorm_nhwc(const void* x, int M, int C, int groups, const float* gamma, const float* beta,
+                        float eps, int act, void* y, float* workspace, void* stream);
+
+/* Depth-wise 5x5, pad 2, NHWC bf16; w_t is [25][C] fp32.  Replaces layers/basic.py:19-25, 33. */
+int rmem_dwconv5x5_nhwc(const void* x, const float* w_t, void* y, int H, int W, int C, void* stream);
+
+/* ------------------------------------------------------------------ layout / resampling */
+/* fp32 [3][H][W] image -> bf16 [H][W][8] (channels 3..7 zero): input of encoders/resnet.py:179. */
+int rmem_image_to_nhwc8(const float* img_chw, void* out, int H, int W, void* stream);
+/* 3x3 stride-2 pad-1 max-pool (encoders/resnet.py:105, 182). */
+int rmem_maxpool3x3s2_nhwc(const void* x, void* y, int H, int W, int C, void* stream);
+/* bilinear resize, NHWC bf16 (decoders/fpn.py:49-52, 57-60). */
+int rmem_bilinear_nhwc(const void* x, void* y, int Hi, int Wi, int Ho, int Wo, int C, int align_corners, void* stream);
+/* logits fp32 NHWC [Hi][Wi][ldl]: ids > keep_max_id forced to -1e10, bilinear to (Ho, Wo); writes any of
+ * NCHW fp32 logits, uint8 argmax labels, fp32 argmax labels (engines/aot_engine.py:450-463;
+ * managers/evaluator.py:430-441). */
+int rmem_logits_post(const float* logits_nhwc, int ldl, int num_classes, int keep_max_id, int Hi, int Wi,
+                     int Ho, int Wo, int align_corners, float* out_nchw, unsigned char* label_u8,
+                     float* label_f32, void* stream);
+/* label map (uint8 or fp32) -> nearest resize -> one-hot + ignore channel, bf16 [Hd][Wd][16]
+ * (utils/image.py:69-74; engines/aot_engine.py:208-224; managers/evaluator.py:518-522). */
+int rmem_label_to_onehot16(const void* label, int label_is_f32, int Hs, int Ws, int Hd, int Wd,
+                           int num_classes, void* out, void* stream);
+/* scores[t] = sum_q mass[q][t] * (1 - softmax(bilinear_ac(logits -> He x We))[0])
+ * (engines/aot_engine.py:355-362 + layers/transformer.py:341-351, the device half of the eviction policy). */
+int rmem_evict_scores(const float* logits_nhwc, int ldl, int num_classes, int keep_max_id, int Hi, int Wi,
+                      int He, int We, const float* attn_mass, int T, float* scores, void* stream);
+
+/* ------------------------------------------------------------------ stream capture helpers
+ * Thin wrappers over hipStreamBeginCapture / hipGraphInstantiate / hipGraphLaunch so the Python host
+ * can replay one frame's launch sequence as a hipGraph. */
+int rmem_graph_begin(void* stream);
+int rmem_graph_end(void* stream, void** graph_exec_out);
+int rmem_graph_launch(void* graph_exec, void* stream);
+int rmem_graph_destroy(void* graph_exec);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RMEM_H_ */

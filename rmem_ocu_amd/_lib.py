@@ -1,0 +1,90 @@
+"""ctypes binding of librmem_hip.so (include/rmem.h).
+
+There is no CPU fallback: if the shared object is missing or a call fails, an
+exception is raised.  ``build()`` compiles it in-tree with hipcc for gfx950.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'librmem_hip.so')
+ABI_VERSION = 1
+
+
+class RmemError(RuntimeError):
+    pass
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ('H', 'W', 'Cin', 'Ho', 'Wo', 'Cout', 'KH', 'KW', 'stride', 'pad',
+                                       'ldo', 'ldr', 'ld2', 'relu', 'out_f32', 'res_f32')]
+
+
+class AttnChunk(C.Structure):
+    _fields_ = [('slot', C.c_int), ('key_begin', C.c_int), ('key_count', C.c_int), ('pe_slot', C.c_int),
+                ('t', C.c_int), ('reserved', C.c_int * 3)]
+
+
+_vp, _i, _ll, _f = C.c_void_p, C.c_int, C.c_longlong, C.c_float
+# name -> (restype, argtypes); the list is checked against include/rmem.h by tests/test_abi.py
+SIGNATURES = {
+    'rmem_abi_version': (_i, []),
+    'rmem_last_error_string': (C.c_char_p, []),
+    'rmem_conv2d_nhwc': (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'rmem_attn_workspace_bytes': (C.c_size_t, [_i, _i, _i]),
+    'rmem_mem_read_attn': (_i, [_vp, _i, _vp, _vp, _ll, _i, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _vp, _vp]),
+    'rmem_layernorm256': (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _f, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _vp]),
+    'rmem_add_bf16': (_i, [_vp, _vp, _vp, _ll, _vp]),
+    'rmem_groupnorm_workspace_bytes': (C.c_size_t, [_i]),
+    'rmem_groupnorm_nhwc': (_i, [_vp, _i, _i, _i, _vp, _vp, _f, _i, _vp, _vp, _vp]),
+    'rmem_dwconv5x5_nhwc': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    'rmem_image_to_nhwc8': (_i, [_vp, _vp, _i, _i, _vp]),
+    'rmem_maxpool3x3s2_nhwc': (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    'rmem_bilinear_nhwc': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    'rmem_logits_post': (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    'rmem_label_to_onehot16': (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    'rmem_evict_scores': (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp]),
+    'rmem_graph_begin': (_i, [_vp]),
+    'rmem_graph_end': (_i, [_vp, C.POINTER(_vp)]),
+    'rmem_graph_launch': (_i, [_vp, _vp]),
+    'rmem_graph_destroy': (_i, [_vp]),
+}
+
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    """Compile librmem_hip.so in-tree (hipcc --offload-arch=gfx950)."""
+    src = os.path.join(_HERE, 'csrc')
+    if force:
+        subprocess.run(['make', '-C', src, 'clean'], check=True, capture_output=True)
+    r = subprocess.run(['make', '-C', src, '-j8'], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RmemError('building librmem_hip.so failed:\n' + r.stdout + r.stderr)
+    return LIB_PATH
+
+
+def lib():
+    """The loaded library (loads on first use; raises if it is not built)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RmemError(f'{LIB_PATH} is missing: run `python -c "import __graft_entry__ as g; g.build()"` '
+                            '(there is no CPU fallback for the HIP path)')
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        if L.rmem_abi_version() != ABI_VERSION:
+            raise RmemError('librmem_hip.so ABI version mismatch; rebuild it')
+        _lib = L
+    return _lib
+
+
+def check(rc: int, what: str = ''):
+    if rc != 0:
+        raise RmemError(f'{what} failed ({rc}): {lib().rmem_last_error_string().decode()}')

@@ -1,0 +1,270 @@
+// Space-time memory-read attention for gfx950 (CDNA4), head dim 32.
+//
+// One kernel serves the three attention call sites of an LSTT block
+// (layers/transformer.py:569, 632-635, 657-662 through layers/attention.py:45-74):
+//   long-term : Q = curr_Q + cur_pe, keys = the restricted memory bank (T frames x HW
+//               tokens, K[t] + mem_pe[slot(t)]), optional per-memory-frame probability
+//               mass side output (transformer.py:636-643);
+//   short-term and self attention : one key frame, no temporal embedding.
+//
+// Decomposition (flash-decoding style): grid = (query tiles of 128) x heads x key
+// chunks.  A chunk is a contiguous key range of ONE memory frame, described by a
+// device-resident table so a captured hipGraph stays valid while the bank's slot
+// table changes.  Every workgroup produces an unnormalised partial O plus (m, l);
+// k_attn_combine merges the chunks, normalises, writes bf16 O and the mass matrix.
+//
+// Per workgroup: 4 waves x 32 query rows.  K/V tiles of 64 keys go global ->
+// registers -> LDS (double buffered); K stays row-major [key][32] with an XOR chunk
+// swizzle (conflict-free ds_read_b128), V is transposed on the way in to [d][key]
+// so the PV A-fragment is two ds_read_b64.
+//   S^T = K . Q^T   : v_mfma_f32_32x32x16_bf16, A = K rows (keys), B = Q^T held in
+//                     registers for the whole kernel; the query sits on the lane,
+//                     so row max / row sum are in-lane plus one exchange with lane^32.
+//                     The temporal-PE term q'.pe[slot] is the accumulator's initial value.
+//   O^T += V^T . P^T: the S^T accumulator (exp2'd, packed to bf16) IS the B operand:
+//                     registers 8s..8s+7 of lane half h are keys 16s+8(j>>2)+4h+(j&3),
+//                     and the V^T A-fragment is read in that same key order.
+// Logits live in the log2 domain: Q is pre-scaled by log2(e)/sqrt(32).
+#include "common.h"
+#include "../../include/rmem.h"
+
+namespace {
+
+constexpr int D = 32;          // head dim
+constexpr int KT = 64;         // keys per LDS tile
+constexpr int VT_LD = KT + 4;  // padded row of the transposed V tile (136 B: 8-byte aligned, conflict-free b64 reads)
+constexpr float NEG_BIG = -1.0e30f;
+
+struct AttnParams {
+  const bf16* q; int ldq;
+  const bf16* k; const bf16* v; long slot_stride; int ldkv;
+  const rmem_attn_chunk* chunks; int nchunks; int lk; int per_chunk;
+  const float* pe_cur; const float* pe_mem;
+  int Lq, heads, C;
+  float* opart; float* ml;
+  float qscale;
+};
+
+__device__ __forceinline__ int kswz(int row, int chunk) { return row * D + ((chunk ^ ((row >> 2) & 3)) << 3); }
+
+__global__ __launch_bounds__(256) void k_attn_partial(AttnParams p) {
+  __shared__ __attribute__((aligned(16))) bf16 Ks[2][KT * D];
+  __shared__ __attribute__((aligned(16))) bf16 Vt[2][D * VT_LD];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lq = lane & 31, lh = lane >> 5;
+  const int head = blockIdx.y, c = blockIdx.z;
+
+  int slot, kb, kn, pe_slot;
+  if (p.chunks) {
+    const rmem_attn_chunk ch = p.chunks[c];
+    slot = ch.slot; kb = ch.key_begin; kn = ch.key_count; pe_slot = ch.pe_slot;
+  } else {
+    slot = 0; kb = c * p.per_chunk; kn = min(p.per_chunk, p.lk - kb); pe_slot = -1;
+  }
+  const bf16* Kp = p.k + (long)slot * p.slot_stride + head * D;
+  const bf16* Vp = p.v + (long)slot * p.slot_stride + head * D;
+
+  // ---- Q^T fragment (B operand) and the temporal-PE logit bias ----
+  const int qrow = min(blockIdx.x * 128 + wave * 32 + lq, p.Lq - 1);
+  bf16x8 qf[2];
+  float bias = 0.f;
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const int d0 = head * D + 16 * s + 8 * lh;
+    const bf16x8 raw = *reinterpret_cast<const bf16x8*>(p.q + (long)qrow * p.ldq + d0);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float f = (float)raw[j];
+      if (p.pe_cur) f += p.pe_cur[d0 + j];
+      const bf16 b = (bf16)(f * p.qscale);
+      qf[s][j] = b;
+      if (pe_slot >= 0) bias += (float)b * p.pe_mem[pe_slot * p.C + d0 + j];
+    }
+  }
+  bias += __shfl_xor(bias, 32, 64);
+
+  // ---- staging state: thread -> (key, 16-byte chunk of the head's 64-byte row) ----
+  const int skey = tid >> 2, schunk = tid & 3;
+  bf16x8 rk, rv;
+  const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+  auto load_tile = [&](int t) {
+    const int kidx = t * KT + skey;
+    rk = zero8; rv = zero8;
+    if (kidx < kn) {
+      const long off = (long)(kb + kidx) * p.ldkv + schunk * 8;
+      rk = *reinterpret_cast<const bf16x8*>(Kp + off);
+      rv = *reinterpret_cast<const bf16x8*>(Vp + off);
+    }
+  };
+  auto store_tile = [&](int buf) {
+    *reinterpret_cast<bf16x8*>(&Ks[buf][kswz(skey, schunk)]) = rk;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) Vt[buf][(schunk * 8 + j) * VT_LD + skey] = rv[j];
+  };
+
+  f32x16 oacc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) oacc[r] = 0.f;
+  float m_run = NEG_BIG, l_run = 0.f;
+
+  const int ntiles = (kn + KT - 1) / KT;
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+
+  for (int t = 0; t < ntiles; ++t) {
+    const int cur = t & 1;
+    if (t + 1 < ntiles) load_tile(t + 1);
+
+    // S^T for the two 32-key blocks of this tile
+    f32x16 sacc[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[b][r] = bias;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(&Ks[cur][kswz(b * 32 + lq, 2 * s + lh)]);
+        sacc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[s], sacc[b], 0, 0, 0);
+      }
+    }
+    if (t == ntiles - 1 && (kn & (KT - 1))) {
+      const int base = t * KT + 4 * lh;
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (base + b * 32 + (r & 3) + 8 * (r >> 2) >= kn) sacc[b][r] = NEG_BIG;
+    }
+
+    // online softmax (query = lane & 31; the other 16 keys of each block sit in lane ^ 32)
+    float tmax = sacc[0][0];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, sacc[b][r]);
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    const float m_new = fmaxf(m_run, tmax);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    m_run = m_new;
+    float lsum = 0.f;
+    bf16x8 pb[2][2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float e = __builtin_amdgcn_exp2f(sacc[b][r] - m_new);
+        lsum += e;
+        pb[b][r >> 3][r & 7] = (bf16)e;
+      }
+    l_run = l_run * alpha + lsum;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[r] *= alpha;
+
+    // O^T += V^T . P^T
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const bf16* vrow = &Vt[cur][lq * VT_LD + b * 32 + 16 * s + 4 * lh];
+        const bf16x4 lo = *reinterpret_cast<const bf16x4*>(vrow);
+        const bf16x4 hi = *reinterpret_cast<const bf16x4*>(vrow + 8);
+        const bf16x8 a = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pb[b][s], oacc, 0, 0, 0);
+      }
+
+    if (t + 1 < ntiles) store_tile(cur ^ 1);
+    __syncthreads();
+  }
+
+  l_run += __shfl_xor(l_run, 32, 64);
+  const int qg = blockIdx.x * 128 + wave * 32 + lq;
+  if (qg < p.Lq) {
+    const long row = ((long)c * p.heads + head) * p.Lq + qg;
+    float* o = p.opart + row * D;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)  // C/D rows (r&3) + 8(r>>2) + 4h  ->  d = 8g + 4h + (0..3)
+      *reinterpret_cast<f32x4*>(o + 8 * g + 4 * lh) = f32x4{oacc[4 * g], oacc[4 * g + 1], oacc[4 * g + 2], oacc[4 * g + 3]};
+    if (lh == 0) *reinterpret_cast<f32x2*>(p.ml + row * 2) = f32x2{m_run, l_run};
+  }
+}
+
+struct CombineParams {
+  const float* opart; const float* ml;
+  const rmem_attn_chunk* chunks; int nchunks;
+  int Lq, heads;
+  bf16* out; int ldo;
+  float* mass; int T;
+};
+
+// one block per query row; thread = output channel (head * 32 + d)
+__global__ __launch_bounds__(256) void k_attn_combine(CombineParams p) {
+  __shared__ float hm[8][33];
+  const int q = blockIdx.x, tid = threadIdx.x;
+  const int head = tid >> 5, d = tid & 31;
+  if (head < p.heads) {
+    float m = NEG_BIG;
+    for (int c = 0; c < p.nchunks; ++c) m = fmaxf(m, p.ml[(((long)c * p.heads + head) * p.Lq + q) * 2]);
+    float num = 0.f, den = 0.f, mine = 0.f;
+    for (int c = 0; c < p.nchunks; ++c) {
+      const long row = ((long)c * p.heads + head) * p.Lq + q;
+      const float w = __builtin_amdgcn_exp2f(p.ml[row * 2] - m);
+      const float wl = w * p.ml[row * 2 + 1];
+      den += wl;
+      num += w * p.opart[row * D + d];
+      if (c == d) mine = wl;
+    }
+    const float inv = 1.f / den;
+    p.out[(long)q * p.ldo + tid] = (bf16)(num * inv);
+    if (p.mass) hm[head][d] = mine * inv;
+  }
+  if (p.mass) {
+    __syncthreads();
+    if (tid < p.T) {
+      float acc = 0.f;
+      for (int c = 0; c < p.nchunks; ++c) {
+        const int t = p.chunks ? p.chunks[c].t : 0;
+        if (t != tid) continue;
+        for (int h = 0; h < p.heads; ++h) acc += hm[h][c];
+      }
+      p.mass[(long)q * p.T + tid] = acc / (float)p.heads;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" size_t rmem_attn_workspace_bytes(int Lq, int heads, int nchunks) {
+  return (size_t)nchunks * heads * Lq * (D + 2) * sizeof(float);
+}
+
+extern "C" int rmem_mem_read_attn(const void* q, int ldq, const void* k_bank, const void* v_bank, long long slot_stride,
+                                  int ldkv, const rmem_attn_chunk* chunks, int nchunks, int lk_single,
+                                  const float* pe_cur, const float* pe_mem, int Lq, int heads, void* out, int ldo,
+                                  float* attn_mass, int T, void* workspace, void* stream) {
+  RMEM_REQUIRE(q && k_bank && v_bank && out && workspace, "rmem_mem_read_attn: null argument");
+  RMEM_REQUIRE(heads >= 1 && heads <= 8, "rmem_mem_read_attn: heads must be in 1..8 (head dim is fixed at 32)");
+  RMEM_REQUIRE(Lq > 0 && nchunks >= 1 && nchunks <= 32, "rmem_mem_read_attn: need Lq > 0 and 1 <= nchunks <= 32");
+  RMEM_REQUIRE(ldq % 8 == 0 && ldkv % 8 == 0 && slot_stride % 8 == 0, "rmem_mem_read_attn: strides must be multiples of 8 elements");
+  RMEM_REQUIRE(ldq >= heads * D && ldkv >= heads * D && ldo >= heads * D, "rmem_mem_read_attn: leading dimension < heads*32");
+  RMEM_REQUIRE(chunks || lk_single > 0, "rmem_mem_read_attn: lk_single must be > 0 when no chunk table is given");
+  RMEM_REQUIRE(!attn_mass || (chunks && T >= 1 && T <= 32), "rmem_mem_read_attn: the mass output needs a chunk table and 1 <= T <= 32");
+  RMEM_REQUIRE(!pe_mem || chunks, "rmem_mem_read_attn: pe_mem needs a chunk table");
+  hipStream_t s = (hipStream_t)stream;
+  AttnParams p;
+  p.q = (const bf16*)q; p.ldq = ldq; p.k = (const bf16*)k_bank; p.v = (const bf16*)v_bank;
+  p.slot_stride = slot_stride; p.ldkv = ldkv; p.chunks = chunks; p.nchunks = nchunks;
+  p.lk = lk_single; p.per_chunk = chunks ? 0 : (lk_single + nchunks - 1) / nchunks;
+  RMEM_REQUIRE(chunks || (long)p.per_chunk * (nchunks - 1) < lk_single, "rmem_mem_read_attn: too many chunks for lk_single");
+  p.pe_cur = pe_cur; p.pe_mem = pe_mem; p.Lq = Lq; p.heads = heads; p.C = heads * D;
+  p.opart = (float*)workspace; p.ml = p.opart + (size_t)nchunks * heads * Lq * D;
+  p.qscale = 1.4426950408889634f / sqrtf((float)D);
+  dim3 grid((Lq + 127) / 128, heads, nchunks);
+  hipLaunchKernelGGL(k_attn_partial, grid, dim3(256), 0, s, p);
+  CombineParams cp;
+  cp.opart = p.opart; cp.ml = p.ml; cp.chunks = chunks; cp.nchunks = nchunks; cp.Lq = Lq; cp.heads = heads;
+  cp.out = (bf16*)out; cp.ldo = ldo; cp.mass = attn_mass; cp.T = T;
+  hipLaunchKernelGGL(k_attn_combine, dim3(Lq), dim3(256), 0, s, cp);
+  return rmem_check_launch("rmem_mem_read_attn");
+}

@@ -1,0 +1,211 @@
+// Normalisation / activation glue of the LSTT block and the FPN head (HBM-bound
+// streaming kernels, 8-16 bytes per lane):
+//   LayerNorm(256) with optional summed second input and optional "+ positional
+//   embedding" second output      (layers/transformer.py:566-568, 574, 659-660, 683, 250-259)
+//   GroupNorm + {none, ReLU, GELU} on NHWC   (layers/basic.py:27-35, 60-70; decoders/fpn.py:44-64)
+//   depth-wise 5x5 convolution on NHWC       (layers/basic.py:19-25, 34)
+//   bf16 elementwise add                      (layers/transformer.py:279-285: curr_V + id_emb)
+#include "common.h"
+#include "../../include/rmem.h"
+
+namespace {
+
+// ------------------------------------------------------------------ LayerNorm
+struct LnParams {
+  const void* a; int a_f32; int lda;
+  const void* b; int b_f32; int ldb;
+  const float* gamma; const float* beta; float eps; int M;
+  bf16* y; int ldy; const float* pos; bf16* ypos; int ldyp;
+  float* yf; int ldyf;
+};
+
+__device__ __forceinline__ f32x4 load4(const void* base, int is_f32, long off) {
+  if (is_f32) return *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(base) + off);
+  const bf16x4 v = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16*>(base) + off);
+  return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+}
+
+// one wave per row of 256 channels, 4 channels per lane
+__global__ __launch_bounds__(256) void k_layernorm256(LnParams p) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= p.M) return;
+  const int c0 = lane * 4;
+  f32x4 v = load4(p.a, p.a_f32, (long)row * p.lda + c0);
+  if (p.b) {
+    const f32x4 w = load4(p.b, p.b_f32, (long)row * p.ldb + c0);
+    v += w;
+  }
+  const float mean = wave_sum(v[0] + v[1] + v[2] + v[3]) * (1.f / 256.f);
+  const f32x4 dv = v - mean;
+  const float var = wave_sum(dv[0] * dv[0] + dv[1] * dv[1] + dv[2] * dv[2] + dv[3] * dv[3]) * (1.f / 256.f);
+  const float rstd = rsqrtf(var + p.eps);
+  const f32x4 g = *reinterpret_cast<const f32x4*>(p.gamma + c0);
+  const f32x4 bt = *reinterpret_cast<const f32x4*>(p.beta + c0);
+  const f32x4 o = dv * rstd * g + bt;
+  if (p.y) *reinterpret_cast<bf16x4*>(p.y + (long)row * p.ldy + c0) = bf16x4{(bf16)o[0], (bf16)o[1], (bf16)o[2], (bf16)o[3]};
+  if (p.yf) *reinterpret_cast<f32x4*>(p.yf + (long)row * p.ldyf + c0) = o;
+  if (p.ypos) {
+    const f32x4 ps = *reinterpret_cast<const f32x4*>(p.pos + (long)row * 256 + c0);
+    const f32x4 q = o + ps;
+    *reinterpret_cast<bf16x4*>(p.ypos + (long)row * p.ldyp + c0) = bf16x4{(bf16)q[0], (bf16)q[1], (bf16)q[2], (bf16)q[3]};
+  }
+}
+
+// ------------------------------------------------------------------ add
+__global__ __launch_bounds__(256) void k_add_bf16(const bf16* a, const bf16* b, bf16* y, long n8) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+    const bf16x8 x = reinterpret_cast<const bf16x8*>(a)[i];
+    const bf16x8 z = reinterpret_cast<const bf16x8*>(b)[i];
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (bf16)((float)x[j] + (float)z[j]);
+    reinterpret_cast<bf16x8*>(y)[i] = o;
+  }
+}
+
+// ------------------------------------------------------------------ GroupNorm (NHWC)
+constexpr int GN_SPLITS = 32;
+
+// partial (sum, sumsq) per (group, split); deterministic two-stage reduction
+__global__ __launch_bounds__(256) void k_gn_stats(const bf16* x, int M, int C, int cpg, float* ws) {
+  const int g = blockIdx.x, sp = blockIdx.y;
+  const int vec = cpg / 8;                       // 16-byte pieces per pixel in this group
+  const int rows_per = (M + GN_SPLITS - 1) / GN_SPLITS;
+  const int r0 = sp * rows_per, r1 = min(M, r0 + rows_per);
+  float s = 0.f, ss = 0.f;
+  const long total = (long)(r1 - r0) * vec;
+  for (long i = threadIdx.x; i < total; i += 256) {
+    const int r = r0 + (int)(i / vec), v = (int)(i % vec);
+    const bf16x8 d = *reinterpret_cast<const bf16x8*>(x + (long)r * C + g * cpg + v * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float f = (float)d[j];
+      s += f; ss += f * f;
+    }
+  }
+  s = wave_sum(s); ss = wave_sum(ss);
+  __shared__ float red[2][4];
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s; red[1][threadIdx.x >> 6] = ss; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    ws[(g * GN_SPLITS + sp) * 2 + 0] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    ws[(g * GN_SPLITS + sp) * 2 + 1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+  }
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+
+__global__ __launch_bounds__(256) void k_gn_apply(const bf16* x, int M, int C, int cpg, int groups, const float* ws,
+                                                  const float* gamma, const float* beta, float eps, int act, bf16* y) {
+  __shared__ float s_mean[64], s_rstd[64];
+  if (threadIdx.x < groups) {
+    float s = 0.f, ss = 0.f;
+    for (int i = 0; i < GN_SPLITS; ++i) {
+      s += ws[(threadIdx.x * GN_SPLITS + i) * 2];
+      ss += ws[(threadIdx.x * GN_SPLITS + i) * 2 + 1];
+    }
+    const float n = (float)M * (float)cpg;
+    const float mean = s / n;
+    const float var = fmaxf(ss / n - mean * mean, 0.f);
+    s_mean[threadIdx.x] = mean;
+    s_rstd[threadIdx.x] = rsqrtf(var + eps);
+  }
+  __syncthreads();
+  const int vpr = C / 8;
+  const long total = (long)M * vpr;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c0 = (int)(i % vpr) * 8;
+    const int g = c0 / cpg;
+    const bf16x8 d = reinterpret_cast<const bf16x8*>(x)[i];
+    const float mean = s_mean[g], rstd = s_rstd[g];
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float f = ((float)d[j] - mean) * rstd * gamma[c0 + j] + beta[c0 + j];
+      if (act == 1) f = fmaxf(f, 0.f);
+      else if (act == 2) f = gelu_erf(f);
+      o[j] = (bf16)f;
+    }
+    reinterpret_cast<bf16x8*>(y)[i] = o;
+  }
+}
+
+// ------------------------------------------------------------------ depth-wise 5x5 (NHWC, pad 2)
+// thread = (pixel, 8 channels); weights pre-transposed to [25][C] fp32
+__global__ __launch_bounds__(256) void k_dwconv5(const bf16* x, const float* w, bf16* y, int H, int W, int C) {
+  const int vpr = C / 8;
+  const long total = (long)H * W * vpr;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int c0 = (int)(i % vpr) * 8;
+  const int pix = (int)(i / vpr);
+  const int py = pix / W, px = pix - py * W;
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  for (int dy = 0; dy < 5; ++dy) {
+    const int yy = py + dy - 2;
+    if ((unsigned)yy >= (unsigned)H) continue;
+    for (int dx = 0; dx < 5; ++dx) {
+      const int xx = px + dx - 2;
+      if ((unsigned)xx >= (unsigned)W) continue;
+      const bf16x8 d = *reinterpret_cast<const bf16x8*>(x + ((long)yy * W + xx) * C + c0);
+      const float* wt = w + (dy * 5 + dx) * C + c0;
+      const f32x4 w0 = *reinterpret_cast<const f32x4*>(wt), w1 = *reinterpret_cast<const f32x4*>(wt + 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { acc[j] += (float)d[j] * w0[j]; acc[4 + j] += (float)d[4 + j] * w1[j]; }
+    }
+  }
+  bf16x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = (bf16)acc[j];
+  reinterpret_cast<bf16x8*>(y)[i] = o;
+}
+
+}  // namespace
+
+extern "C" int rmem_layernorm256(const void* a, int a_is_f32, int lda, const void* b, int b_is_f32, int ldb,
+                                 const float* gamma, const float* beta, float eps, int M, void* y_bf16, int ldy,
+                                 const float* pos, void* ypos_bf16, int ldyp, float* y_f32, int ldyf, void* stream) {
+  RMEM_REQUIRE(a && gamma && beta && M > 0, "rmem_layernorm256: null argument");
+  RMEM_REQUIRE(y_bf16 || y_f32 || ypos_bf16, "rmem_layernorm256: no output requested");
+  RMEM_REQUIRE(lda % 4 == 0 && (!b || ldb % 4 == 0) && (!y_bf16 || ldy % 4 == 0) && (!ypos_bf16 || ldyp % 4 == 0) &&
+                   (!y_f32 || ldyf % 4 == 0), "rmem_layernorm256: leading dimensions must be multiples of 4");
+  RMEM_REQUIRE(!ypos_bf16 || pos, "rmem_layernorm256: ypos needs pos");
+  LnParams p{a, a_is_f32, lda, b, b_is_f32, ldb, gamma, beta, eps, M, (bf16*)y_bf16, ldy, pos, (bf16*)ypos_bf16, ldyp, y_f32, ldyf};
+  hipLaunchKernelGGL(k_layernorm256, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
+  return rmem_check_launch("rmem_layernorm256");
+}
+
+extern "C" int rmem_add_bf16(const void* a, const void* b, void* y, long long n, void* stream) {
+  RMEM_REQUIRE(a && b && y && n > 0 && n % 8 == 0, "rmem_add_bf16: n must be a positive multiple of 8");
+  const long n8 = n / 8;
+  const int blocks = (int)min((long)2048, (n8 + 255) / 256);
+  hipLaunchKernelGGL(k_add_bf16, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16*)a, (const bf16*)b, (bf16*)y, n8);
+  return rmem_check_launch("rmem_add_bf16");
+}
+
+extern "C" size_t rmem_groupnorm_workspace_bytes(int groups) { return (size_t)groups * GN_SPLITS * 2 * sizeof(float); }
+
+extern "C" int rmem_groupnorm_nhwc(const void* x, int M, int C, int groups, const float* gamma, const float* beta, float eps,
+                                   int act, void* y, float* workspace, void* stream) {
+  RMEM_REQUIRE(x && y && gamma && beta && workspace, "rmem_groupnorm_nhwc: null argument");
+  RMEM_REQUIRE(groups >= 1 && groups <= 64 && C % groups == 0 && (C / groups) % 8 == 0,
+               "rmem_groupnorm_nhwc: channels per group must be a multiple of 8 and groups <= 64");
+  RMEM_REQUIRE(act >= 0 && act <= 2 && M > 0, "rmem_groupnorm_nhwc: bad act / M");
+  const int cpg = C / groups;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_gn_stats, dim3(groups, GN_SPLITS), dim3(256), 0, s, (const bf16*)x, M, C, cpg, workspace);
+  const long total = (long)M * (C / 8);
+  const int blocks = (int)min((long)2048, (total + 255) / 256);
+  hipLaunchKernelGGL(k_gn_apply, dim3(blocks), dim3(256), 0, s, (const bf16*)x, M, C, cpg, groups, workspace, gamma, beta, eps, act, (bf16*)y);
+  return rmem_check_launch("rmem_groupnorm_nhwc");
+}
+
+extern "C" int rmem_dwconv5x5_nhwc(const void* x, const float* w_t, void* y, int H, int W, int C, void* stream) {
+  RMEM_REQUIRE(x && w_t && y && H > 0 && W > 0 && C % 8 == 0, "rmem_dwconv5x5_nhwc: bad argument");
+  const long total = (long)H * W * (C / 8);
+  hipLaunchKernelGGL(k_dwconv5, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, w_t, (bf16*)y, H, W, C);
+  return rmem_check_launch("rmem_dwconv5x5_nhwc");
+}

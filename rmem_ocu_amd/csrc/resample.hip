@@ -1,0 +1,225 @@
+// Layout / resampling kernels around the encoder, the FPN head and the engine
+// (all HBM-bound, one pass each):
+//   NCHW fp32 image -> NHWC8 bf16                      (input of encoders/resnet.py:179)
+//   3x3 stride-2 max-pool, NHWC                        (encoders/resnet.py:105, 182)
+//   bilinear resize NHWC bf16 (align_corners on/off)   (decoders/fpn.py:49-52, 57-60)
+//   logits: mask unused ids, bilinear to output size, NCHW fp32 + argmax labels
+//                                                      (engines/aot_engine.py:450-463; managers/evaluator.py:430-441)
+//   label map -> nearest resize -> one-hot(+ignore) NHWC16 bf16
+//                                                      (utils/image.py:69-74; aot_engine.py:208-224; evaluator.py:518-522)
+//   eviction scores: sum_q mass[q, t] * (1 - softmax(bilinear(logits))[0])
+//                                                      (aot_engine.py:355-362; layers/transformer.py:341-351)
+#include "common.h"
+#include "../../include/rmem.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void k_image_to_nhwc8(const float* img, bf16* out, int H, int W) {
+  const long n = (long)H * W;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  bf16x8 o = {0, 0, 0, 0, 0, 0, 0, 0};
+  o[0] = (bf16)img[i];
+  o[1] = (bf16)img[n + i];
+  o[2] = (bf16)img[2 * n + i];
+  reinterpret_cast<bf16x8*>(out)[i] = o;
+}
+
+__global__ __launch_bounds__(256) void k_maxpool3s2(const bf16* x, bf16* y, int H, int W, int C, int Ho, int Wo) {
+  const int vpr = C / 8;
+  const long total = (long)Ho * Wo * vpr;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int c0 = (int)(i % vpr) * 8;
+  const int pix = (int)(i / vpr);
+  const int oy = pix / Wo, ox = pix - oy * Wo;
+  float m[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) m[j] = -3.0e38f;
+  for (int dy = 0; dy < 3; ++dy) {
+    const int yy = oy * 2 - 1 + dy;
+    if ((unsigned)yy >= (unsigned)H) continue;
+    for (int dx = 0; dx < 3; ++dx) {
+      const int xx = ox * 2 - 1 + dx;
+      if ((unsigned)xx >= (unsigned)W) continue;
+      const bf16x8 d = *reinterpret_cast<const bf16x8*>(x + ((long)yy * W + xx) * C + c0);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) m[j] = fmaxf(m[j], (float)d[j]);
+    }
+  }
+  bf16x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = (bf16)m[j];
+  reinterpret_cast<bf16x8*>(y)[i] = o;
+}
+
+// source coordinate of destination index d (PyTorch upsample_bilinear2d semantics)
+__device__ __forceinline__ void src_coord(int d, int in, int out, int align, int& i0, int& i1, float& w1) {
+  float s;
+  if (align) s = out > 1 ? (float)d * ((float)(in - 1) / (float)(out - 1)) : 0.f;
+  else s = fmaxf(((float)d + 0.5f) * ((float)in / (float)out) - 0.5f, 0.f);
+  i0 = min((int)s, in - 1);
+  i1 = min(i0 + 1, in - 1);
+  w1 = s - (float)i0;
+}
+
+__global__ __launch_bounds__(256) void k_bilinear_nhwc(const bf16* x, bf16* y, int Hi, int Wi, int Ho, int Wo, int C, int align) {
+  const int vpr = C / 8;
+  const long total = (long)Ho * Wo * vpr;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int c0 = (int)(i % vpr) * 8;
+  const int pix = (int)(i / vpr);
+  const int oy = pix / Wo, ox = pix - oy * Wo;
+  int y0, y1, x0, x1; float wy, wx;
+  src_coord(oy, Hi, Ho, align, y0, y1, wy);
+  src_coord(ox, Wi, Wo, align, x0, x1, wx);
+  const bf16x8 a = *reinterpret_cast<const bf16x8*>(x + ((long)y0 * Wi + x0) * C + c0);
+  const bf16x8 b = *reinterpret_cast<const bf16x8*>(x + ((long)y0 * Wi + x1) * C + c0);
+  const bf16x8 c = *reinterpret_cast<const bf16x8*>(x + ((long)y1 * Wi + x0) * C + c0);
+  const bf16x8 d = *reinterpret_cast<const bf16x8*>(x + ((long)y1 * Wi + x1) * C + c0);
+  bf16x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float top = (float)a[j] * (1.f - wx) + (float)b[j] * wx;
+    const float bot = (float)c[j] * (1.f - wx) + (float)d[j] * wx;
+    o[j] = (bf16)(top * (1.f - wy) + bot * wy);
+  }
+  reinterpret_cast<bf16x8*>(y)[i] = o;
+}
+
+// logits NHWC fp32 [Hi][Wi][ldl] -> NCHW fp32 [nc][Ho][Wo] (optional) + argmax labels (optional)
+__global__ __launch_bounds__(256) void k_logits_post(const float* lg, int ldl, int nc, int keep, int Hi, int Wi, int Ho, int Wo,
+                                                     int align, float* out, uint8_t* label, float* label_f32) {
+  const long total = (long)Ho * Wo;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int oy = (int)(i / Wo), ox = (int)(i - (long)oy * Wo);
+  int y0, y1, x0, x1; float wy, wx;
+  src_coord(oy, Hi, Ho, align, y0, y1, wy);
+  src_coord(ox, Wi, Wo, align, x0, x1, wx);
+  const float* a = lg + ((long)y0 * Wi + x0) * ldl;
+  const float* b = lg + ((long)y0 * Wi + x1) * ldl;
+  const float* c = lg + ((long)y1 * Wi + x0) * ldl;
+  const float* d = lg + ((long)y1 * Wi + x1) * ldl;
+  float best = -3.0e38f; int arg = 0;
+  for (int ch = 0; ch < nc; ++ch) {
+    float v;
+    if (ch > keep) v = -1.0e10f;  // aot_engine.py:451-453
+    else {
+      const float top = a[ch] * (1.f - wx) + b[ch] * wx;
+      const float bot = c[ch] * (1.f - wx) + d[ch] * wx;
+      v = top * (1.f - wy) + bot * wy;
+    }
+    if (out) out[(long)ch * total + i] = v;
+    if (v > best) { best = v; arg = ch; }
+  }
+  if (label) label[i] = (uint8_t)arg;
+  if (label_f32) label_f32[i] = (float)arg;
+}
+
+// label [Hs][Ws] (uint8 or fp32) -> nearest resize to [Hd][Wd] -> one-hot NHWC16 bf16
+// channels 0..ncls-1 one-hot (channel 0 cleared where label == 255), channel ncls = ignore (label == 255)
+__global__ __launch_bounds__(256) void k_label_onehot(const void* lab, int lab_f32, int Hs, int Ws, int Hd, int Wd, int ncls, bf16* out) {
+  const long total = (long)Hd * Wd;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int y = (int)(i / Wd), x = (int)(i - (long)y * Wd);
+  const int sy = min((int)floorf((float)y * ((float)Hs / (float)Hd)), Hs - 1);   // F.interpolate(mode='nearest')
+  const int sx = min((int)floorf((float)x * ((float)Ws / (float)Wd)), Ws - 1);
+  const long si = (long)sy * Ws + sx;
+  const int v = lab_f32 ? (int)reinterpret_cast<const float*>(lab)[si] : (int)reinterpret_cast<const uint8_t*>(lab)[si];
+  bf16x8 lo = {0, 0, 0, 0, 0, 0, 0, 0}, hi = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int c = 0; c < 16; ++c) {
+    float f = 0.f;
+    if (c < ncls) f = (v == c) ? 1.f : 0.f;
+    else if (c == ncls) f = (v == 255) ? 1.f : 0.f;
+    if (c < 8) lo[c] = (bf16)f; else hi[c - 8] = (bf16)f;
+  }
+  reinterpret_cast<bf16x8*>(out)[2 * i] = lo;
+  reinterpret_cast<bf16x8*>(out)[2 * i + 1] = hi;
+}
+
+// scores[t] = sum_q mass[q][t] * fg[q],  fg = 1 - softmax(bilinear_ac(logits -> enc size))[0]
+// single block (HW ~ 1.7k tokens, T <= 32): deterministic
+__global__ __launch_bounds__(256) void k_evict_scores(const float* lg, int ldl, int nc, int keep, int Hi, int Wi, int He, int We,
+                                                      const float* mass, int T, float* scores) {
+  __shared__ float red[4][32];
+  float acc[32];
+#pragma unroll
+  for (int t = 0; t < 32; ++t) acc[t] = 0.f;
+  const int total = He * We;
+  for (int q = threadIdx.x; q < total; q += 256) {
+    const int oy = q / We, ox = q - oy * We;
+    int y0, y1, x0, x1; float wy, wx;
+    src_coord(oy, Hi, He, 1, y0, y1, wy);
+    src_coord(ox, Wi, We, 1, x0, x1, wx);
+    const float* a = lg + ((long)y0 * Wi + x0) * ldl;
+    const float* b = lg + ((long)y0 * Wi + x1) * ldl;
+    const float* c = lg + ((long)y1 * Wi + x0) * ldl;
+    const float* d = lg + ((long)y1 * Wi + x1) * ldl;
+    float v[16]; float mx = -3.0e38f;
+    for (int ch = 0; ch < nc; ++ch) {
+      float f;
+      if (ch > keep) f = -1.0e10f;
+      else f = (a[ch] * (1.f - wx) + b[ch] * wx) * (1.f - wy) + (c[ch] * (1.f - wx) + d[ch] * wx) * wy;
+      v[ch] = f; mx = fmaxf(mx, f);
+    }
+    float den = 0.f;
+    for (int ch = 0; ch < nc; ++ch) den += expf(v[ch] - mx);
+    const float fg = 1.f - expf(v[0] - mx) / den;
+    for (int t = 0; t < T; ++t) acc[t] += mass[(long)q * T + t] * fg;
+  }
+  for (int t = 0; t < T; ++t) {
+    const float s = wave_sum(acc[t]);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][t] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < T) scores[threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+inline unsigned nblk(long total) { return (unsigned)((total + 255) / 256); }
+
+}  // namespace
+
+extern "C" int rmem_image_to_nhwc8(const float* img_chw, void* out, int H, int W, void* stream) {
+  RMEM_REQUIRE(img_chw && out && H > 0 && W > 0, "rmem_image_to_nhwc8: bad argument");
+  hipLaunchKernelGGL(k_image_to_nhwc8, dim3(nblk((long)H * W)), dim3(256), 0, (hipStream_t)stream, img_chw, (bf16*)out, H, W);
+  return rmem_check_launch("rmem_image_to_nhwc8");
+}
+
+extern "C" int rmem_maxpool3x3s2_nhwc(const void* x, void* y, int H, int W, int C, void* stream) {
+  RMEM_REQUIRE(x && y && H > 0 && W > 0 && C % 8 == 0, "rmem_maxpool3x3s2_nhwc: bad argument");
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  hipLaunchKernelGGL(k_maxpool3s2, dim3(nblk((long)Ho * Wo * (C / 8))), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, (bf16*)y, H, W, C, Ho, Wo);
+  return rmem_check_launch("rmem_maxpool3x3s2_nhwc");
+}
+
+extern "C" int rmem_bilinear_nhwc(const void* x, void* y, int Hi, int Wi, int Ho, int Wo, int C, int align_corners, void* stream) {
+  RMEM_REQUIRE(x && y && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C % 8 == 0, "rmem_bilinear_nhwc: bad argument");
+  hipLaunchKernelGGL(k_bilinear_nhwc, dim3(nblk((long)Ho * Wo * (C / 8))), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, (bf16*)y, Hi, Wi, Ho, Wo, C, align_corners);
+  return rmem_check_launch("rmem_bilinear_nhwc");
+}
+
+extern "C" int rmem_logits_post(const float* logits_nhwc, int ldl, int num_classes, int keep_max_id, int Hi, int Wi, int Ho, int Wo,
+                                int align_corners, float* out_nchw, unsigned char* label_u8, float* label_f32, void* stream) {
+  RMEM_REQUIRE(logits_nhwc && num_classes >= 1 && num_classes <= 16 && ldl >= num_classes, "rmem_logits_post: bad argument");
+  RMEM_REQUIRE(out_nchw || label_u8 || label_f32, "rmem_logits_post: no output requested");
+  hipLaunchKernelGGL(k_logits_post, dim3(nblk((long)Ho * Wo)), dim3(256), 0, (hipStream_t)stream, logits_nhwc, ldl, num_classes, keep_max_id,
+                     Hi, Wi, Ho, Wo, align_corners, out_nchw, label_u8, label_f32);
+  return rmem_check_launch("rmem_logits_post");
+}
+
+extern "C" int rmem_label_to_onehot16(const void* label, int label_is_f32, int Hs, int Ws, int Hd, int Wd, int num_classes, void* out, void* stream) {
+  RMEM_REQUIRE(label && out && Hs > 0 && Ws > 0 && Hd > 0 && Wd > 0 && num_classes >= 1 && num_classes <= 15, "rmem_label_to_onehot16: bad argument");
+  hipLaunchKernelGGL(k_label_onehot, dim3(nblk((long)Hd * Wd)), dim3(256), 0, (hipStream_t)stream, label, label_is_f32, Hs, Ws, Hd, Wd, num_classes, (bf16*)out);
+  return rmem_check_launch("rmem_label_to_onehot16");
+}
+
+extern "C" int rmem_evict_scores(const float* logits_nhwc, int ldl, int num_classes, int keep_max_id, int Hi, int Wi, int He, int We,
+                                 const float* attn_mass, int T, float* scores, void* stream) {
+  RMEM_REQUIRE(logits_nhwc && attn_mass && scores && T >= 1 && T <= 32 && num_classes >= 1 && num_classes <= 16, "rmem_evict_scores: bad argument");
+  hipLaunchKernelGGL(k_evict_scores, dim3(1), dim3(256), 0, (hipStream_t)stream, logits_nhwc, ldl, num_classes, keep_max_id, Hi, Wi, He, We, attn_mass, T, scores);
+  return rmem_check_launch("rmem_evict_scores");
+}

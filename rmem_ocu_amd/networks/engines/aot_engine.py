@@ -1,0 +1,339 @@
+"""Per-clip inference engines with the reference's method surface.
+
+``AOTEngine`` mirrors networks/engines/aot_engine.py:18-568 (inference half) and
+``AOTInferEngine`` mirrors 571-725: same method names, arguments, attributes
+(``long_term_mem_gap, input_size_2d, enc_size_2d, enc_hw, long_memories_indexes``) and
+error behaviour; the math runs as HIP launch lists (rmem_ocu_amd.runtime).  What stays on
+the host is exactly what the reference keeps in Python: the frame counter, the
+"append every ``gap`` frames" rule (338-343), and the restricted-memory eviction policy
+(layers/transformer.py:324-436), restated in ``MemoryPolicy``.
+
+Differences by design: clip state is engine-owned (the reference stores it in
+the shared model); bs = 1 per engine (the reference asserts it in eval,
+layers/transformer.py:641); the attention-weight top-32 D2H of every layer
+(transformer.py:644-648) is not produced (only dead code consumed it).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from ... import ops
+from ...runtime import ClipRuntime
+
+F32 = torch.float32
+
+
+class MemoryPolicy:
+    """Which bank entry to evict (layers/transformer.py:338-411, eval branch).
+
+    Inputs are the per-memory-frame attention mass of layer 0 weighted by the
+    foreground probability (already reduced over tokens on the device); the EMA (0.8) with the
+    stored score of the same frame index, the UCB bonus 1.5*sqrt(log(sum n)/(n_i+8)) with
+    n_0 := T', and the argmin over entries >= 1 are evaluated here in fp32 torch CPU ops,
+    the same arithmetic the reference runs.
+    """
+
+    def __init__(self):
+        self.ema: Dict[int, torch.Tensor] = {}
+        self.visits: Dict[int, int] = {}
+
+    def choose(self, scores: torch.Tensor, indexes: List[int]) -> int:
+        a = (scores / scores.sum()).clone()
+        cur = {indexes[i]: a[i].clone() for i in range(a.shape[0])}
+        cur = {k: ((1 - 0.8) * self.ema[k] + 0.8 * v) if k in self.ema else v for k, v in cur.items()}
+        self.ema = cur
+        for i in range(a.shape[0]):
+            a[i] = cur[indexes[i]]
+        self.visits = {k: 1 + self.visits.get(k, 0) for k in indexes}
+        n = torch.tensor([float(self.visits[k]) for k in indexes[:-1]])
+        n[0] = len(n)
+        a = a + 1.5 * torch.sqrt(torch.log(n.sum()) / (n + 8))
+        rest = a[1:]
+        return int(torch.argmin(rest).item()) + 1 if rest.shape[0] > 0 else 1
+
+
+class AOTEngine:
+    def __init__(self, aot_model, gpu_id=0, long_term_mem_gap=9999, short_term_mem_skip=1):
+        self.cfg = aot_model.cfg
+        self.align_corners = aot_model.cfg.MODEL_ALIGN_CORNERS
+        self.AOT = aot_model
+        self.max_obj_num = aot_model.max_obj_num
+        self.gpu_id = gpu_id
+        self.long_term_mem_gap = long_term_mem_gap
+        self.short_term_mem_skip = short_term_mem_skip
+        if short_term_mem_skip != 1:
+            raise NotImplementedError('short_term_mem_skip != 1 is not used by the reference evaluator')
+        self.device = torch.device('cuda', gpu_id)
+        self.rt: Optional[ClipRuntime] = None
+        self.use_graphs = False
+        self._graphs: Dict[str, ops.Graph] = {}
+        self.restart_engine()
+
+    # ------------------------------------------------------------------ state
+    def restart_engine(self, batch_size=1, enable_id_shuffle=False):
+        if batch_size != 1 or enable_id_shuffle:
+            raise NotImplementedError('inference engine: batch_size 1, no id shuffle (layers/transformer.py:641)')
+        self.batch_size = 1
+        self.frame_step = 0
+        self.last_mem_step = -1
+        self.obj_nums = None
+        self.input_size_2d = None
+        self.enc_size_2d = None
+        self.enc_hw = None
+        self.long_memories_indexes: List[int] = []
+        self.policy = MemoryPolicy()
+        self.drop_trace: List[int] = []
+        self.pred_id_logits = None
+        self._T_at_propagate = 0
+        if self.rt is not None:
+            self.rt.reset_bank()
+
+    def eval(self):
+        return self
+
+    def update_size(self, input_size, enc_size):
+        self.input_size_2d = tuple(int(v) for v in input_size)
+        self.enc_size_2d = tuple(int(v) for v in enc_size)
+        self.enc_hw = self.enc_size_2d[0] * self.enc_size_2d[1]
+
+    def _stream(self) -> int:
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def _ensure_runtime(self, img):
+        H, W = int(img.shape[-2]), int(img.shape[-1])
+        n = self.cfg.FORMER_MEM_LEN + self.cfg.LATTER_MEM_LEN
+        slots = n + 1 if n < 64 else 16            # +1: the bank holds N+1 entries between append and eviction
+        if self.rt is None or (self.rt.H, self.rt.W) != (H, W):
+            self.rt = ClipRuntime(self.AOT.packed(), (H, W), slots, self.device, self.cfg.MODEL_LSTT_NUM,
+                                  self.align_corners, self.max_obj_num + 1)
+            self.img_in = torch.empty(3, H, W, dtype=F32, device=self.device)
+            self.label_in = torch.empty(H, W, dtype=F32, device=self.device)
+            self._graphs = {}
+        return self.rt
+
+    def _run(self, key: str, prog: list):
+        s = self._stream()
+        if self.use_graphs:
+            g = self._graphs.get(key)
+            if g is None:
+                ops.run(prog, s)               # warm run (first-touch, lazy module load) outside capture
+                g = self._graphs[key] = ops.Graph(prog, s)
+            else:
+                g(s)
+        else:
+            ops.run(prog, s)
+
+    def _set_label(self, mask):
+        m = mask.reshape(mask.shape[-2], mask.shape[-1])
+        if tuple(m.shape) != (self.rt.H, self.rt.W):
+            raise ValueError(f'mask must be at the network size {(self.rt.H, self.rt.W)}, got {tuple(m.shape)}')
+        self.label_in.copy_(m, non_blocking=True)
+
+    # ------------------------------------------------------------------ reference frame
+    def add_reference_frame(self, img=None, mask=None, frame_step=-1, obj_nums=None, img_embs=None):
+        if self.obj_nums is None and obj_nums is None:
+            print('No objects for reference frame!')
+            exit()
+        elif obj_nums is not None:
+            self.obj_nums = obj_nums
+        if frame_step == -1:
+            frame_step = self.frame_step
+        if img is None:
+            print('No image for reference frame!')
+            exit()
+        if mask is None:
+            print('No mask for reference frame!')
+            exit()
+        rt = self._ensure_runtime(img)
+        if self.input_size_2d is None:
+            self.update_size(img.shape[2:], (rt.H16, rt.W16))
+        self.img_in.copy_(img.reshape(3, rt.H, rt.W), non_blocking=True)
+        self._set_label(mask)
+        s = self._stream()
+        # (re)initialise the bank to this frame only (aot_engine.py:322; quirk: long_memories_indexes keeps growing, 323)
+        rt.reset_bank()
+        slot = rt.take_slot()
+        rt.slots.append(slot)
+        rt.upload_chunks(s)
+        self._run('encode', rt.prog_encode(self.img_in))
+        self._run('id_label_in', rt.prog_id_emb(self.label_in, rt.H, rt.W))
+        self._run(f'lstt_ref{slot}', rt.prog_lstt(True, 1, slot))
+        self.last_mem_step = frame_step
+        self.policy = MemoryPolicy()
+        self.long_memories_indexes.append(self.frame_step)
+        self._run('decode', rt.prog_decode())
+        self.pred_id_logits = rt.logits
+
+    # ------------------------------------------------------------------ propagate
+    def match_propogate_one_frame(self, img=None, img_embs=None, mask=None, output_size=None):
+        self.frame_step += 1
+        if img is None:
+            raise ValueError('match_propogate_one_frame needs the frame (offline encoding is a training-only path)')
+        rt = self.rt
+        self.img_in.copy_(img.reshape(3, rt.H, rt.W), non_blocking=True)
+        T = len(rt.slots)
+        self._T_at_propagate = T
+        self._run('encode', rt.prog_encode(self.img_in))
+        self._run(f'lstt_prop{T}', rt.prog_lstt(False, T))
+        self._run('decode', rt.prog_decode())
+        self.pred_id_logits = rt.logits
+        return self.decode_current_logits(output_size)
+
+    def decode_current_logits(self, output_size=None):
+        """Logits with unused ids masked (aot_engine.py:450-453), resized to output_size (457-463)."""
+        rt = self.rt
+        Ho, Wo = (rt.H4, rt.W4) if output_size is None else (int(output_size[0]), int(output_size[1]))
+        out = torch.empty(1, rt.nc, Ho, Wo, dtype=F32, device=self.device)
+        keep = self.obj_nums[0] if self.obj_nums else self.max_obj_num
+        ops.run(ops.logits_post(rt.logits, ldl=16, nc=rt.nc, keep=keep, Hi=rt.H4, Wi=rt.W4, Ho=Ho, Wo=Wo,
+                                align_corners=self.align_corners, out=out), self._stream())
+        return out
+
+    def predict_current_mask(self, output_size=None, return_prob=False):
+        """aot_engine.py:467-483."""
+        if output_size is None:
+            output_size = self.input_size_2d
+        logits = self.decode_current_logits(output_size)
+        pred_mask = torch.argmax(logits, dim=1)
+        return (pred_mask, torch.softmax(logits, dim=1)) if return_prob else pred_mask
+
+    # ------------------------------------------------------------------ memory update
+    def update_short_term_memory(self, curr_mask, curr_id_emb=None, step=0):
+        if curr_id_emb is not None:
+            raise NotImplementedError('update_short_term_memory takes the label mask')
+        rt = self.rt
+        if curr_mask.dim() == 4 and curr_mask.shape[1] != 1:
+            raise NotImplementedError('probability masks (>10 objects soft aggregation) are not built yet')
+        self._set_label(curr_mask)
+        self._run('id_label_in', rt.prog_id_emb(self.label_in, rt.H, rt.W))
+        self._finish_update()
+
+    def update_memory_from_label_u8(self, label_u8: torch.Tensor):
+        """Fast path: argmax labels at the OUTPUT size (uint8 [Ho, Wo], device); the nearest resize to the
+        network size (evaluator.py:518-522) happens inside the one-hot kernel."""
+        rt = self.rt
+        hs, ws = int(label_u8.shape[-2]), int(label_u8.shape[-1])
+        self._run(f'id_u8_{label_u8.data_ptr()}', rt.prog_id_emb(label_u8, hs, ws))
+        self._finish_update()
+
+    def _finish_update(self):
+        rt, s = self.rt, self._stream()
+        update_long = (not getattr(self.cfg, 'NO_LONG_MEMORY', False)) and \
+            (self.frame_step - self.last_mem_step >= self.long_term_mem_gap)
+        slot = None
+        if update_long:
+            self.last_mem_step = self.frame_step
+            slot = rt.take_slot()
+        if slot is None:
+            self._run('update_None', rt.prog_update(None))
+        else:
+            ops.run(rt.prog_update(slot), s)
+        if not update_long:
+            return
+        rt.slots.append(slot)
+        self.long_memories_indexes.append(self.frame_step)
+        n_keep = self.cfg.FORMER_MEM_LEN + self.cfg.LATTER_MEM_LEN
+        if len(rt.slots) > n_keep:
+            Tp = self._T_at_propagate
+            keep = self.obj_nums[0] if self.obj_nums else self.max_obj_num
+            ops.run(ops.evict_scores(rt.logits, rt.mass, rt.scores, ldl=16, nc=rt.nc, keep=keep, Hi=rt.H4, Wi=rt.W4,
+                                     He=rt.H16, We=rt.W16, T=Tp), s)
+            scores = rt.scores[:Tp].cpu()           # the one host sync of the policy (the reference has it too, transformer.py:353)
+            drop = self.policy.choose(scores, self.long_memories_indexes)
+            self.drop_trace.append(drop)
+            rt.free.append(rt.slots.pop(drop))
+            del self.long_memories_indexes[drop]
+        rt.upload_chunks(s)
+
+
+class AOTInferEngine:
+    def __init__(self, aot_model, gpu_id=0, long_term_mem_gap=9999, short_term_mem_skip=1, max_aot_obj_num=None):
+        self.cfg = aot_model.cfg
+        self.AOT = aot_model
+        if max_aot_obj_num is None or max_aot_obj_num > aot_model.max_obj_num:
+            self.max_aot_obj_num = aot_model.max_obj_num
+        else:
+            self.max_aot_obj_num = max_aot_obj_num
+        self.gpu_id = gpu_id
+        self.long_term_mem_gap = long_term_mem_gap
+        self.short_term_mem_skip = short_term_mem_skip
+        self.use_graphs = False
+        self.aot_engines: List[AOTEngine] = []
+        self._pool: List[AOTEngine] = []
+        self.restart_engine()
+
+    def eval(self):
+        return self
+
+    def restart_engine(self):
+        for engine in self.aot_engines:
+            engine.restart_engine()
+        self._pool = self.aot_engines + [e for e in self._pool if e not in self.aot_engines]
+        self.aot_engines = []
+        self.obj_nums = None
+
+    def separate_mask(self, mask):
+        """aot_engine.py:604-628 (label-map branch)."""
+        if mask is None:
+            return [None] * len(self.aot_engines)
+        if len(self.aot_engines) == 1:
+            return [mask]
+        if mask.dim() == 3 or mask.shape[0] == 1:
+            out = []
+            for idx in range(len(self.aot_engines)):
+                start_id = idx * self.max_aot_obj_num + 1
+                end_id = (idx + 1) * self.max_aot_obj_num
+                fg = ((mask >= start_id) & (mask <= end_id)).float()
+                out.append((fg * mask - start_id + 1) * fg)
+            return out
+        raise NotImplementedError('probability masks for >10 objects')
+
+    def soft_logit_aggregation(self, all_logits):
+        """aot_engine.py:650-673."""
+        if len(all_logits) == 1:
+            return all_logits[0]
+        fg_probs, bg_probs = [], []
+        for logit in all_logits:
+            prob = torch.softmax(logit, dim=1)
+            bg_probs.append(prob[:, 0:1])
+            fg_probs.append(prob[:, 1:1 + self.max_aot_obj_num])
+        bg_prob = torch.prod(torch.cat(bg_probs, dim=1), dim=1, keepdim=True)
+        merged = torch.cat([bg_prob] + fg_probs, dim=1).clamp(1e-5, 1 - 1e-5)
+        return torch.logit(merged)
+
+    def add_reference_frame(self, img, mask, obj_nums, frame_step=-1):
+        if isinstance(obj_nums, list):
+            obj_nums = obj_nums[0]
+        aot_num = max(np.ceil(obj_nums / self.max_aot_obj_num), 1)
+        while aot_num > len(self.aot_engines):
+            if self._pool:
+                eng = self._pool.pop(0)           # reuse device buffers of an earlier clip
+                eng.long_term_mem_gap = self.long_term_mem_gap
+            else:
+                eng = AOTEngine(self.AOT, self.gpu_id, self.long_term_mem_gap, self.short_term_mem_skip)
+            eng.use_graphs = self.use_graphs
+            self.aot_engines.append(eng)
+        for eng, m in zip(self.aot_engines, self.separate_mask(mask)):
+            eng.add_reference_frame(img, m, obj_nums=[self.max_aot_obj_num], frame_step=frame_step)
+        self.update_size()
+
+    def match_propogate_one_frame(self, img=None, mask=None, output_size=None):
+        all_logits = [e.match_propogate_one_frame(img, mask=mask, output_size=output_size) for e in self.aot_engines]
+        return self.soft_logit_aggregation(all_logits)
+
+    def update_memory(self, curr_mask):
+        for eng, m in zip(self.aot_engines, self.separate_mask(curr_mask)):
+            eng.update_short_term_memory(m)
+
+    def update_size(self):
+        self.input_size_2d = self.aot_engines[0].input_size_2d
+        self.enc_size_2d = self.aot_engines[0].enc_size_2d
+        self.enc_hw = self.aot_engines[0].enc_hw
+
+    @property
+    def long_memories_indexes(self):
+        return self.aot_engines[0].long_memories_indexes

@@ -1,0 +1,86 @@
+"""AOT model object: the reference's parameter tree, executed by the HIP runtime.
+
+Mirrors networks/models/aot.py:12-105 at the interface level: the same attributes
+(``encoder, encoder_projector, LSTT, decoder, patch_wise_id_bank, cur_pos_emb,
+mem_pos_emb, cfg, max_obj_num``) and the same 362 ``state_dict`` keys, so a reference
+checkpoint loads with ``load_state_dict`` / utils/checkpoint.py:75-104 unchanged.
+The modules are parameter containers only: no torch op runs in ``forward``; the
+per-frame math is the launch lists of rmem_ocu_amd.runtime.ClipRuntime over
+``packed()`` (BN-folded, bf16, NHWC weights).  Unlike the reference (which keeps the
+clip's LSTT memory inside the shared model, layers/transformer.py:455-463), clip
+state lives in the engine, so one weight set serves many clips per GPU.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+import torch.nn as nn
+
+from ...pack import pack_state_dict
+from ...weights import synth_state_dict
+
+_BUFFER_SUFFIXES = ('running_mean', 'running_var')
+
+
+class _Node(nn.Module):
+    """Nested parameter container addressed by the reference's dotted key names."""
+
+    def __getitem__(self, idx):
+        return getattr(self, str(idx))
+
+
+def _attach(root: nn.Module, key: str, value: torch.Tensor):
+    parts = key.split('.')
+    node = root
+    for p in parts[:-1]:
+        if not hasattr(node, p):
+            node.add_module(p, _Node())
+        node = getattr(node, p)
+    leaf = parts[-1]
+    # FrozenBatchNorm2d keeps all four tensors as buffers (layers/normalization.py:13-16)
+    is_bn = any(k in key for k in ('.bn1.', '.bn2.', '.bn3.', '.downsample.1.')) and key.startswith('encoder.')
+    if leaf in _BUFFER_SUFFIXES or is_bn:
+        node.register_buffer(leaf, value.clone())
+    else:
+        node.register_parameter(leaf, nn.Parameter(value.clone(), requires_grad=False))
+
+
+class AOT(nn.Module):
+    def __init__(self, cfg, encoder='resnet50', decoder='fpn'):
+        super().__init__()
+        if encoder != 'resnet50' or decoder != 'fpn':
+            raise NotImplementedError('only the resnet50 encoder + fpn decoder of R50-AOTL are built')
+        if cfg.MODEL_LINEAR_Q:
+            raise NotImplementedError('MODEL_LINEAR_Q=True: the reference eval path itself crashes there '
+                                      '(layers/transformer.py:650-665); use the pre_vost setting False')
+        self.cfg = cfg
+        self.max_obj_num = cfg.MODEL_MAX_OBJ_NUM
+        self.epsilon = cfg.MODEL_EPSILON
+        self.use_temporal_pe = cfg.USE_TEMPORAL_POSITIONAL_EMBEDDING
+        # same construction-time randomness contract as the reference: fresh weights unless loaded
+        for k, v in synth_state_dict(0, cfg.MODEL_LSTT_NUM, cfg.MODEL_ENCODER_EMBEDDING_DIM, cfg.MODEL_MAX_OBJ_NUM).items():
+            _attach(self, k, v)
+        self._packed: Optional[Dict[str, torch.Tensor]] = None
+        self._packed_device = None
+        self._runtimes = {}
+
+    # -- weights ------------------------------------------------------------
+    def load_state_dict(self, state_dict, strict: bool = True, **kw):
+        self._packed = None
+        self._runtimes = {}
+        return super().load_state_dict(state_dict, strict=strict, **kw)
+
+    def packed(self) -> Dict[str, torch.Tensor]:
+        dev = self.cur_pos_emb.device
+        if self._packed is None or self._packed_device != dev:
+            if dev.type != 'cuda':
+                raise RuntimeError('the HIP engine needs the model on a GPU: call model.cuda(gpu_id) '
+                                   '(there is no CPU execution path in this package)')
+            self._packed = pack_state_dict(self.state_dict(), dev, self.cfg.MODEL_LSTT_NUM)
+            self._packed_device = dev
+            self._runtimes = {}
+        return self._packed
+
+    def forward(self, *a, **k):
+        raise RuntimeError('AOT is driven through build_engine(...): add_reference_frame / match_propogate_one_frame / update_memory')

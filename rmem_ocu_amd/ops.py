@@ -1,0 +1,202 @@
+"""Prepared launches of the librmem_hip.so kernels on torch device tensors.
+
+Every function validates shapes/dtypes on the host ONCE and returns an ``Op``: a C
+function plus its fully marshalled argument tuple.  ``op(stream)`` only enqueues; a
+frame is a list of Ops replayed every frame (or captured into a hipGraph once),
+which keeps Python out of the per-frame critical path.  torch is used for device
+memory and streams only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import torch
+
+from . import _lib
+from ._lib import AttnChunk, ConvDesc, RmemError
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+
+
+class Op:
+    __slots__ = ('fn', 'args', 'name', 'keep')
+
+    def __init__(self, fn, args, name, keep=()):
+        self.fn, self.args, self.name, self.keep = fn, args, name, keep
+
+    def __call__(self, stream: int):
+        rc = self.fn(*self.args, stream)
+        if rc:
+            raise RmemError(f'{self.name} failed ({rc}): {_lib.lib().rmem_last_error_string().decode()}')
+
+
+def run(ops, stream: Optional[int] = None):
+    """Enqueue one Op or a list of Ops on ``stream`` (default: torch's current stream)."""
+    if stream is None:
+        stream = torch.cuda.current_stream().cuda_stream
+    if isinstance(ops, Op):
+        ops(stream)
+    else:
+        for o in ops:
+            o(stream)
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _dev(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RmemError('librmem_hip ops need device tensors (no CPU fallback)')
+
+
+def conv2d(x, w, bias, y, *, H, W, Cin, Cout, KH=1, KW=1, stride=1, pad=0, residual=None, y2=None, relu=False,
+           ldo=None, ldr=None, ld2=None) -> Op:
+    """y = act(conv(x, w) + bias (+ residual)); w is [Cout, KH, KW, Cin] bf16, x NHWC bf16."""
+    _dev(x, w, bias, y, residual, y2)
+    assert x.dtype == BF16 and w.dtype == BF16 and w.is_contiguous()
+    assert w.numel() == Cout * KH * KW * Cin, (w.shape, Cout, KH, KW, Cin)
+    assert bias is None or (bias.dtype == F32 and bias.numel() == Cout)
+    assert y.dtype in (BF16, F32) and (y2 is None or y2.dtype == BF16)
+    Ho = (H + 2 * pad - KH) // stride + 1
+    Wo = (W + 2 * pad - KW) // stride + 1
+    ldo = Cout if ldo is None else ldo
+    ldr = Cout if ldr is None else ldr
+    ld2 = Cout if ld2 is None else ld2
+    assert x.numel() >= H * W * Cin and y.numel() >= (Ho * Wo - 1) * ldo + Cout
+    d = ConvDesc(H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, ldo, ldr, ld2, int(relu), int(y.dtype == F32),
+                 int(residual is not None and residual.dtype == F32))
+    args = (C.byref(d), _ptr(x), _ptr(w), _ptr(bias), _ptr(residual), _ptr(y), _ptr(y2))
+    return Op(_lib.lib().rmem_conv2d_nhwc, args, 'rmem_conv2d_nhwc', (d, x, w, bias, residual, y, y2))
+
+
+def linear(x, w, bias, y, *, M, K, N, residual=None, y2=None, relu=False, ldo=None, ldr=None, ld2=None) -> Op:
+    """y[M, N] = x[M, K] @ w[N, K]^T + bias: the 1x1 case of conv2d (x rows contiguous with stride K)."""
+    return conv2d(x, w, bias, y, H=M, W=1, Cin=K, Cout=N, residual=residual, y2=y2, relu=relu, ldo=ldo, ldr=ldr, ld2=ld2)
+
+
+def attn_workspace(Lq: int, heads: int, nchunks: int, device) -> torch.Tensor:
+    n = _lib.lib().rmem_attn_workspace_bytes(Lq, heads, nchunks)
+    return torch.empty(n // 4, dtype=F32, device=device)
+
+
+def make_chunk_table(chunks: Sequence[Sequence[int]]) -> torch.Tensor:
+    """Host int32 [n, 8] table from (slot, key_begin, key_count, pe_slot, t) rows."""
+    t = torch.zeros(len(chunks), 8, dtype=torch.int32)
+    for i, c in enumerate(chunks):
+        t[i, :5] = torch.tensor(list(c), dtype=torch.int32)
+    return t
+
+
+def mem_read_attn(q, k_bank, v_bank, out, workspace, *, Lq, heads=8, ldq, ldkv, ldo, slot_stride=0, chunks=None,
+                  nchunks=1, lk_single=0, pe_cur=None, pe_mem=None, mass=None, T=0) -> Op:
+    _dev(q, k_bank, v_bank, out, workspace, chunks, pe_cur, pe_mem, mass)
+    assert q.dtype == BF16 and k_bank.dtype == BF16 and v_bank.dtype == BF16 and out.dtype == BF16
+    assert workspace.numel() * 4 >= _lib.lib().rmem_attn_workspace_bytes(Lq, heads, nchunks)
+    assert chunks is None or (chunks.dtype == torch.int32 and chunks.numel() >= nchunks * 8)
+    assert mass is None or (mass.dtype == F32 and mass.numel() >= Lq * T)
+    args = (_ptr(q), ldq, _ptr(k_bank), _ptr(v_bank), slot_stride, ldkv, _ptr(chunks), nchunks, lk_single,
+            _ptr(pe_cur), _ptr(pe_mem), Lq, heads, _ptr(out), ldo, _ptr(mass), T, _ptr(workspace))
+    return Op(_lib.lib().rmem_mem_read_attn, args, 'rmem_mem_read_attn',
+              (q, k_bank, v_bank, out, workspace, chunks, pe_cur, pe_mem, mass))
+
+
+def layernorm256(a, gamma, beta, *, M, lda=256, b=None, ldb=256, y=None, ldy=256, pos=None, ypos=None, ldyp=256,
+                 yf=None, ldyf=256, eps=1e-5) -> Op:
+    _dev(a, b, gamma, beta, y, pos, ypos, yf)
+    assert a.dtype in (BF16, F32) and (b is None or b.dtype in (BF16, F32))
+    assert gamma.dtype == F32 and beta.dtype == F32 and gamma.numel() == 256
+    assert (y is None or y.dtype == BF16) and (ypos is None or ypos.dtype == BF16) and (yf is None or yf.dtype == F32)
+    args = (_ptr(a), int(a.dtype == F32), lda, _ptr(b), int(b is not None and b.dtype == F32), ldb, _ptr(gamma), _ptr(beta),
+            eps, M, _ptr(y), ldy, _ptr(pos), _ptr(ypos), ldyp, _ptr(yf), ldyf)
+    return Op(_lib.lib().rmem_layernorm256, args, 'rmem_layernorm256', (a, b, gamma, beta, y, pos, ypos, yf))
+
+
+def add_bf16(a, b, y, n: int) -> Op:
+    _dev(a, b, y)
+    assert a.dtype == BF16 and b.dtype == BF16 and y.dtype == BF16
+    return Op(_lib.lib().rmem_add_bf16, (_ptr(a), _ptr(b), _ptr(y), n), 'rmem_add_bf16', (a, b, y))
+
+
+def groupnorm_workspace(groups: int, device) -> torch.Tensor:
+    return torch.empty(_lib.lib().rmem_groupnorm_workspace_bytes(groups) // 4, dtype=F32, device=device)
+
+
+def groupnorm(x, gamma, beta, y, ws, *, M, C, groups, act=0, eps=1e-5) -> Op:
+    _dev(x, gamma, beta, y, ws)
+    assert x.dtype == BF16 and y.dtype == BF16 and gamma.dtype == F32 and gamma.numel() == C
+    args = (_ptr(x), M, C, groups, _ptr(gamma), _ptr(beta), eps, act, _ptr(y), _ptr(ws))
+    return Op(_lib.lib().rmem_groupnorm_nhwc, args, 'rmem_groupnorm_nhwc', (x, gamma, beta, y, ws))
+
+
+def dwconv5x5(x, w_t, y, *, H, W, C) -> Op:
+    _dev(x, w_t, y)
+    assert x.dtype == BF16 and y.dtype == BF16 and w_t.dtype == F32 and w_t.numel() == 25 * C
+    return Op(_lib.lib().rmem_dwconv5x5_nhwc, (_ptr(x), _ptr(w_t), _ptr(y), H, W, C), 'rmem_dwconv5x5_nhwc', (x, w_t, y))
+
+
+def image_to_nhwc8(img, out, *, H, W) -> Op:
+    _dev(img, out)
+    assert img.dtype == F32 and img.is_contiguous() and img.numel() == 3 * H * W and out.dtype == BF16
+    return Op(_lib.lib().rmem_image_to_nhwc8, (_ptr(img), _ptr(out), H, W), 'rmem_image_to_nhwc8', (img, out))
+
+
+def maxpool3x3s2(x, y, *, H, W, C) -> Op:
+    _dev(x, y)
+    return Op(_lib.lib().rmem_maxpool3x3s2_nhwc, (_ptr(x), _ptr(y), H, W, C), 'rmem_maxpool3x3s2_nhwc', (x, y))
+
+
+def bilinear(x, y, *, Hi, Wi, Ho, Wo, C, align_corners=True) -> Op:
+    _dev(x, y)
+    assert x.dtype == BF16 and y.dtype == BF16
+    return Op(_lib.lib().rmem_bilinear_nhwc, (_ptr(x), _ptr(y), Hi, Wi, Ho, Wo, C, int(align_corners)), 'rmem_bilinear_nhwc', (x, y))
+
+
+def logits_post(logits, *, ldl, nc, keep, Hi, Wi, Ho, Wo, align_corners=True, out=None, label_u8=None, label_f32=None) -> Op:
+    _dev(logits, out, label_u8, label_f32)
+    assert logits.dtype == F32 and (out is None or out.dtype == F32) and (label_u8 is None or label_u8.dtype == torch.uint8)
+    args = (_ptr(logits), ldl, nc, keep, Hi, Wi, Ho, Wo, int(align_corners), _ptr(out), _ptr(label_u8), _ptr(label_f32))
+    return Op(_lib.lib().rmem_logits_post, args, 'rmem_logits_post', (logits, out, label_u8, label_f32))
+
+
+def label_to_onehot16(label, out, *, Hs, Ws, Hd, Wd, ncls=11) -> Op:
+    _dev(label, out)
+    assert label.dtype in (torch.uint8, F32) and label.is_contiguous() and out.dtype == BF16
+    args = (_ptr(label), int(label.dtype == F32), Hs, Ws, Hd, Wd, ncls, _ptr(out))
+    return Op(_lib.lib().rmem_label_to_onehot16, args, 'rmem_label_to_onehot16', (label, out))
+
+
+def evict_scores(logits, mass, scores, *, ldl, nc, keep, Hi, Wi, He, We, T) -> Op:
+    _dev(logits, mass, scores)
+    args = (_ptr(logits), ldl, nc, keep, Hi, Wi, He, We, _ptr(mass), T, _ptr(scores))
+    return Op(_lib.lib().rmem_evict_scores, args, 'rmem_evict_scores', (logits, mass, scores))
+
+
+class Graph:
+    """A captured launch list (hipGraph) replayable on any stream."""
+
+    def __init__(self, ops, stream: int):
+        L = _lib.lib()
+        _lib.check(L.rmem_graph_begin(stream), 'rmem_graph_begin')
+        try:
+            for o in ops:
+                o(stream)
+        finally:
+            h = C.c_void_p()
+            rc = L.rmem_graph_end(stream, C.byref(h))
+        _lib.check(rc, 'rmem_graph_end')
+        self.handle = h
+        self.keep = ops
+
+    def __call__(self, stream: int):
+        _lib.check(_lib.lib().rmem_graph_launch(self.handle, stream), 'rmem_graph_launch')
+
+    def __del__(self):
+        try:
+            if self.handle:
+                _lib.lib().rmem_graph_destroy(self.handle)
+        except Exception:
+            pass

@@ -1,0 +1,359 @@
+"""Per-clip device state and the launch lists of one frame.
+
+``ClipRuntime`` owns everything one AOTEngine needs on the GPU for one network size:
+activation buffers (NHWC bf16; the LSTT residual stream is fp32), the long-term memory
+bank as a slot ring per layer (bf16 [slots, HW, 256] for K and V, an index table instead
+of the reference's torch.cat / slice, layers/transformer.py:319, 432-433), the short-term
+memory, and the prepared launch lists (``ops.Op``) for
+
+    encode      image -> ResNet-50 -> 1x1 projector            (models/aot.py:116-134)
+    lstt_ref    3 LSTT layers, reference-frame mode            (layers/transformer.py:582-588)
+    lstt_prop   3 LSTT layers, propagate mode, bank size T     (layers/transformer.py:589-692)
+    decode      FPN head -> logits at 1/4 resolution           (decoders/fpn.py:36-68)
+    id_emb      label map -> one-hot -> identity bank conv     (engines/aot_engine.py:208-232)
+    update      short/long-term memory update                  (layers/transformer.py:269-322)
+
+The lists are pure functions of the buffers' addresses, so each one is built once and
+replayed (directly or as a captured hipGraph).  Everything that changes from frame to
+frame (slot table, temporal-PE slots) lives in device memory.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import ops
+from .pack import R50_BLOCKS, R50_STRIDES
+
+BF16, F32 = torch.bfloat16, torch.float32
+D_MODEL, HEADS, FFN = 256, 8, 1024
+MAX_CHUNKS = 32
+
+
+def temporal_slots(T: int, n_slots: int = 4) -> List[int]:
+    """Temporal-PE slot of each bank entry (layers/transformer.py:598-621).
+
+    T <= 4: entry t uses slot t.  T > 4: the slots are flipped, nearest-resized to T
+    (src = floor(dst * float32(4 / T))) and flipped back.
+    """
+    if T <= n_slots:
+        return list(range(T))
+    scale = torch.tensor(float(n_slots), dtype=F32) / torch.tensor(float(T), dtype=F32)
+    out = []
+    for t in range(T):
+        src = int(torch.floor(torch.tensor(float(T - 1 - t), dtype=F32) * scale).item())
+        out.append(n_slots - 1 - min(src, n_slots - 1))
+    return out
+
+
+def sine_pos_emb(h: int, w: int, c: int = D_MODEL) -> torch.Tensor:
+    """2-D sine positional embedding [h*w, c] (layers/position.py:50-77: normalize=True,
+    scale 2*pi, temperature 1e4, y half then x half); computed once per clip on the host."""
+    nf = c // 2
+    ys = torch.arange(h, dtype=F32)[:, None].expand(h, w)
+    xs = torch.arange(w, dtype=F32)[None, :].expand(h, w)
+    ys = ys / (ys[-1:, :] + 1e-6) * (2 * torch.pi)
+    xs = xs / (xs[:, -1:] + 1e-6) * (2 * torch.pi)
+    dim_t = 10000 ** (2 * torch.div(torch.arange(nf, dtype=F32), 2, rounding_mode='trunc') / nf)
+    px, py = xs[:, :, None] / dim_t, ys[:, :, None] / dim_t
+    px = torch.stack((px[:, :, 0::2].sin(), px[:, :, 1::2].cos()), dim=3).flatten(2)
+    py = torch.stack((py[:, :, 0::2].sin(), py[:, :, 1::2].cos()), dim=3).flatten(2)
+    return torch.cat((py, px), dim=2).reshape(h * w, c).contiguous()
+
+
+def _out(n, k, s, p):
+    return (n + 2 * p - k) // s + 1
+
+
+class ClipRuntime:
+    def __init__(self, P: Dict[str, torch.Tensor], in_hw: Tuple[int, int], bank_slots: int, device,
+                 num_lstt: int = 3, align_corners: bool = True, num_classes: int = 11):
+        self.P, self.dev, self.NL = P, device, num_lstt
+        self.align = align_corners
+        self.nc = num_classes
+        H, W = in_hw
+        self.H, self.W = H, W
+        self.H2, self.W2 = _out(H, 7, 2, 3), _out(W, 7, 2, 3)
+        self.H4, self.W4 = _out(self.H2, 3, 2, 1), _out(self.W2, 3, 2, 1)
+        self.H8, self.W8 = _out(self.H4, 3, 2, 1), _out(self.W4, 3, 2, 1)
+        self.H16, self.W16 = _out(self.H8, 3, 2, 1), _out(self.W8, 3, 2, 1)
+        self.L = self.H16 * self.W16
+        L = self.L
+        e = lambda *shape, dt=BF16: torch.empty(*shape, dtype=dt, device=device)  # noqa: E731
+
+        # ---- encoder buffers ----
+        self.img8 = e(H * W, 8)
+        self.stem = e(self.H2 * self.W2, 64)
+        M4, M8 = self.H4 * self.W4, self.H8 * self.W8
+        self.pool = e(M4, 64)
+        self.x4 = [e(M4, 256), e(M4, 256)]          # layer1 ping-pong
+        self.x8 = [e(M8, 512), e(M8, 512)]
+        self.x16 = [e(L, 1024), e(L, 1024)]
+        self.mid_a = e(M4, 128)                     # bottleneck conv1 out (<= M4*64, M4*128 for layer2.0, ...)
+        self.mid_b = e(M4, 64)                      # bottleneck conv2 out
+        self.ds = e(M4, 256)                        # downsample branch
+        # ---- LSTT buffers ----
+        self.x = e(L, D_MODEL, dt=F32)              # residual stream
+        self.dec_in = e(L, 4 * D_MODEL)             # cat(enc256, 3 x normed LSTT out), decoders/fpn.py:38-39
+        self.t1b, self.t1p = e(L, D_MODEL), e(L, D_MODEL)
+        self.qkv = e(L, 3 * D_MODEL)
+        self.att = e(L, D_MODEL)
+        self.t3 = e(L, D_MODEL)
+        self.k4, self.v4 = e(L, D_MODEL), e(L, D_MODEL)
+        self.h1, self.h2, self.h3 = e(L, FFN), e(L, FFN), e(L, FFN)
+        self.tmp = e(L, D_MODEL)
+        self.curr_Q = [e(L, D_MODEL) for _ in range(num_lstt)]   # = curr_K
+        self.curr_V = [e(L, D_MODEL) for _ in range(num_lstt)]   # LN2 output
+        self.tgt3 = [e(L, D_MODEL) for _ in range(num_lstt)]
+        self.short_K = [e(L, D_MODEL) for _ in range(num_lstt)]
+        self.short_V = [e(L, D_MODEL) for _ in range(num_lstt)]
+        self.id_emb = e(L, D_MODEL)
+        self.onehot = e(H * W, 16)
+        self.pos = sine_pos_emb(self.H16, self.W16).to(device)
+        self.attn_ws = ops.attn_workspace(L, HEADS, MAX_CHUNKS, device)
+        self.gn_ws = ops.groupnorm_workspace(32, device)
+        self.mass = torch.zeros(L, MAX_CHUNKS, dtype=F32, device=device)
+        self.scores = torch.zeros(MAX_CHUNKS, dtype=F32, device=device)
+        # ---- decoder buffers ----
+        self.d16a, self.d16b = e(L, 256), e(L, 256)
+        self.d8a, self.d8b = e(M8, 256), e(M8, 256)
+        self.d4a, self.d4b = e(M4, 128), e(M4, 128)
+        self.logits = torch.zeros(M4, 16, dtype=F32, device=device)
+        # ---- memory bank ----
+        self.chunks = torch.zeros(MAX_CHUNKS, 8, dtype=torch.int32, device=device)
+        self.chunks_host = torch.zeros(MAX_CHUNKS, 8, dtype=torch.int32).pin_memory() if device.type == 'cuda' else None
+        self._alloc_bank(bank_slots)
+        self._prog: Dict[str, list] = {}
+
+    # ------------------------------------------------------------------ bank
+    def _alloc_bank(self, slots: int):
+        self.S = slots
+        self.bank_K = [torch.empty(slots, self.L, D_MODEL, dtype=BF16, device=self.dev) for _ in range(self.NL)]
+        self.bank_V = [torch.empty(slots, self.L, D_MODEL, dtype=BF16, device=self.dev) for _ in range(self.NL)]
+        self.slots: List[int] = []           # logical order t -> physical slot
+        self.free: List[int] = list(range(slots))
+
+    def reset_bank(self):
+        self.slots = []
+        self.free = list(range(self.S))
+
+    def grow_bank(self):
+        """Unbounded-memory mode (latter_mem_len = 9999, tools/eval.py:92): double the ring."""
+        old_K, old_V, old_S = self.bank_K, self.bank_V, self.S
+        new_S = old_S * 2
+        self.bank_K = [torch.empty(new_S, self.L, D_MODEL, dtype=BF16, device=self.dev) for _ in range(self.NL)]
+        self.bank_V = [torch.empty(new_S, self.L, D_MODEL, dtype=BF16, device=self.dev) for _ in range(self.NL)]
+        for i in range(self.NL):
+            self.bank_K[i][:old_S].copy_(old_K[i])
+            self.bank_V[i][:old_S].copy_(old_V[i])
+        self.free += list(range(old_S, new_S))
+        self.S = new_S
+        self._prog = {k: v for k, v in self._prog.items() if not k.startswith(('lstt', 'update'))}
+
+    def take_slot(self) -> int:
+        if not self.free:
+            self.grow_bank()
+        return self.free.pop(0)
+
+    def chunk_plan(self, T: int) -> Tuple[int, int]:
+        """(splits per memory frame, chunk count): keep >= ~8 key chunks in flight for small T."""
+        if T > MAX_CHUNKS:
+            raise ops.RmemError(f'memory bank of {T} frames exceeds the {MAX_CHUNKS}-chunk table')
+        splits = max(1, min(8 // T, MAX_CHUNKS // T))
+        return splits, T * splits
+
+    def upload_chunks(self, stream: int):
+        """Write the chunk table for the current slot order (call after every bank change)."""
+        T = len(self.slots)
+        splits, n = self.chunk_plan(T)
+        pes = temporal_slots(T)
+        per = (self.L + splits - 1) // splits
+        rows = []
+        for t, s in enumerate(self.slots):
+            for j in range(splits):
+                kb = j * per
+                rows.append((s, kb, min(per, self.L - kb), pes[t], t))
+        host = self.chunks_host
+        host.zero_()
+        host[:n, :5] = torch.tensor(rows, dtype=torch.int32)
+        with torch.cuda.stream(torch.cuda.ExternalStream(stream)):
+            self.chunks.copy_(host, non_blocking=True)
+
+    # ------------------------------------------------------------------ programs
+    def _lin(self, x, name, y, M, K, N, **kw):
+        return ops.linear(x, self.P[name + '.w'], self.P[name + '.b'], y, M=M, K=K, N=N, **kw)
+
+    def prog_encode(self, img: torch.Tensor) -> list:
+        """img: fp32 [3, H, W] device tensor at a FIXED address (the caller copies frames into it)."""
+        key = 'encode'
+        if key in self._prog:
+            return self._prog[key]
+        P, o = self.P, []
+        o.append(ops.image_to_nhwc8(img, self.img8, H=self.H, W=self.W))
+        o.append(ops.conv2d(self.img8, P['stem.w'], P['stem.b'], self.stem, H=self.H, W=self.W, Cin=8, Cout=64, KH=7, KW=7,
+                            stride=2, pad=3, relu=True))
+        o.append(ops.maxpool3x3s2(self.stem, self.pool, H=self.H2, W=self.W2, C=64))
+        x, (h, w), cin = self.pool, (self.H4, self.W4), 64
+        outs = [self.x4, self.x8, self.x16]
+        for li, (nblk, stride) in enumerate(zip(R50_BLOCKS, R50_STRIDES), start=1):
+            planes = 64 * 2 ** (li - 1)
+            for bi in range(nblk):
+                p = f'encoder.layer{li}.{bi}'
+                s = stride if bi == 0 else 1
+                ho, wo = _out(h, 3, s, 1), _out(w, 3, s, 1)
+                y = outs[li - 1][bi % 2]
+                a = self.mid_a.view(-1)[: h * w * planes]
+                b = self.mid_b.view(-1)[: ho * wo * planes]
+                o.append(ops.conv2d(x, P[p + '.conv1.w'], P[p + '.conv1.b'], a, H=h, W=w, Cin=cin, Cout=planes, relu=True))
+                o.append(ops.conv2d(a, P[p + '.conv2.w'], P[p + '.conv2.b'], b, H=h, W=w, Cin=planes, Cout=planes, KH=3, KW=3,
+                                    stride=s, pad=1, relu=True))
+                if (p + '.ds.w') in P:
+                    r = self.ds.view(-1)[: ho * wo * planes * 4]
+                    o.append(ops.conv2d(x, P[p + '.ds.w'], P[p + '.ds.b'], r, H=h, W=w, Cin=cin, Cout=planes * 4, stride=s))
+                else:
+                    r = x
+                o.append(ops.conv2d(b, P[p + '.conv3.w'], P[p + '.conv3.b'], y, H=ho, W=wo, Cin=planes, Cout=planes * 4,
+                                    residual=r, relu=True))
+                x, (h, w), cin = y, (ho, wo), planes * 4
+            setattr(self, f'enc{li}', x)
+        # encoder_projector: fp32 residual stream + bf16 copy into the decoder's concat buffer
+        o.append(ops.conv2d(self.enc3, P['proj.w'], P['proj.b'], self.x, H=self.L, W=1, Cin=1024, Cout=D_MODEL,
+                            y2=self.dec_in, ld2=4 * D_MODEL))
+        self._prog[key] = o
+        return o
+
+    def _attn(self, q, ldq, k, v, ldkv, out, **kw):
+        return ops.mem_read_attn(q, k, v, out, self.attn_ws, Lq=self.L, heads=HEADS, ldq=ldq, ldkv=ldkv, ldo=D_MODEL, **kw)
+
+    def prog_lstt(self, ref_mode: bool, T: int, ref_slot: int = 0) -> list:
+        """The 3-layer LSTT on self.x.  ref_mode: reference frame (id_emb already in self.id_emb,
+        K/V go straight into bank slot ``ref_slot``); else propagate against a bank of T frames."""
+        key = f'lstt_ref{ref_slot}' if ref_mode else f'lstt_prop{T}'
+        if key in self._prog:
+            return self._prog[key]
+        P, L, o = self.P, self.L, []
+        C = D_MODEL
+        _, nchunks = self.chunk_plan(1 if ref_mode else T)
+        for i in range(self.NL):
+            d = f'l{i}'
+            # --- self attention (transformer.py:565-571)
+            o.append(ops.layernorm256(self.x, P[d + '.ln1.g'], P[d + '.ln1.b'], M=L, y=self.t1b, pos=self.pos, ypos=self.t1p))
+            o.append(self._lin(self.t1p, d + '.self_qk', self.qkv, L, C, 2 * C, ldo=3 * C))
+            o.append(self._lin(self.t1b, d + '.self_v', self.qkv.view(-1)[2 * C:], L, C, C, ldo=3 * C))
+            o.append(self._attn(self.qkv, 3 * C, self.qkv.view(-1)[C:], self.qkv.view(-1)[2 * C:], 3 * C, self.att,
+                                nchunks=4, lk_single=L))
+            o.append(self._lin(self.att, d + '.self_proj', self.x, L, C, C, residual=self.x))
+            # --- long/short-term attention (573-680)
+            o.append(ops.layernorm256(self.x, P[d + '.ln2.g'], P[d + '.ln2.b'], M=L, y=self.curr_V[i]))
+            if ref_mode:
+                cq = self.bank_K[i][ref_slot]                       # curr_K is the bank's first entry
+                gv = self.bank_V[i][ref_slot]
+                o.append(self._lin(self.curr_V[i], d + '.linear_Q', cq, L, C, C))
+                o.append(ops.add_bf16(self.curr_V[i], self.id_emb, self.tmp, L * C))
+                o.append(self._lin(self.tmp, d + '.linear_V', gv, L, C, C))
+                sk, sv = cq, gv                                     # local_K/V = global_K/V (585-586)
+            else:
+                cq = self.curr_Q[i]
+                o.append(self._lin(self.curr_V[i], d + '.linear_Q', cq, L, C, C))
+                sk, sv = self.short_K[i], self.short_V[i]
+            o.append(self._attn(cq, C, self.bank_K[i], self.bank_V[i], C, self.att, slot_stride=L * C, chunks=self.chunks,
+                                nchunks=nchunks, pe_cur=P['pe_cur'], pe_mem=P['pe_mem'],
+                                mass=self.mass if (i == 0 and not ref_mode) else None, T=T))
+            o.append(self._lin(self.att, d + '.long_proj', self.x, L, C, C, residual=self.x))
+            o.append(ops.layernorm256(sk, P[d + '.ln4.g'], P[d + '.ln4.b'], M=L, b=cq, y=self.k4))
+            o.append(ops.layernorm256(sv, P[d + '.ln4.g'], P[d + '.ln4.b'], M=L, b=self.curr_V[i], y=self.v4))
+            o.append(self._attn(cq, C, self.k4, self.v4, C, self.att, nchunks=4, lk_single=L))
+            o.append(self._lin(self.att, d + '.short_proj', self.x, L, C, C, residual=self.x, y2=self.tgt3[i]))
+            if ref_mode:   # short-term memory of the reference frame (675-678)
+                o.append(self._lin(self.tgt3[i], d + '.linear_QMem', self.short_K[i], L, C, C))
+                o.append(ops.add_bf16(self.tgt3[i], self.id_emb, self.tmp, L * C))
+                o.append(self._lin(self.tmp, d + '.linear_VMem', self.short_V[i], L, C, C))
+            # --- feed-forward (683-687)
+            o.append(ops.layernorm256(self.x, P[d + '.ln3.g'], P[d + '.ln3.b'], M=L, y=self.t3))
+            o.append(self._lin(self.t3, d + '.linear1', self.h1, L, C, FFN))
+            o.append(ops.groupnorm(self.h1, P[d + '.gn.g'], P[d + '.gn.b'], self.h2, self.gn_ws, M=L, C=FFN, groups=32, act=2))
+            o.append(ops.dwconv5x5(self.h2, P[d + '.dw.w'], self.h3, H=self.H16, W=self.W16, C=FFN))
+            o.append(self._lin(self.h3, d + '.linear2', self.x, L, FFN, C, residual=self.x))
+            # --- decoder norm of this layer's output into the concat buffer (248-259)
+            o.append(ops.layernorm256(self.x, P[f'dec_norm{i}.g'], P[f'dec_norm{i}.b'], M=L,
+                                      y=self.dec_in.view(-1)[(i + 1) * C:], ldy=4 * C))
+        self._prog[key] = o
+        return o
+
+    def prog_decode(self) -> list:
+        key = 'decode'
+        if key in self._prog:
+            return self._prog[key]
+        P, o, L = self.P, [], self.L
+        M8, M4 = self.H8 * self.W8, self.H4 * self.W4
+        gn = lambda x, name, y, M, C: ops.groupnorm(x, P[name + '.gn.g'], P[name + '.gn.b'], y, self.gn_ws, M=M, C=C, groups=8, act=1)  # noqa: E731
+        o.append(ops.conv2d(self.dec_in, P['dec.conv_in.w'], P['dec.conv_in.b'], self.d16a, H=L, W=1, Cin=1024, Cout=256))
+        o.append(gn(self.d16a, 'dec.conv_in', self.d16b, L, 256))
+        o.append(ops.conv2d(self.enc3, P['dec.adapter_16x.w'], P['dec.adapter_16x.b'], self.d16a, H=L, W=1, Cin=1024, Cout=256,
+                            residual=self.d16b))
+        o.append(ops.conv2d(self.d16a, P['dec.conv_16x.w'], P['dec.conv_16x.b'], self.d16b, H=self.H16, W=self.W16, Cin=256, Cout=256,
+                            KH=3, KW=3, pad=1))
+        o.append(gn(self.d16b, 'dec.conv_16x', self.d16a, L, 256))
+        o.append(ops.bilinear(self.d16a, self.d8a, Hi=self.H16, Wi=self.W16, Ho=self.H8, Wo=self.W8, C=256, align_corners=self.align))
+        o.append(ops.conv2d(self.enc2, P['dec.adapter_8x.w'], P['dec.adapter_8x.b'], self.d8b, H=M8, W=1, Cin=512, Cout=256,
+                            residual=self.d8a))
+        d8c = self.d8a.view(-1)[: M8 * 128]
+        o.append(ops.conv2d(self.d8b, P['dec.conv_8x.w'], P['dec.conv_8x.b'], d8c, H=self.H8, W=self.W8, Cin=256, Cout=128,
+                            KH=3, KW=3, pad=1))
+        d8d = self.d8b.view(-1)[: M8 * 128]
+        o.append(gn(d8c, 'dec.conv_8x', d8d, M8, 128))
+        o.append(ops.bilinear(d8d, self.d4a, Hi=self.H8, Wi=self.W8, Ho=self.H4, Wo=self.W4, C=128, align_corners=self.align))
+        o.append(ops.conv2d(self.enc1, P['dec.adapter_4x.w'], P['dec.adapter_4x.b'], self.d4b, H=M4, W=1, Cin=256, Cout=128,
+                            residual=self.d4a))
+        o.append(ops.conv2d(self.d4b, P['dec.conv_4x.w'], P['dec.conv_4x.b'], self.d4a, H=self.H4, W=self.W4, Cin=128, Cout=128,
+                            KH=3, KW=3, pad=1))
+        o.append(gn(self.d4a, 'dec.conv_4x', self.d4b, M4, 128))
+        o.append(ops.conv2d(self.d4b, P['dec.conv_out.w'], P['dec.conv_out.b'], self.logits, H=M4, W=1, Cin=128, Cout=self.nc, ldo=16))
+        self._prog[key] = o
+        return o
+
+    def prog_id_emb(self, label: torch.Tensor, hs: int, ws: int) -> list:
+        """label: uint8 or fp32 [hs, ws] device tensor at a fixed address -> self.id_emb."""
+        key = f'id_{label.data_ptr()}_{hs}_{ws}'
+        if key in self._prog:
+            return self._prog[key]
+        P = self.P
+        k, s, p = (17, 16, 8) if self.align else (16, 16, 0)
+        o = [ops.label_to_onehot16(label, self.onehot, Hs=hs, Ws=ws, Hd=self.H, Wd=self.W, ncls=self.nc),
+             ops.conv2d(self.onehot, P['idbank.w'], P['idbank.b'], self.id_emb, H=self.H, W=self.W, Cin=16, Cout=D_MODEL,
+                        KH=k, KW=k, stride=s, pad=p)]
+        self._prog[key] = o
+        return o
+
+    def prog_update(self, append_slot: Optional[int]) -> list:
+        """Memory update after a propagated frame (layers/transformer.py:269-322); self.id_emb holds the
+        identity embedding of the predicted mask.  append_slot: bank slot receiving (curr_K, linear_V(curr_V + id))."""
+        key = f'update_{append_slot}'
+        if key in self._prog:
+            return self._prog[key]
+        L, C, o = self.L, D_MODEL, []
+        for i in range(self.NL):
+            d = f'l{i}'
+            o.append(self._lin(self.tgt3[i], d + '.linear_QMem', self.short_K[i], L, C, C))
+            o.append(ops.add_bf16(self.tgt3[i], self.id_emb, self.tmp, L * C))
+            o.append(self._lin(self.tmp, d + '.linear_VMem', self.short_V[i], L, C, C))
+            if append_slot is not None:
+                o.append(ops.add_bf16(self.curr_V[i], self.id_emb, self.tmp, L * C))
+                o.append(self._lin(self.tmp, d + '.linear_V', self.bank_V[i][append_slot], L, C, C))
+                o.append(_CopyOp(self.curr_Q[i], self.bank_K[i][append_slot], L * C))
+        self._prog[key] = o
+        return o
+
+
+class _CopyOp(ops.Op):
+    """Device-to-device copy on the launch stream (bank append of curr_K)."""
+    __slots__ = ('src', 'dst', 'n')
+
+    def __init__(self, src, dst, n):
+        self.src, self.dst, self.n = src, dst, n
+        self.fn, self.args, self.name, self.keep = None, (), 'copy', (src, dst)
+
+    def __call__(self, stream: int):
+        with torch.cuda.stream(torch.cuda.ExternalStream(stream)):
+            self.dst.view(-1)[: self.n].copy_(self.src.view(-1)[: self.n], non_blocking=True)

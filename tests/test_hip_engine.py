@@ -1,0 +1,113 @@
+"""End-to-end GPU parity of the HIP engine against the golden clips the reference produced
+(tests/golden/make_golden.py) -- through the drop-in Python API, on the same seeded inputs."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+def _iou(a, b):
+    """mean over object ids of the Jaccard index (evaluation/source/metrics.py:6-37)."""
+    ids = [i for i in np.unique(np.concatenate([a.ravel(), b.ravel()])) if i != 0]
+    vals = []
+    for i in ids:
+        u = np.sum((a == i) | (b == i))
+        vals.append(1.0 if u == 0 else np.sum((a == i) & (b == i)) / u)
+    return float(np.mean(vals)) if vals else 1.0
+
+
+def _load(name):
+    from rmem_ocu_amd.synth import make_clip
+    g = np.load(os.path.join(GOLDEN, name))
+    former, latter, n, h, w, oh, ow, gap, objs, seed = g['meta'].tolist()
+    frames, mask = make_clip(seed, n, h, w, objs)
+    assert hashlib.sha256(frames.numpy().tobytes()).hexdigest() == str(g['frames_sha'])
+    return g, frames, mask, (former, latter, n, h, w, oh, ow, gap)
+
+
+def _engine(former, latter, gap):
+    from rmem_ocu_amd import build_engine, build_vos_model, get_config
+    from rmem_ocu_amd.weights import synth_state_dict
+    cfg = get_config('pre_vost', 'test', 'r50_aotl')
+    cfg.FORMER_MEM_LEN, cfg.LATTER_MEM_LEN = former, latter
+    model = build_vos_model(cfg.MODEL_VOS, cfg).cuda(0)
+    model.load_state_dict(synth_state_dict(0))
+    eng = build_engine(cfg.MODEL_ENGINE, phase='eval', aot_model=model, gpu_id=0, long_term_mem_gap=gap)
+    eng.eval()
+    return eng
+
+
+def _run(name, teacher_forced, use_graphs=False):
+    g, frames, mask, (former, latter, n, h, w, oh, ow, gap) = _load(name)
+    eng = _engine(former, latter, gap)
+    eng.use_graphs = use_graphs
+    dev = torch.device('cuda', 0)
+    frames_d = frames.to(dev)
+    eng.add_reference_frame(frames_d[0:1], mask.to(dev), obj_nums=[int(mask.max())], frame_step=0)
+    ys, xs = torch.from_numpy(g['sample_y']).to(dev), torch.from_numpy(g['sample_x']).to(dev)
+    labels, samples, trace = [], [], []
+    for i in range(1, n):
+        logit = eng.match_propogate_one_frame(frames_d[i:i + 1], output_size=(oh, ow))
+        prob = torch.softmax(logit, dim=1)
+        label = torch.argmax(prob, dim=1, keepdim=True).float()
+        fed = torch.from_numpy(g['labels'][i - 1].astype(np.float32)).to(dev)[None, None] if teacher_forced else label
+        eng.update_memory(F.interpolate(fed, size=eng.input_size_2d, mode='nearest'))
+        labels.append(label[0, 0].to(torch.uint8).cpu().numpy())
+        samples.append(logit[0][:, ys, xs].cpu().numpy())
+        trace.append(list(eng.long_memories_indexes))
+    return g, np.stack(labels), np.stack(samples), trace
+
+
+def _trace_matrix(trace, like):
+    got = -np.ones_like(like)
+    for i, t in enumerate(trace):
+        got[i, :len(t)] = t
+    return got
+
+
+def test_small_clip_teacher_forced():
+    """Per-frame parity with the reference's masks fed back (no error feedback): logits within bf16
+    tolerance, identical eviction trace."""
+    g, labels, samples, trace = _run('clip_small.npz', True)
+    ref = g['logit_samples']
+    err = np.abs(samples - ref).max()
+    print('teacher-forced: max |dlogit| =', err, ' logit std =', ref.std(), ' label agreement =', (labels == g['labels']).mean())
+    assert err < 0.08 * ref.std() + 0.05, err
+    assert (_trace_matrix(trace, g['indexes']) == g['indexes']).all()
+    assert (labels == g['labels']).mean() > 0.97
+
+
+def test_small_clip_free_running():
+    g, labels, samples, trace = _run('clip_small.npz', False)
+    agree = (labels == g['labels']).mean(axis=(1, 2))
+    ious = [_iou(a, b) for a, b in zip(g['labels'], labels)]
+    print('free-running: label agreement first/last/mean', agree[0], agree[-1], agree.mean(), ' mean IoU', np.mean(ious))
+    assert agree[0] > 0.97
+    assert (_trace_matrix(trace, g['indexes']) == g['indexes']).all()
+
+
+def test_small_clip_graph_replay_bitwise():
+    """hipGraph replay of the frame launch lists gives bit-identical logits to direct launches."""
+    _, l0, s0, t0 = _run('clip_small.npz', True, use_graphs=False)
+    _, l1, s1, t1 = _run('clip_small.npz', True, use_graphs=True)
+    assert t0 == t1
+    assert np.array_equal(s0, s1) and np.array_equal(l0, l1)
+
+
+def test_full_clip_cfg2_geometry():
+    """481x849 network size, bank N = 8: masks / eviction trace against the reference's golden clip."""
+    if not os.path.exists(os.path.join(GOLDEN, 'clip_full.npz')):
+        pytest.skip('clip_full.npz not generated')
+    g, labels, samples, trace = _run('clip_full.npz', True)
+    ref = g['logit_samples']
+    err = np.abs(samples - ref).max()
+    print('full clip teacher-forced: max |dlogit| =', err, ' logit std =', ref.std(), ' agreement =', (labels == g['labels']).mean())
+    assert err < 0.08 * ref.std() + 0.05
+    assert (_trace_matrix(trace, g['indexes']) == g['indexes']).all()

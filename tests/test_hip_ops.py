@@ -1,0 +1,291 @@
+"""GPU parity of every librmem_hip.so kernel against the CPU oracle / torch fp32 primitives,
+on the same seeded inputs (inputs are rounded to bf16 first, so the comparison isolates the
+kernel's own arithmetic: bf16 operands, fp32 accumulation, bf16 or fp32 store)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+def seeded(seed, shape, scale=1.0):
+    rng = np.random.Generator(np.random.PCG64([seed, 0xC0FFEE]))
+    return torch.from_numpy(rng.standard_normal(shape).astype(np.float32) * np.float32(scale))
+
+
+def rb(t):  # round through bf16
+    return t.to(BF16).to(F32)
+
+
+def assert_close(got, ref, rtol, what=''):
+    got, ref = got.detach().float().cpu(), ref.detach().float().cpu()
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    assert torch.isfinite(got).all(), what
+    err = (got - ref).abs().max().item()
+    scale = ref.abs().max().item() + 1e-6
+    assert err <= rtol * scale, f'{what}: max err {err:.4g} vs scale {scale:.4g} (rtol {rtol})'
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device('cuda', 0)
+
+
+def nhwc(x):  # [1,C,H,W] fp32 -> [H*W, C] bf16
+    return x[0].permute(1, 2, 0).reshape(-1, x.shape[1]).contiguous().to(BF16)
+
+
+def pack_w(w, cin_pad=0):
+    w = w.permute(0, 2, 3, 1)
+    if cin_pad > w.shape[-1]:
+        w = F.pad(w, (0, cin_pad - w.shape[-1]))
+    return w.contiguous().to(BF16)
+
+
+CONV_CASES = [
+    # H, W, Cin, Cout, k, stride, pad, relu, residual, out_f32
+    (31, 54, 64, 64, 3, 1, 1, True, None, False),
+    (31, 54, 256, 64, 1, 1, 0, True, None, False),
+    (31, 54, 64, 256, 1, 1, 0, True, 'bf16', False),
+    (61, 107, 128, 128, 3, 2, 1, True, None, False),
+    (61, 107, 256, 512, 1, 2, 0, False, None, False),
+    (97, 129, 8, 64, 7, 2, 3, True, None, False),
+    (97, 129, 16, 256, 17, 16, 8, False, None, False),
+    (1674, 1, 256, 256, 1, 1, 0, False, 'f32', True),
+    (1674, 1, 1024, 256, 1, 1, 0, False, None, True),
+    (1674, 1, 256, 1024, 1, 1, 0, False, None, False),
+    (500, 1, 128, 11, 1, 1, 0, False, None, True),
+    (121, 213, 128, 128, 3, 1, 1, False, None, False),
+]
+
+
+@pytest.mark.parametrize('case', CONV_CASES)
+def test_conv2d(dev, case):
+    from rmem_ocu_amd import ops
+    H, W, Cin, Cout, k, s, p, relu, res, out_f32 = case
+    x = rb(seeded(1, (1, Cin, H, W)))
+    w = rb(seeded(2, (Cout, Cin, k, k), 1.0 / (Cin * k * k) ** 0.5))
+    b = seeded(3, (Cout,), 0.1)
+    ref = F.conv2d(x, w, b, stride=s, padding=p)
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    r = None
+    if res:
+        r = seeded(4, (1, Cout, Ho, Wo))
+        r = rb(r) if res == 'bf16' else r
+        ref = ref + r
+    if relu:
+        ref = F.relu(ref)
+    ldo = 16 if Cout == 11 else Cout
+    y = torch.zeros(Ho * Wo, ldo, dtype=F32 if out_f32 else BF16, device=dev)
+    y2 = torch.zeros(Ho * Wo, Cout, dtype=BF16, device=dev)
+    rd = None
+    if r is not None:
+        rd = r[0].permute(1, 2, 0).reshape(-1, Cout).contiguous().to(dev)
+        rd = rd.to(BF16) if res == 'bf16' else rd
+    op = ops.conv2d(nhwc(x).to(dev), pack_w(w).to(dev), b.to(dev), y, H=H, W=W, Cin=Cin, Cout=Cout, KH=k, KW=k, stride=s, pad=p,
+                    residual=rd, y2=y2, relu=relu, ldo=ldo)
+    ops.run(op)
+    torch.cuda.synchronize()
+    refm = ref[0].permute(1, 2, 0).reshape(-1, Cout)
+    assert_close(y[:, :Cout], refm, 1e-2, f'conv {case}')
+    pre = F.conv2d(x, w, b, stride=s, padding=p)[0].permute(1, 2, 0).reshape(-1, Cout)
+    assert_close(y2, pre, 1e-2, f'conv y2 {case}')
+
+
+@pytest.mark.parametrize('T,L', [(1, 42), (2, 42), (5, 42), (8, 42), (12, 42), (3, 300), (8, 1674)])
+def test_mem_read_attn_vs_oracle(dev, T, L, synth_weights):
+    """a1 + a2 + a3: long-term attention with temporal PE and the per-frame mass output."""
+    from oracle import ref_cpu as O
+    from rmem_ocu_amd import ops
+    from rmem_ocu_amd.runtime import temporal_slots
+    C = 256
+    q, k, v = rb(seeded(10 + T, (L, C))), rb(seeded(20 + T, (T, L, C))), rb(seeded(30 + T, (T, L, C)))
+    pe_cur, pe_mem = synth_weights['cur_pos_emb'].view(-1), synth_weights['mem_pos_emb']
+    slots = temporal_slots(T)
+    # oracle: explicit softmax path of attention.py:45-64 on (Q + cur_pe), (K + pe[slot])
+    Qh = ((q + pe_cur) / 32 ** 0.5).view(L, 8, 32).permute(1, 0, 2)
+    Kh = (k + pe_mem[slots][:, None, :]).reshape(T * L, 8, 32).permute(1, 2, 0)
+    Vh = v.reshape(T * L, 8, 32).permute(1, 0, 2)
+    attn = torch.softmax(Qh @ Kh, dim=-1)
+    ref = (attn @ Vh).permute(1, 0, 2).reshape(L, C)
+    ref_mass = attn.view(8, L, T, L).mean(0).sum(2)
+    # HIP: bank with shuffled physical slots
+    S = T + 2
+    perm = list(np.random.RandomState(T).permutation(S)[:T])
+    bank_k = torch.zeros(S, L, C, dtype=BF16, device=dev)
+    bank_v = torch.zeros(S, L, C, dtype=BF16, device=dev)
+    for t, s in enumerate(perm):
+        bank_k[s] = k[t].to(dev)
+        bank_v[s] = v[t].to(dev)
+    splits = 2 if T <= 4 else 1
+    per = (L + splits - 1) // splits
+    rows = [(int(perm[t]), j * per, min(per, L - j * per), slots[t], t) for t in range(T) for j in range(splits)]
+    chunks = ops.make_chunk_table(rows).to(dev)
+    out = torch.zeros(L, C, dtype=BF16, device=dev)
+    mass = torch.zeros(L, T, dtype=F32, device=dev)
+    ws = ops.attn_workspace(L, 8, len(rows), dev)
+    ops.run(ops.mem_read_attn(q.to(BF16).to(dev), bank_k, bank_v, out, ws, Lq=L, ldq=C, ldkv=C, ldo=C, slot_stride=L * C,
+                              chunks=chunks, nchunks=len(rows), pe_cur=pe_cur.to(dev), pe_mem=pe_mem.to(dev).contiguous(),
+                              mass=mass, T=T))
+    torch.cuda.synchronize()
+    assert_close(out, ref, 2e-2, 'attention out')
+    assert_close(mass, ref_mass, 2e-2, 'attention mass')
+    assert abs(mass.sum(1).mean().item() - 1.0) < 1e-3
+
+
+def test_plain_attn_split_keys(dev):
+    """a4 / a5 core: one key frame split into 4 key ranges, no temporal PE, strided q/k/v views."""
+    from rmem_ocu_amd import ops
+    L, C = 1674, 256
+    qkv = rb(seeded(40, (L, 3 * C)))
+    q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
+    Qh = (q / 32 ** 0.5).reshape(L, 8, 32).permute(1, 0, 2)
+    ref = (torch.softmax(Qh @ k.reshape(L, 8, 32).permute(1, 2, 0), -1) @ v.reshape(L, 8, 32).permute(1, 0, 2)).permute(1, 0, 2).reshape(L, C)
+    d = qkv.to(BF16).to(dev)
+    out = torch.zeros(L, C, dtype=BF16, device=dev)
+    ws = ops.attn_workspace(L, 8, 4, dev)
+    ops.run(ops.mem_read_attn(d, d.view(-1)[C:], d.view(-1)[2 * C:], out, ws, Lq=L, ldq=3 * C, ldkv=3 * C, ldo=C, nchunks=4, lk_single=L))
+    torch.cuda.synchronize()
+    assert_close(out, ref, 2e-2, 'plain attention')
+
+
+def test_attention_forced_rescale(dev):
+    """Online-softmax rescale branch: a late key tile whose logits jump far above everything before it."""
+    from rmem_ocu_amd import ops
+    L, C = 200, 256
+    q, k, v = rb(seeded(50, (L, C))), rb(seeded(51, (L, C))), rb(seeded(52, (L, C)))
+    k[150:] = rb(q[:50] * 4.0)          # keys 150.. align with queries 0..49: large logits late in the stream
+    Qh = (q / 32 ** 0.5).reshape(L, 8, 32).permute(1, 0, 2)
+    ref = (torch.softmax(Qh @ k.reshape(L, 8, 32).permute(1, 2, 0), -1) @ v.reshape(L, 8, 32).permute(1, 0, 2)).permute(1, 0, 2).reshape(L, C)
+    out = torch.zeros(L, C, dtype=BF16, device=dev)
+    ws = ops.attn_workspace(L, 8, 1, dev)
+    ops.run(ops.mem_read_attn(q.to(BF16).to(dev), k.to(BF16).to(dev), v.to(BF16).to(dev), out, ws, Lq=L, ldq=C, ldkv=C, ldo=C,
+                              nchunks=1, lk_single=L))
+    torch.cuda.synchronize()
+    assert_close(out, ref, 2e-2, 'rescale branch')
+
+
+def test_layernorm(dev):
+    from rmem_ocu_amd import ops
+    M = 1674
+    a, b = seeded(60, (M, 256)), rb(seeded(61, (M, 256)))
+    g, be, pos = 1 + 0.1 * seeded(62, (256,)), 0.1 * seeded(63, (256,)), seeded(64, (M, 256))
+    ref = F.layer_norm(a + b, (256,), g, be, 1e-5)
+    y = torch.zeros(M, 1024, dtype=BF16, device=dev)
+    yp = torch.zeros(M, 256, dtype=BF16, device=dev)
+    yf = torch.zeros(M, 256, dtype=F32, device=dev)
+    ops.run(ops.layernorm256(a.to(dev), g.to(dev), be.to(dev), M=M, b=b.to(BF16).to(dev), y=y.view(-1)[256:], ldy=1024,
+                             pos=pos.to(dev), ypos=yp, yf=yf))
+    torch.cuda.synchronize()
+    assert_close(yf, ref, 1e-5, 'ln f32')
+    assert_close(y[:, 256:512], ref, 1e-2, 'ln bf16 strided')
+    assert_close(yp, ref + pos, 1e-2, 'ln + pos')
+    assert y[:, :256].abs().max().item() == 0
+
+
+@pytest.mark.parametrize('M,C,groups,act', [(1674, 1024, 32, 2), (1674, 256, 8, 1), (6527, 128, 8, 1), (300, 128, 8, 0)])
+def test_groupnorm(dev, M, C, groups, act):
+    from rmem_ocu_amd import ops
+    x = rb(seeded(70, (M, C)) * 2 + 0.5)
+    g, b = 1 + 0.1 * seeded(71, (C,)), 0.1 * seeded(72, (C,))
+    ref = F.group_norm(x.t().reshape(1, C, M, 1), groups, g, b, 1e-5)
+    ref = F.relu(ref) if act == 1 else F.gelu(ref) if act == 2 else ref
+    y = torch.zeros(M, C, dtype=BF16, device=dev)
+    ws = ops.groupnorm_workspace(groups, dev)
+    ops.run(ops.groupnorm(x.to(BF16).to(dev), g.to(dev), b.to(dev), y, ws, M=M, C=C, groups=groups, act=act))
+    torch.cuda.synchronize()
+    assert_close(y, ref.reshape(C, M).t(), 1e-2, 'groupnorm')
+
+
+def test_dwconv_and_ffn_activation(dev, synth_weights):
+    """basic.py:27-35 GN(32)+GELU+DW5x5 against the oracle's gn_gelu_dwconv."""
+    from oracle import ref_cpu as O
+    from rmem_ocu_amd import ops
+    h, w, C = 31, 54, 1024
+    x = rb(seeded(80, (h * w, 1, C)))
+    p = 'LSTT.layers.0.activation'
+    ref = O.gn_gelu_dwconv(x, (h, w), synth_weights, p)[:, 0]
+    xd = x[:, 0].to(BF16).to(dev)
+    y1 = torch.zeros(h * w, C, dtype=BF16, device=dev)
+    y2 = torch.zeros(h * w, C, dtype=BF16, device=dev)
+    ws = ops.groupnorm_workspace(32, dev)
+    wt = synth_weights[p + '.conv.weight'].view(C, 25).t().contiguous().to(dev)
+    ops.run([ops.groupnorm(xd, synth_weights[p + '.gn.weight'].to(dev), synth_weights[p + '.gn.bias'].to(dev), y1, ws, M=h * w, C=C, groups=32, act=2),
+             ops.dwconv5x5(y1, wt, y2, H=h, W=w, C=C)])
+    torch.cuda.synchronize()
+    assert_close(y2, ref, 2e-2, 'gn+gelu+dwconv')
+
+
+def test_resample_kernels(dev):
+    from rmem_ocu_amd import ops
+    # image -> NHWC8
+    img = seeded(90, (3, 97, 129))
+    out = torch.zeros(97 * 129, 8, dtype=BF16, device=dev)
+    ops.run(ops.image_to_nhwc8(img.to(dev), out, H=97, W=129))
+    assert_close(out[:, :3], rb(img).permute(1, 2, 0).reshape(-1, 3), 1e-6, 'nhwc8')
+    assert out[:, 3:].abs().max().item() == 0
+    # maxpool
+    x = rb(seeded(91, (1, 64, 49, 65)))
+    y = torch.zeros(25 * 33, 64, dtype=BF16, device=dev)
+    ops.run(ops.maxpool3x3s2(nhwc(x).to(dev), y, H=49, W=65, C=64))
+    assert_close(y, nhwc(F.max_pool2d(x, 3, 2, 1)), 1e-6, 'maxpool')
+    # bilinear, both align modes
+    x = rb(seeded(92, (1, 128, 31, 54)))
+    for ac, (ho, wo) in ((True, (61, 107)), (False, (62, 108))):
+        y = torch.zeros(ho * wo, 128, dtype=BF16, device=dev)
+        ops.run(ops.bilinear(nhwc(x).to(dev), y, Hi=31, Wi=54, Ho=ho, Wo=wo, C=128, align_corners=ac))
+        assert_close(y, nhwc(F.interpolate(x, size=(ho, wo), mode='bilinear', align_corners=ac)), 1e-2, f'bilinear ac={ac}')
+    # logits post
+    lg = seeded(93, (1, 11, 25, 33))
+    lgn = torch.zeros(25 * 33, 16)
+    lgn[:, :11] = lg[0].permute(1, 2, 0).reshape(-1, 11)
+    o = torch.zeros(11, 96, 128, dtype=F32, device=dev)
+    lab = torch.zeros(96, 128, dtype=torch.uint8, device=dev)
+    ops.run(ops.logits_post(lgn.to(dev), ldl=16, nc=11, keep=3, Hi=25, Wi=33, Ho=96, Wo=128, out=o, label_u8=lab))
+    ref = lg.clone()
+    ref[:, 4:] = -1e10
+    ref = F.interpolate(ref, size=(96, 128), mode='bilinear', align_corners=True)[0]
+    assert_close(o[:4], ref[:4], 1e-5, 'logits')
+    assert (o[4:] < -1e9).all()
+    assert (lab.cpu().long() == ref.argmax(0)).float().mean().item() > 0.9999
+    torch.cuda.synchronize()
+
+
+def test_label_onehot_and_id_bank(dev, synth_weights):
+    """a11: label -> nearest resize -> one-hot -> 17x17 s16 conv against the oracle's assign_identity."""
+    from oracle import ref_cpu as O
+    from rmem_ocu_amd import ops
+    from rmem_ocu_amd.pack import _conv_w
+    lab = torch.zeros(96, 128)
+    lab[10:50, 20:70] = 1
+    lab[40:90, 60:120] = 3
+    lab[0:8, 0:8] = 255
+    H, W = 97, 129
+    near = F.interpolate(lab[None, None], size=(H, W), mode='nearest')
+    oh, ign = O.one_hot_mask(near)
+    ref = O.assign_identity(oh, ign, synth_weights)[:, 0]
+    onehot = torch.zeros(H * W, 16, dtype=BF16, device=dev)
+    emb = torch.zeros(7 * 9, 256, dtype=BF16, device=dev)
+    w = _conv_w(synth_weights['patch_wise_id_bank.weight'], 16).to(dev)
+    ops.run([ops.label_to_onehot16(lab.to(torch.uint8).to(dev), onehot, Hs=96, Ws=128, Hd=H, Wd=W),
+             ops.conv2d(onehot, w, synth_weights['patch_wise_id_bank.bias'].to(dev), emb, H=H, W=W, Cin=16, Cout=256, KH=17, KW=17, stride=16, pad=8)])
+    torch.cuda.synchronize()
+    assert_close(emb, ref, 1.5e-2, 'id emb')
+
+
+def test_evict_scores(dev):
+    from rmem_ocu_amd import ops
+    lg = seeded(95, (1, 11, 25, 33))
+    lgn = torch.zeros(25 * 33, 16)
+    lgn[:, :11] = lg[0].permute(1, 2, 0).reshape(-1, 11)
+    mass = seeded(96, (7 * 9, 5)).abs()
+    fg = 1 - torch.softmax(F.interpolate(lg, size=(7, 9), mode='bilinear', align_corners=True), 1)[0, 0].flatten()
+    ref = (mass * fg[:, None]).sum(0)
+    sc = torch.zeros(32, dtype=F32, device=dev)
+    ops.run(ops.evict_scores(lgn.to(dev), mass.to(dev), sc, ldl=16, nc=11, keep=10, Hi=25, Wi=33, He=7, We=9, T=5))
+    torch.cuda.synchronize()
+    assert_close(sc[:5], ref, 1e-4, 'evict scores')
