@@ -15,7 +15,7 @@ layers/transformer.py:641); the attention-weight top-32 D2H of every layer
 """
 from __future__ import annotations
 
-import math
+import contextlib
 from typing import Dict, List, Optional
 
 import numpy as np
@@ -68,6 +68,11 @@ class AOTEngine:
         if short_term_mem_skip != 1:
             raise NotImplementedError('short_term_mem_skip != 1 is not used by the reference evaluator')
         self.device = torch.device('cuda', gpu_id)
+        # every engine enqueues on its own HIP stream (clips overlap on the GPU; the null stream cannot be
+        # captured into a hipGraph); sync_caller orders it after/before the caller's current stream like
+        # the reference's default-stream semantics
+        self.stream = torch.cuda.Stream(self.device)
+        self.sync_caller = True
         self.rt: Optional[ClipRuntime] = None
         self.use_graphs = False
         self._graphs: Dict[str, ops.Graph] = {}
@@ -101,7 +106,17 @@ class AOTEngine:
         self.enc_hw = self.enc_size_2d[0] * self.enc_size_2d[1]
 
     def _stream(self) -> int:
-        return torch.cuda.current_stream(self.device).cuda_stream
+        return self.stream.cuda_stream
+
+    @contextlib.contextmanager
+    def _scope(self):
+        cur = torch.cuda.current_stream(self.device)
+        if self.sync_caller:
+            self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            yield cur
+        if self.sync_caller:
+            cur.wait_stream(self.stream)
 
     def _ensure_runtime(self, img):
         H, W = int(img.shape[-2]), int(img.shape[-1])
@@ -151,22 +166,22 @@ class AOTEngine:
         rt = self._ensure_runtime(img)
         if self.input_size_2d is None:
             self.update_size(img.shape[2:], (rt.H16, rt.W16))
-        self.img_in.copy_(img.reshape(3, rt.H, rt.W), non_blocking=True)
-        self._set_label(mask)
-        s = self._stream()
-        # (re)initialise the bank to this frame only (aot_engine.py:322; quirk: long_memories_indexes keeps growing, 323)
-        rt.reset_bank()
-        slot = rt.take_slot()
-        rt.slots.append(slot)
-        rt.upload_chunks(s)
-        self._run('encode', rt.prog_encode(self.img_in))
-        self._run('id_label_in', rt.prog_id_emb(self.label_in, rt.H, rt.W))
-        self._run(f'lstt_ref{slot}', rt.prog_lstt(True, 1, slot))
-        self.last_mem_step = frame_step
-        self.policy = MemoryPolicy()
-        self.long_memories_indexes.append(self.frame_step)
-        self._run('decode', rt.prog_decode())
-        self.pred_id_logits = rt.logits
+        with self._scope():
+            self.img_in.copy_(img.reshape(3, rt.H, rt.W), non_blocking=True)
+            self._set_label(mask)
+            # (re)initialise the bank to this frame only (aot_engine.py:322; quirk: long_memories_indexes keeps growing, 323)
+            rt.reset_bank()
+            slot = rt.take_slot()
+            rt.slots.append(slot)
+            rt.upload_chunks(self._stream())
+            self._run('encode', rt.prog_encode(self.img_in))
+            self._run('id_label_in', rt.prog_id_emb(self.label_in, rt.H, rt.W))
+            self._run(f'lstt_ref{slot}', rt.prog_lstt(True, 1, slot))
+            self.last_mem_step = frame_step
+            self.policy = MemoryPolicy()
+            self.long_memories_indexes.append(self.frame_step)
+            self._run('decode', rt.prog_decode())
+            self.pred_id_logits = rt.logits
 
     # ------------------------------------------------------------------ propagate
     def match_propogate_one_frame(self, img=None, img_embs=None, mask=None, output_size=None):
@@ -174,17 +189,26 @@ class AOTEngine:
         if img is None:
             raise ValueError('match_propogate_one_frame needs the frame (offline encoding is a training-only path)')
         rt = self.rt
-        self.img_in.copy_(img.reshape(3, rt.H, rt.W), non_blocking=True)
-        T = len(rt.slots)
-        self._T_at_propagate = T
-        self._run('encode', rt.prog_encode(self.img_in))
-        self._run(f'lstt_prop{T}', rt.prog_lstt(False, T))
-        self._run('decode', rt.prog_decode())
-        self.pred_id_logits = rt.logits
-        return self.decode_current_logits(output_size)
+        with self._scope() as cur:
+            self.img_in.copy_(img.reshape(3, rt.H, rt.W), non_blocking=True)
+            T = len(rt.slots)
+            self._T_at_propagate = T
+            self._run('encode', rt.prog_encode(self.img_in))
+            self._run(f'lstt_prop{T}', rt.prog_lstt(False, T))
+            self._run('decode', rt.prog_decode())
+            self.pred_id_logits = rt.logits
+            out = self._logits_out(output_size)
+            out.record_stream(cur)
+        return out
 
     def decode_current_logits(self, output_size=None):
         """Logits with unused ids masked (aot_engine.py:450-453), resized to output_size (457-463)."""
+        with self._scope() as cur:
+            out = self._logits_out(output_size)
+            out.record_stream(cur)
+        return out
+
+    def _logits_out(self, output_size=None):
         rt = self.rt
         Ho, Wo = (rt.H4, rt.W4) if output_size is None else (int(output_size[0]), int(output_size[1]))
         out = torch.empty(1, rt.nc, Ho, Wo, dtype=F32, device=self.device)
@@ -208,17 +232,19 @@ class AOTEngine:
         rt = self.rt
         if curr_mask.dim() == 4 and curr_mask.shape[1] != 1:
             raise NotImplementedError('probability masks (>10 objects soft aggregation) are not built yet')
-        self._set_label(curr_mask)
-        self._run('id_label_in', rt.prog_id_emb(self.label_in, rt.H, rt.W))
-        self._finish_update()
+        with self._scope():
+            self._set_label(curr_mask)
+            self._run('id_label_in', rt.prog_id_emb(self.label_in, rt.H, rt.W))
+            self._finish_update()
 
     def update_memory_from_label_u8(self, label_u8: torch.Tensor):
         """Fast path: argmax labels at the OUTPUT size (uint8 [Ho, Wo], device); the nearest resize to the
         network size (evaluator.py:518-522) happens inside the one-hot kernel."""
         rt = self.rt
         hs, ws = int(label_u8.shape[-2]), int(label_u8.shape[-1])
-        self._run(f'id_u8_{label_u8.data_ptr()}', rt.prog_id_emb(label_u8, hs, ws))
-        self._finish_update()
+        with self._scope():
+            self._run(f'id_u8_{label_u8.data_ptr()}', rt.prog_id_emb(label_u8, hs, ws))
+            self._finish_update()
 
     def _finish_update(self):
         rt, s = self.rt, self._stream()
