@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""bench.py -- frames/s of the MI355X memory-reading VOS engine on BASELINE.json's cfg 2.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload (config.workload = "davis17_480p_r50_N8"): synthetic 480x854 clips of 80 frames at network
+size 481x849 (HW = 1674 tokens), ResNet-50 + 3-layer LSTT + FPN, memory bank N = 8 (1 + 7),
+per-clip gap = max(round(80/30), 5) = 5, 3 objects, bf16 operands / fp32 accumulation.
+A *step* is one propagated frame of one clip: match-propagate + argmax + memory update -- the
+reference's own FPS unit (managers/evaluator.py:399-404, 525-535).  Clips are independent, so
+each rank keeps several clips in flight on separate HIP streams and ranks never exchange data on
+the hot path (weak scaling: per-GPU work is fixed); the only collectives are the barriers around
+the timed region and one final gather of (frames, seconds, checksum) to rank 0.
+Reference frames that fall inside the timed region are executed but not counted as steps.
+Inputs are resident in HBM when the timed region starts.
+
+The single JSON line also carries
+  roofline     -- the dominant kernel (k_attn_partial<true>, the long-term memory read): algorithmic
+                  FLOPs 4*HW*(T*HW)*256 per launch / launch duration measured with HIP events on the
+                  launch stream for a 1-in-8 sample of the timed frames; peak = 2.5 PFLOP/s dense bf16.
+  cpu_baseline -- oracle/ref_cpu.py (fp32 port of the reference path) timed on this host's cores on a
+                  bounded sample of the same workload (rank 0, N = 1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CLIP_LEN = 80
+VIDEO_HW = (480, 854)
+NUM_OBJS = 3
+PEAK_BF16_TFLOPS = 2500.0
+
+
+def cpu_baseline(frames, mask, n_timed=8):
+    """Oracle (CPU port of the reference path) on a bounded sample: bank filled to N = 8 with gap 1 over 8
+    untimed frames, then n_timed propagated frames at T = 8 are timed (propagate + update)."""
+    from oracle import ref_cpu as O
+    from rmem_ocu_amd.weights import synth_state_dict
+    import torch.nn.functional as F
+    threads = torch.get_num_threads()
+    eng = O.OracleEngine(synth_state_dict(0), 1, 7, 1)
+    with torch.no_grad():
+        eng.add_reference_frame(frames[0:1], mask, 0)
+        t0 = None
+        for i in range(1, 9 + n_timed):
+            if i == 9:
+                t0 = time.time()
+            logit = eng.match_propogate_one_frame(frames[i:i + 1], VIDEO_HW)
+            label = torch.argmax(torch.softmax(logit, 1), 1, keepdim=True).float()
+            eng.update_memory(F.interpolate(label, size=eng.input_size_2d, mode='nearest'))
+        dt = time.time() - t0
+    return {'value': round(n_timed / dt, 4), 'unit': 'frames/s', 'cores': threads, 'kind': 'port',
+            'sample': f'{n_timed} propagated frames at 481x849, bank T=8 (steady state of the 80-frame clip), fp32, after 9 untimed frames'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=790)
+    ap.add_argument('--warmup', type=int, default=79)
+    ap.add_argument('--clips-in-flight', type=int, default=int(os.environ.get('RMEM_CLIPS_IN_FLIGHT', 4)))
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-graphs', action='store_true')
+    ap.add_argument('--sample-every', type=int, default=8, help='time the memory-read kernel on 1 in N timed frames')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}')
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: there is no CPU execution path for the product')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=dev)
+
+    from rmem_ocu_amd import _lib, build_engine, build_vos_model, get_config
+    from rmem_ocu_amd.clip_runner import ClipSlot
+    from rmem_ocu_amd.synth import make_clip, network_size
+    from rmem_ocu_amd.weights import synth_state_dict
+
+    cfg = get_config('pre_vost', 'bench', 'r50_aotl')
+    cfg.FORMER_MEM_LEN, cfg.LATTER_MEM_LEN = 1, 7
+    model = build_vos_model(cfg.MODEL_VOS, cfg).cuda(local_rank)
+    model.load_state_dict(synth_state_dict(0))
+    net_hw = network_size(*VIDEO_HW)
+
+    # two distinct synthetic clips per rank, reused round-robin by the clip slots
+    clips_host = [make_clip(1000 * rank + j, CLIP_LEN, net_hw[0], net_hw[1], NUM_OBJS) for j in range(2)]
+    clips = [(f.to(dev), m.to(dev)) for f, m in clips_host]
+
+    C = max(1, args.clips_in_flight)
+    slots = []
+    for j in range(C):
+        eng = build_engine(cfg.MODEL_ENGINE, phase='eval', aot_model=model, gpu_id=local_rank, long_term_mem_gap=5)
+        eng.set_async(use_graphs=not args.no_graphs)
+        slots.append(ClipSlot(eng, VIDEO_HW, dev))
+
+    # ---- priming (untimed setup): one whole clip per slot builds every launch list / hipGraph (T = 1..8) ----
+    for j, s in enumerate(slots):
+        s.start(*clips[j % 2], NUM_OBJS)
+        while not s.done:
+            s.step()
+    torch.cuda.synchronize()
+    # stagger the slots so they are at different clip positions (a steady mix of bank sizes)
+    for j, s in enumerate(slots):
+        s.start(*clips[j % 2], NUM_OBJS)
+        for _ in range((j * (CLIP_LEN - 1)) // C):
+            s.step()
+    torch.cuda.synchronize()
+
+    next_clip = [0]
+
+    def run_steps(n, sample_every=0):
+        done = 0
+        j = 0
+        while done < n:
+            s = slots[j % C]
+            j += 1
+            if s.done:
+                next_clip[0] += 1
+                s.start(*clips[next_clip[0] % 2], NUM_OBJS)      # reference frame: executed, not counted
+            inner = s.engine.aot_engines[0]
+            eager = sample_every and (done % sample_every == 0)
+            if eager:
+                inner.use_graphs = False
+            s.step()
+            if eager:
+                inner.use_graphs = not args.no_graphs
+            done += 1
+
+    run_steps(args.warmup)
+    torch.cuda.synchronize()
+
+    L = _lib.lib()
+    _lib.check(L.rmem_profile_start(4 * (args.steps // max(1, args.sample_every) + 4)), 'rmem_profile_start')
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run_steps(args.steps, args.sample_every)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    ms, fl, nl = ctypes.c_double(), ctypes.c_double(), ctypes.c_int()
+    _lib.check(L.rmem_profile_stop(ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(nl)), 'rmem_profile_stop')
+
+    checksum = float(sum(int(s.labels.sum().item()) for s in slots))
+    stats = torch.tensor([elapsed, float(args.steps), checksum], dtype=torch.float64, device=dev)
+    if dist is not None:
+        gathered = [torch.zeros_like(stats) for _ in range(world)] if rank == 0 else None
+        dist.gather(stats, gathered, dst=0)          # the one data exchange: a few bytes per rank
+        if rank == 0:
+            elapsed = max(float(g[0]) for g in gathered)
+            total_steps = sum(float(g[1]) for g in gathered)
+    else:
+        total_steps = float(args.steps)
+
+    if rank == 0:
+        achieved = (fl.value / (ms.value * 1e-3)) / 1e12 if nl.value and ms.value > 0 else None
+        out = {
+            'metric': 'frames/sec (whole node) 480p VOS, N=8 memory bank', 'value': round(total_steps / elapsed, 2), 'unit': 'frames/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * elapsed / args.steps, 4),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+            'config': {'workload': 'davis17_480p_r50_N8', 'clip_frames': CLIP_LEN, 'video_hw': list(VIDEO_HW), 'network_hw': list(net_hw),
+                       'tokens': 1674, 'objects': NUM_OBJS, 'memory_bank': '1+7', 'gap': 5, 'clips_in_flight_per_gpu': C,
+                       'parallelism': f'clip-parallel x{world}', 'weights': 'synthetic (no checkpoint offline)',
+                       'hipgraphs': not args.no_graphs},
+            'roofline': {'bound': 'mfma', 'kernel': 'k_attn_partial<true>', 'achieved': None if achieved is None else round(achieved, 2),
+                         'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': None if achieved is None else round(achieved / PEAK_BF16_TFLOPS, 4),
+                         'traffic': None, 'launches_timed': nl.value,
+                         'avg_launch_us': None if not nl.value else round(1e3 * ms.value / nl.value, 2)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(*clips_host[0])
+        else:
+            out['cpu_baseline'] = None
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

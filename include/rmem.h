@@ -78,13 +78,21 @@ int rmem_mem_read_attn(const void* q, int ldq,                     /* bf16 [Lq][
                        const void* k_bank, const void* v_bank,     /* bf16, rows [Lk][ldkv] per slot */
                        long long slot_stride, int ldkv,
                        const rmem_attn_chunk* chunks, int nchunks, /* device table, or NULL */
-                       int lk_single,                              /* keys when chunks == NULL */
+                       int lk_single,                              /* keys when chunks == NULL; with a table: total keys
+                                                                      named by it (used by rmem_profile_* only) */
                        const float* pe_cur,                        /* fp32 [C] or NULL */
                        const float* pe_mem,                        /* fp32 [4][C] or NULL */
                        int Lq, int heads,
                        void* out, int ldo,                         /* bf16 [Lq][ldo] */
                        float* attn_mass, int T,                    /* fp32 [Lq][T] or NULL */
                        void* workspace, void* stream);
+
+/* Optional timing of the memory-read launches (chunks != NULL) with HIP events on the launch stream:
+ * between start and stop every such launch outside a graph capture is bracketed by two events;
+ * stop() synchronises on them and returns the summed kernel time, the summed algorithmic FLOPs
+ * (4 * Lq * keys * C per launch) and the launch count.  Used by bench.py's roofline leg. */
+int rmem_profile_start(int max_launches);
+int rmem_profile_stop(double* total_ms, double* total_flops, int* launches);
 
 /* ------------------------------------------------------------------ normalisation / activation
  * LayerNorm over 256 channels of (a [+ b]); writes any of: bf16 y, fp32 y, bf16 (y + pos).

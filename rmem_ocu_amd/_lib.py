@@ -36,6 +36,8 @@ SIGNATURES = {
     'rmem_conv2d_nhwc': (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'rmem_attn_workspace_bytes': (C.c_size_t, [_i, _i, _i]),
     'rmem_mem_read_attn': (_i, [_vp, _i, _vp, _vp, _ll, _i, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _vp, _vp]),
+    'rmem_profile_start': (_i, [_i]),
+    'rmem_profile_stop': (_i, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i)]),
     'rmem_layernorm256': (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _f, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _vp]),
     'rmem_add_bf16': (_i, [_vp, _vp, _vp, _ll, _vp]),
     'rmem_groupnorm_workspace_bytes': (C.c_size_t, [_i]),
@@ -74,6 +76,9 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise RmemError(f'{LIB_PATH} is missing: run `python -c "import __graft_entry__ as g; g.build()"` '
                             '(there is no CPU fallback for the HIP path)')
+        # torch bundles its own libamdhip64; it must be in the process first so that this library binds to the
+        # SAME HIP runtime (streams and device pointers are torch's), not to a second copy from /opt/rocm
+        import torch  # noqa: F401
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)

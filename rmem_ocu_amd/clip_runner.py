@@ -1,0 +1,68 @@
+"""Clip-parallel driver: many clips in flight per GPU, one process per GPU.
+
+Mirrors the reference's evaluation protocol (managers/evaluator.py:330-335, 385-441, 509-523:
+per-sequence gap = max(round(n/30), 5), reference frame, then propagate -> argmax -> update per
+frame) and its multi-GPU scheme (tools/eval.py:137-143, evaluator.py:276-295: one worker per GPU
+draining a queue of sequences; no collective on the data path, one final gather of statistics).
+Frames inside a clip are strictly sequential (short-term memory recurrence + mask feedback), so
+a GPU is filled by interleaving independent clips: each clip owns an engine, a HIP stream and its
+hipGraphs; the host only enqueues.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import torch
+
+
+def shard_clips(num_clips: int, rank: int, world: int, lengths: Optional[Sequence[int]] = None) -> List[int]:
+    """Static longest-first assignment of clip ids to ranks (the reference pops a shared queue; with
+    equal hardware a greedy longest-first split gives the same balance without a host-side queue)."""
+    ids = list(range(num_clips))
+    if lengths is not None:
+        ids.sort(key=lambda i: (-lengths[i], i))
+    loads = [0] * world
+    mine: List[int] = []
+    for i in ids:
+        r = min(range(world), key=lambda j: (loads[j], j))
+        loads[r] += lengths[i] if lengths is not None else 1
+        if r == rank:
+            mine.append(i)
+    return mine
+
+
+class ClipSlot:
+    """One clip in flight: an engine, its frames on the device, its output label buffer."""
+
+    def __init__(self, engine, out_hw, device):
+        self.engine = engine
+        self.labels: Optional[torch.Tensor] = None
+        self.cur_label = torch.zeros(out_hw[0], out_hw[1], dtype=torch.uint8, device=device)   # fixed address (graph-captured)
+        self.out_hw = out_hw
+        self.device = device
+        self.frames = None
+        self.cursor = 0
+        self.done = True
+
+    def start(self, frames: torch.Tensor, first_mask: torch.Tensor, num_objs: int):
+        """frames [n,3,H,W] fp32 device, first_mask [1,1,H,W] at network size."""
+        n = frames.shape[0]
+        self.frames = frames
+        if self.labels is None or self.labels.shape[0] < n:
+            self.labels = torch.zeros(n, self.out_hw[0], self.out_hw[1], dtype=torch.uint8, device=self.device)
+        eng = self.engine
+        eng.restart_engine()
+        eng.long_term_mem_gap = max(int(round(n / 30)), 5)      # evaluator.py:330-335
+        eng.add_reference_frame(frames[0:1], first_mask, obj_nums=[num_objs], frame_step=0)
+        self.cursor = 1
+        self.done = n <= 1
+
+    def step(self):
+        """Propagate one frame and update the memory with the predicted labels (all asynchronous)."""
+        i = self.cursor
+        self.engine.propagate_to_label(self.frames[i:i + 1], self.cur_label)
+        self.engine.update_memory_from_label_u8(self.cur_label)
+        with torch.cuda.stream(self.engine.aot_engines[0].stream):
+            self.labels[i].copy_(self.cur_label, non_blocking=True)      # the clip's delivered masks stay on the device
+        self.cursor += 1
+        self.done = self.cursor >= self.frames.shape[0]

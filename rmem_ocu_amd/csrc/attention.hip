@@ -27,6 +27,8 @@
 // Logits live in the log2 domain: Q is pre-scaled by log2(e)/sqrt(32).
 #include "common.h"
 #include "../../include/rmem.h"
+#include <mutex>
+#include <vector>
 
 namespace {
 
@@ -47,6 +49,9 @@ struct AttnParams {
 
 __device__ __forceinline__ int kswz(int row, int chunk) { return row * D + ((chunk ^ ((row >> 2) & 3)) << 3); }
 
+// MEM = true: memory-read flavour (chunk table, temporal PE); false: one plain key frame.  Two symbols so a
+// kernel trace separates the long-term memory read from the short-term / self attention launches.
+template <bool MEM>
 __global__ __launch_bounds__(256) void k_attn_partial(AttnParams p) {
   __shared__ __attribute__((aligned(16))) bf16 Ks[2][KT * D];
   __shared__ __attribute__((aligned(16))) bf16 Vt[2][D * VT_LD];
@@ -56,7 +61,7 @@ __global__ __launch_bounds__(256) void k_attn_partial(AttnParams p) {
   const int head = blockIdx.y, c = blockIdx.z;
 
   int slot, kb, kn, pe_slot;
-  if (p.chunks) {
+  if (MEM) {
     const rmem_attn_chunk ch = p.chunks[c];
     slot = ch.slot; kb = ch.key_begin; kn = ch.key_count; pe_slot = ch.pe_slot;
   } else {
@@ -76,10 +81,10 @@ __global__ __launch_bounds__(256) void k_attn_partial(AttnParams p) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       float f = (float)raw[j];
-      if (p.pe_cur) f += p.pe_cur[d0 + j];
+      if (MEM && p.pe_cur) f += p.pe_cur[d0 + j];
       const bf16 b = (bf16)(f * p.qscale);
       qf[s][j] = b;
-      if (pe_slot >= 0) bias += (float)b * p.pe_mem[pe_slot * p.C + d0 + j];
+      if (MEM && pe_slot >= 0) bias += (float)b * p.pe_mem[pe_slot * p.C + d0 + j];
     }
   }
   bias += __shfl_xor(bias, 32, 64);
@@ -233,7 +238,50 @@ __global__ __launch_bounds__(256) void k_attn_combine(CombineParams p) {
   }
 }
 
+// ---- optional launch timing of the memory-read kernel (bench.py's roofline leg) ----
+struct ProfState {
+  std::mutex mu;
+  bool on = false;
+  std::vector<hipEvent_t> ev;   // pairs
+  std::vector<double> flops;
+  size_t used = 0;
+};
+ProfState g_prof;
+
 }  // namespace
+
+extern "C" int rmem_profile_start(int max_launches) {
+  std::lock_guard<std::mutex> lk(g_prof.mu);
+  RMEM_REQUIRE(max_launches > 0, "rmem_profile_start: max_launches must be > 0");
+  while (g_prof.ev.size() < (size_t)max_launches * 2) {
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) { rmem_set_error("rmem_profile_start: hipEventCreate failed"); return -3; }
+    g_prof.ev.push_back(e);
+  }
+  g_prof.flops.assign(max_launches, 0.0);
+  g_prof.used = 0;
+  g_prof.on = true;
+  return 0;
+}
+
+extern "C" int rmem_profile_stop(double* total_ms, double* total_flops, int* launches) {
+  std::lock_guard<std::mutex> lk(g_prof.mu);
+  g_prof.on = false;
+  double ms = 0.0, fl = 0.0;
+  for (size_t i = 0; i < g_prof.used; ++i) {
+    float t = 0.f;
+    if (hipEventSynchronize(g_prof.ev[2 * i + 1]) != hipSuccess || hipEventElapsedTime(&t, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]) != hipSuccess) {
+      rmem_set_error("rmem_profile_stop: event query failed");
+      return -3;
+    }
+    ms += t;
+    fl += g_prof.flops[i];
+  }
+  if (total_ms) *total_ms = ms;
+  if (total_flops) *total_flops = fl;
+  if (launches) *launches = (int)g_prof.used;
+  return 0;
+}
 
 extern "C" size_t rmem_attn_workspace_bytes(int Lq, int heads, int nchunks) {
   return (size_t)nchunks * heads * Lq * (D + 2) * sizeof(float);
@@ -243,12 +291,14 @@ extern "C" int rmem_mem_read_attn(const void* q, int ldq, const void* k_bank, co
                                   int ldkv, const rmem_attn_chunk* chunks, int nchunks, int lk_single,
                                   const float* pe_cur, const float* pe_mem, int Lq, int heads, void* out, int ldo,
                                   float* attn_mass, int T, void* workspace, void* stream) {
+  const long long prof_keys = chunks ? (long long)lk_single : 0;   // with a chunk table lk_single carries the total key count (timing only)
   RMEM_REQUIRE(q && k_bank && v_bank && out && workspace, "rmem_mem_read_attn: null argument");
   RMEM_REQUIRE(heads >= 1 && heads <= 8, "rmem_mem_read_attn: heads must be in 1..8 (head dim is fixed at 32)");
   RMEM_REQUIRE(Lq > 0 && nchunks >= 1 && nchunks <= 32, "rmem_mem_read_attn: need Lq > 0 and 1 <= nchunks <= 32");
   RMEM_REQUIRE(ldq % 8 == 0 && ldkv % 8 == 0 && slot_stride % 8 == 0, "rmem_mem_read_attn: strides must be multiples of 8 elements");
   RMEM_REQUIRE(ldq >= heads * D && ldkv >= heads * D && ldo >= heads * D, "rmem_mem_read_attn: leading dimension < heads*32");
   RMEM_REQUIRE(chunks || lk_single > 0, "rmem_mem_read_attn: lk_single must be > 0 when no chunk table is given");
+  RMEM_REQUIRE(lk_single >= 0, "rmem_mem_read_attn: lk_single must be >= 0");
   RMEM_REQUIRE(!attn_mass || (chunks && T >= 1 && T <= 32), "rmem_mem_read_attn: the mass output needs a chunk table and 1 <= T <= 32");
   RMEM_REQUIRE(!pe_mem || chunks, "rmem_mem_read_attn: pe_mem needs a chunk table");
   hipStream_t s = (hipStream_t)stream;
@@ -261,7 +311,27 @@ extern "C" int rmem_mem_read_attn(const void* q, int ldq, const void* k_bank, co
   p.opart = (float*)workspace; p.ml = p.opart + (size_t)nchunks * heads * Lq * D;
   p.qscale = 1.4426950408889634f / sqrtf((float)D);
   dim3 grid((Lq + 127) / 128, heads, nchunks);
-  hipLaunchKernelGGL(k_attn_partial, grid, dim3(256), 0, s, p);
+  if (chunks) {
+    // time this launch if asked to (never while the stream is being captured into a graph)
+    long slot_i = -1;
+    double keys = 0.0;
+    if (g_prof.on && prof_keys > 0) {
+      hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+      (void)hipStreamIsCapturing(s, &cs);
+      if (cs == hipStreamCaptureStatusNone) {
+        std::lock_guard<std::mutex> lk(g_prof.mu);
+        if (g_prof.on && g_prof.used * 2 + 1 < g_prof.ev.size()) { slot_i = (long)g_prof.used++; keys = (double)prof_keys; }
+      }
+    }
+    if (slot_i >= 0) (void)hipEventRecord(g_prof.ev[2 * slot_i], s);
+    hipLaunchKernelGGL(k_attn_partial<true>, grid, dim3(256), 0, s, p);
+    if (slot_i >= 0) {
+      (void)hipEventRecord(g_prof.ev[2 * slot_i + 1], s);
+      g_prof.flops[slot_i] = 4.0 * (double)Lq * keys * (double)(heads * D);   // QK^T + PV
+    }
+  } else {
+    hipLaunchKernelGGL(k_attn_partial<false>, grid, dim3(256), 0, s, p);
+  }
   CombineParams cp;
   cp.opart = p.opart; cp.ml = p.ml; cp.chunks = chunks; cp.nchunks = nchunks; cp.Lq = Lq; cp.heads = heads;
   cp.out = (bf16*)out; cp.ldo = ldo; cp.mass = attn_mass; cp.T = T;

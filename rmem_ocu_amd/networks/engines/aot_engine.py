@@ -201,6 +201,28 @@ class AOTEngine:
             out.record_stream(cur)
         return out
 
+    def propagate_to_label(self, img, label_u8):
+        """Fused fast path of one frame: propagate, then argmax labels (uint8 [Ho, Wo], caller's device
+        buffer at a fixed address) straight from the 1/4-resolution logits -- the evaluator's
+        softmax -> argmax (managers/evaluator.py:430-441) without materialising [11, Ho, Wo] logits."""
+        self.frame_step += 1
+        rt = self.rt
+        Ho, Wo = int(label_u8.shape[-2]), int(label_u8.shape[-1])
+        keep = self.obj_nums[0] if self.obj_nums else self.max_obj_num
+        with self._scope():
+            self.img_in.copy_(img.reshape(3, rt.H, rt.W), non_blocking=True)
+            T = len(rt.slots)
+            self._T_at_propagate = T
+            self._run('encode', rt.prog_encode(self.img_in))
+            self._run(f'lstt_prop{T}', rt.prog_lstt(False, T))
+            self._run('decode', rt.prog_decode())
+            key = f'post_{label_u8.data_ptr()}_{Ho}_{Wo}'
+            if key not in rt._prog:
+                rt._prog[key] = [ops.logits_post(rt.logits, ldl=16, nc=rt.nc, keep=keep, Hi=rt.H4, Wi=rt.W4, Ho=Ho, Wo=Wo,
+                                                 align_corners=self.align_corners, label_u8=label_u8)]
+            self._run(key, rt._prog[key])
+            self.pred_id_logits = rt.logits
+
     def decode_current_logits(self, output_size=None):
         """Logits with unused ids masked (aot_engine.py:450-453), resized to output_size (457-463)."""
         with self._scope() as cur:
@@ -342,6 +364,7 @@ class AOTInferEngine:
             else:
                 eng = AOTEngine(self.AOT, self.gpu_id, self.long_term_mem_gap, self.short_term_mem_skip)
             eng.use_graphs = self.use_graphs
+            eng.sync_caller = not getattr(self, '_async', False)
             self.aot_engines.append(eng)
         for eng, m in zip(self.aot_engines, self.separate_mask(mask)):
             eng.add_reference_frame(img, m, obj_nums=[self.max_aot_obj_num], frame_step=frame_step)
@@ -354,6 +377,27 @@ class AOTInferEngine:
     def update_memory(self, curr_mask):
         for eng, m in zip(self.aot_engines, self.separate_mask(curr_mask)):
             eng.update_short_term_memory(m)
+
+    # -- fused fast path (single engine, <= 10 objects): labels in, labels out, everything on the engine's stream
+    def propagate_to_label(self, img, label_u8):
+        if len(self.aot_engines) != 1:
+            raise NotImplementedError('the fused label path covers clips with <= 10 objects')
+        self.aot_engines[0].propagate_to_label(img, label_u8)
+
+    def update_memory_from_label_u8(self, label_u8):
+        self.aot_engines[0].update_memory_from_label_u8(label_u8)
+
+    def set_async(self, use_graphs=True):
+        """Detach the engines from the caller's stream (each clip runs on its own stream) and replay frames as hipGraphs."""
+        self.use_graphs = use_graphs
+        for e in self.aot_engines + self._pool:
+            e.use_graphs = use_graphs
+            e.sync_caller = False
+        self._async = True
+
+    def synchronize(self):
+        for e in self.aot_engines:
+            e.stream.synchronize()
 
     def update_size(self):
         self.input_size_2d = self.aot_engines[0].input_size_2d

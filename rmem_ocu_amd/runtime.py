@@ -258,7 +258,7 @@ class ClipRuntime:
                 o.append(self._lin(self.curr_V[i], d + '.linear_Q', cq, L, C, C))
                 sk, sv = self.short_K[i], self.short_V[i]
             o.append(self._attn(cq, C, self.bank_K[i], self.bank_V[i], C, self.att, slot_stride=L * C, chunks=self.chunks,
-                                nchunks=nchunks, pe_cur=P['pe_cur'], pe_mem=P['pe_mem'],
+                                nchunks=nchunks, lk_single=(1 if ref_mode else T) * L, pe_cur=P['pe_cur'], pe_mem=P['pe_mem'],
                                 mass=self.mass if (i == 0 and not ref_mode) else None, T=T))
             o.append(self._lin(self.att, d + '.long_proj', self.x, L, C, C, residual=self.x))
             o.append(ops.layernorm256(sk, P[d + '.ln4.g'], P[d + '.ln4.b'], M=L, b=cq, y=self.k4))
