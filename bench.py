@@ -48,7 +48,8 @@ def cpu_baseline(frames, mask, n_timed=8):
     from oracle import ref_cpu as O
     from rmem_ocu_amd.weights import synth_state_dict
     import torch.nn.functional as F
-    threads = torch.get_num_threads()
+    threads = int(os.environ.get('RMEM_CPU_THREADS', min(16, os.cpu_count() or 1)))   # the 1-GPU box's CPU share is 16 cores
+    torch.set_num_threads(threads)
     eng = O.OracleEngine(synth_state_dict(0), 1, 7, 1)
     with torch.no_grad():
         eng.add_reference_frame(frames[0:1], mask, 0)
@@ -111,17 +112,20 @@ def main():
         eng.set_async(use_graphs=not args.no_graphs)
         slots.append(ClipSlot(eng, VIDEO_HW, dev))
 
-    # ---- priming (untimed setup): one whole clip per slot builds every launch list / hipGraph (T = 1..8) ----
+    # ---- priming (untimed setup): every slot runs one whole clip, interleaved exactly like the timed region, which builds
+    # every launch list / hipGraph (T = 1..8); then the slots are staggered so they sit at different clip positions ----
     for j, s in enumerate(slots):
         s.start(*clips[j % 2], NUM_OBJS)
-        while not s.done:
-            s.step()
-    torch.cuda.synchronize()
-    # stagger the slots so they are at different clip positions (a steady mix of bank sizes)
+    while not all(s.done for s in slots):
+        for s in slots:
+            if not s.done:
+                s.step()
     for j, s in enumerate(slots):
         s.start(*clips[j % 2], NUM_OBJS)
-        for _ in range((j * (CLIP_LEN - 1)) // C):
-            s.step()
+    for k in range(CLIP_LEN - 1):
+        for j, s in enumerate(slots):
+            if k < (j * (CLIP_LEN - 1)) // C:
+                s.step()
     torch.cuda.synchronize()
 
     next_clip = [0]
@@ -162,15 +166,10 @@ def main():
     _lib.check(L.rmem_profile_stop(ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(nl)), 'rmem_profile_stop')
 
     checksum = float(sum(int(s.labels.sum().item()) for s in slots))
-    stats = torch.tensor([elapsed, float(args.steps), checksum], dtype=torch.float64, device=dev)
-    if dist is not None:
-        gathered = [torch.zeros_like(stats) for _ in range(world)] if rank == 0 else None
-        dist.gather(stats, gathered, dst=0)          # the one data exchange: a few bytes per rank
-        if rank == 0:
-            elapsed = max(float(g[0]) for g in gathered)
-            total_steps = sum(float(g[1]) for g in gathered)
-    else:
-        total_steps = float(args.steps)
+    from rmem_ocu_amd.clip_runner import gather_stats
+    agg = gather_stats(float(args.steps), elapsed, checksum, dist, rank, world, dev)   # the one data exchange: 24 bytes per rank
+    if rank == 0:
+        total_steps, elapsed, _ = agg
 
     if rank == 0:
         achieved = (fl.value / (ms.value * 1e-3)) / 1e12 if nl.value and ms.value > 0 else None

@@ -31,6 +31,19 @@ def shard_clips(num_clips: int, rank: int, world: int, lengths: Optional[Sequenc
     return mine
 
 
+def gather_stats(frames: float, seconds: float, checksum: float, dist, rank: int, world: int, device):
+    """The one exchange of the clip-parallel design (reference: info_queue, managers/evaluator.py:589-613):
+    every rank sends (frames, seconds, checksum) to rank 0, which returns (sum frames, max seconds, sum checksum)."""
+    stats = torch.tensor([frames, seconds, checksum], dtype=torch.float64, device=device)
+    if dist is None or world == 1:
+        return float(stats[0]), float(stats[1]), float(stats[2])
+    gathered = [torch.zeros_like(stats) for _ in range(world)] if rank == 0 else None
+    dist.gather(stats, gathered, dst=0)
+    if rank != 0:
+        return None
+    return (sum(float(g[0]) for g in gathered), max(float(g[1]) for g in gathered), sum(float(g[2]) for g in gathered))
+
+
 class ClipSlot:
     """One clip in flight: an engine, its frames on the device, its output label buffer."""
 

@@ -1,0 +1,98 @@
+"""Host-side logic of the engine (no GPU): temporal-PE slots, positional embedding, the eviction
+policy against the oracle's restatement, weight packing, the state_dict contract, clip sharding."""
+import numpy as np
+import torch
+
+from oracle import ref_cpu as O
+
+
+def test_temporal_slots_match_reference_fixture(golden_ops):
+    from rmem_ocu_amd.runtime import temporal_slots
+    assert temporal_slots(1) == [0]
+    for T in range(2, 33):
+        assert temporal_slots(T) == golden_ops[f'slots_T{T}'].tolist(), T
+
+
+def test_sine_pos_emb_matches_reference_fixture(golden_ops):
+    from rmem_ocu_amd.runtime import sine_pos_emb
+    assert np.abs(sine_pos_emb(6, 7).numpy() - golden_ops['sine_pos_6x7']).max() < 1e-6
+    rows = sine_pos_emb(31, 54)[[0, 53, 54, 800, 1673]].numpy()
+    assert np.abs(rows - golden_ops['sine_pos_31x54_rows']).max() < 1e-6
+
+
+def test_memory_policy_equals_oracle_policy():
+    """MemoryPolicy (product) and oracle.choose_eviction walk the same random score streams identically."""
+    from rmem_ocu_amd.networks.engines.aot_engine import MemoryPolicy
+    rng = np.random.default_rng(0)
+    for trial in range(20):
+        N = int(rng.integers(2, 9))
+        pol, st = MemoryPolicy(), O.EvictionState()
+        idx_a, idx_b = list(range(0, 2 * N, 2)), list(range(0, 2 * N, 2))
+        frame = 2 * N
+        for step in range(30):
+            idx_a.append(frame)
+            idx_b.append(frame)
+            frame += int(rng.integers(1, 4))
+            hw = 50
+            mass = torch.from_numpy(rng.random((hw, N)).astype(np.float32))
+            fg = torch.from_numpy(rng.random(hw).astype(np.float32))
+            da = pol.choose((mass * fg[:, None]).sum(0), idx_a)
+            db = O.choose_eviction(mass, fg, idx_b, st)
+            assert da == db and 1 <= da <= N
+            del idx_a[da]
+            del idx_b[db]
+            assert idx_a == idx_b and idx_a[0] == 0
+
+
+def test_state_dict_contract_and_packing():
+    from rmem_ocu_amd import build_vos_model, get_config
+    from rmem_ocu_amd.pack import pack_state_dict
+    from rmem_ocu_amd.weights import synth_state_dict
+    cfg = get_config()
+    model = build_vos_model('aot', cfg)
+    sd = model.state_dict()
+    ref = synth_state_dict(0)
+    assert list(sd.keys()) == list(ref.keys()) and len(sd) == 362
+    for k in ref:
+        assert sd[k].shape == ref[k].shape
+    for attr in ('encoder', 'encoder_projector', 'LSTT', 'decoder', 'patch_wise_id_bank', 'cur_pos_emb', 'mem_pos_emb', 'cfg', 'max_obj_num'):
+        assert hasattr(model, attr)
+    other = synth_state_dict(7)
+    model.load_state_dict(other)
+    assert torch.equal(model.state_dict()['LSTT.layers.2.linear_Q.weight'], other['LSTT.layers.2.linear_Q.weight'])
+    P = pack_state_dict(ref, torch.device('cpu'))
+    assert P['stem.w'].shape == (64, 7, 7, 8) and P['stem.w'][..., 3:].abs().max() == 0
+    assert P['idbank.w'].shape == (256, 17, 17, 16) and P['l0.self_qk.w'].shape == (512, 256)
+    assert P['l1.dw.w'].shape == (25, 1024) and P['pe_mem'].shape == (4, 256)
+    # BN folding: conv(x)*scale + shift == frozen_bn(conv(x))
+    x = torch.randn(1, 64, 9, 9)
+    p = 'encoder.layer1.0'
+    y_ref = O.frozen_bn(torch.nn.functional.conv2d(x, ref[p + '.conv1.weight']), ref, p + '.bn1')
+    w = P[p + '.conv1.w'].float().permute(0, 3, 1, 2)
+    y = torch.nn.functional.conv2d(x, w, P[p + '.conv1.b'])
+    assert (y - y_ref).abs().max() < 0.05 * y_ref.abs().max()
+
+
+def test_network_size_rule():
+    from rmem_ocu_amd.synth import network_size
+    assert network_size(480, 854) == (481, 849)          # cfg 2
+    assert network_size(720, 1280) == (577, 1041)        # cfg 3
+    assert network_size(480, 854, align_corners=False) == (480, 848)
+
+
+def test_shard_clips_partitions_exactly():
+    from rmem_ocu_amd.clip_runner import shard_clips
+    lengths = [36, 80, 600, 12, 90, 300, 45, 45, 80, 80, 7]
+    for world in (1, 2, 3, 8):
+        parts = [shard_clips(len(lengths), r, world, lengths) for r in range(world)]
+        flat = sorted(i for p in parts for i in p)
+        assert flat == list(range(len(lengths)))
+        loads = [sum(lengths[i] for i in p) for p in parts]
+        assert max(loads) - min(loads) <= max(lengths)
+    assert shard_clips(5, 0, 2) == [0, 2, 4] and shard_clips(5, 1, 2) == [1, 3]
+
+
+def test_oracle_iou_metric():
+    a = np.zeros((4, 4), int); b = np.zeros((4, 4), int)
+    a[:2] = 1; b[:3] = 1
+    assert abs(O.db_eval_iou(a, b) - 8 / 12) < 1e-9 and O.db_eval_iou(np.zeros((2, 2)), np.zeros((2, 2))) == 1.0
