@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define RMEM_ABI_VERSION 1
+#define RMEM_ABI_VERSION 2
 
 int rmem_abi_version(void);
 const char* rmem_last_error_string(void);
@@ -50,8 +50,12 @@ typedef struct rmem_conv_desc {
   int res_f32;        /* 1: residual is fp32, 0: bf16 */
 } rmem_conv_desc;
 
+/* Problems with few output tiles are cut along K (split-K) when a workspace of at least
+ * rmem_conv_workspace_bytes(desc) bytes is supplied (fp32 slabs, summed in slice order: reproducible);
+ * workspace may be NULL (no split-K). */
+size_t rmem_conv_workspace_bytes(const rmem_conv_desc* desc);
 int rmem_conv2d_nhwc(const rmem_conv_desc* desc, const void* x, const void* w, const float* bias,
-                     const void* residual, void* y, void* y2, void* stream);
+                     const void* residual, void* y, void* y2, void* workspace, void* stream);
 
 /* ------------------------------------------------------------------ memory-read attention
  * out[q, 32h:32h+32] = softmax_k( (Q[q,h]+pe_cur[h]) . (K[k,h]+pe_mem[slot(k),h]) / sqrt(32) ) V[k,h]

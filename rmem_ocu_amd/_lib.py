@@ -11,7 +11,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'librmem_hip.so')
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class RmemError(RuntimeError):
@@ -33,7 +33,8 @@ _vp, _i, _ll, _f = C.c_void_p, C.c_int, C.c_longlong, C.c_float
 SIGNATURES = {
     'rmem_abi_version': (_i, []),
     'rmem_last_error_string': (C.c_char_p, []),
-    'rmem_conv2d_nhwc': (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'rmem_conv_workspace_bytes': (C.c_size_t, [C.POINTER(ConvDesc)]),
+    'rmem_conv2d_nhwc': (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'rmem_attn_workspace_bytes': (C.c_size_t, [_i, _i, _i]),
     'rmem_mem_read_attn': (_i, [_vp, _i, _vp, _vp, _ll, _i, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _vp, _vp]),
     'rmem_profile_start': (_i, [_i]),

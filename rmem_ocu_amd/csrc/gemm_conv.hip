@@ -16,6 +16,15 @@
 // LDS after them (one barrier per k-step).  LDS rows are 64 B (32 bf16); the 16-byte
 // chunk index is XOR-swizzled with (-(row >> 2)) & 3 so that the four 16-lane groups
 // of a ds_read_b128 fragment read hit 16 distinct 16-byte slots of the 256-byte bank row.
+//
+// Epilogue: the accumulators go through LDS (fp32, half a tile at a time) so that every
+// thread finishes 8 consecutive channels of one output row: bias / residual / second
+// output / store are 16- or 32-byte accesses instead of 2-byte scatters.
+//
+// Split-K: problems with few output tiles (M = 1674 token GEMMs with K up to 4624) are
+// cut along K over gridDim.z; each slice stores an fp32 slab with plain 16-byte stores
+// and k_splitk_epilogue sums the slabs in slice order (bitwise reproducible, no atomics)
+// while applying the same fused epilogue.
 #include "common.h"
 #include "../../include/rmem.h"
 
@@ -28,22 +37,83 @@ struct ConvParams {
   const void* res;
   void* y;
   bf16* y2;
+  float* slabs;          // split-K partials [splits][M][Cout] (fp32) or null
   int H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad;
   int M, K;
   int ldo, ldr, ld2;
   int relu, out_f32, res_f32;
+  int steps_per_split;   // k-steps (of 32) per gridDim.z slice
+  int vec_ok;            // all leading dimensions / pointers allow 8-wide vector access
 };
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * 32 + ((chunk ^ ((-(row >> 2)) & 3)) << 3); }
 
-template <int BM, int BN, bool IS1X1>
+// finish 8 consecutive channels n..n+7 of output row m (v = accumulator + nothing yet)
+__device__ __forceinline__ void finish8(const ConvParams& p, int m, int n, float (&v)[8]) {
+  if (p.bias) {
+    const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + n), b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[j] += b0[j]; v[4 + j] += b1[j]; }
+  }
+  if (p.y2) {
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (bf16)v[j];
+    *reinterpret_cast<bf16x8*>(p.y2 + (long)m * p.ld2 + n) = o;
+  }
+  if (p.res) {
+    if (p.res_f32) {
+      const float* r = reinterpret_cast<const float*>(p.res) + (long)m * p.ldr + n;
+      const f32x4 r0 = *reinterpret_cast<const f32x4*>(r), r1 = *reinterpret_cast<const f32x4*>(r + 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { v[j] += r0[j]; v[4 + j] += r1[j]; }
+    } else {
+      const bf16x8 r = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16*>(p.res) + (long)m * p.ldr + n);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] += (float)r[j];
+    }
+  }
+  if (p.relu) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+  }
+  if (p.out_f32) {
+    float* y = reinterpret_cast<float*>(p.y) + (long)m * p.ldo + n;
+    *reinterpret_cast<f32x4*>(y) = f32x4{v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<f32x4*>(y + 4) = f32x4{v[4], v[5], v[6], v[7]};
+  } else {
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (bf16)v[j];
+    *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p.y) + (long)m * p.ldo + n) = o;
+  }
+}
+
+// scalar tail (Cout not a multiple of 8, or unaligned leading dimensions)
+__device__ __forceinline__ void finish1(const ConvParams& p, int m, int n, float v) {
+  if (p.bias) v += p.bias[n];
+  if (p.y2) p.y2[(long)m * p.ld2 + n] = (bf16)v;
+  if (p.res)
+    v += p.res_f32 ? reinterpret_cast<const float*>(p.res)[(long)m * p.ldr + n]
+                   : (float)reinterpret_cast<const bf16*>(p.res)[(long)m * p.ldr + n];
+  if (p.relu) v = fmaxf(v, 0.f);
+  if (p.out_f32) reinterpret_cast<float*>(p.y)[(long)m * p.ldo + n] = v;
+  else reinterpret_cast<bf16*>(p.y)[(long)m * p.ldo + n] = (bf16)v;
+}
+
+template <int BM, int BN, bool IS1X1, bool SPLITK>
 __global__ __launch_bounds__(256) void k_conv_gemm(ConvParams p) {
   constexpr int NA = BM / 64;  // 16-byte A chunks per thread per k-step
   constexpr int NB = BN / 64;
   constexpr int TM = BM / 32;  // 16x16 tiles per wave along M
   constexpr int TN = BN / 32;
-  __shared__ __attribute__((aligned(16))) bf16 As[2][BM * 32];
-  __shared__ __attribute__((aligned(16))) bf16 Bs[2][BN * 32];
+  constexpr int CP = BN + 4;   // padded fp32 row of the epilogue staging tile
+  constexpr int AB_BYTES = 2 * (BM + BN) * 32 * 2;
+  constexpr int C_BYTES = (BM / 2) * CP * 4;
+  constexpr int SMEM = AB_BYTES > C_BYTES ? AB_BYTES : C_BYTES;
+  __shared__ __attribute__((aligned(16))) char smem[SMEM];
+  bf16* As = reinterpret_cast<bf16*>(smem);                 // [2][BM*32]
+  bf16* Bs = As + 2 * BM * 32;                              // [2][BN*32]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -51,10 +121,13 @@ __global__ __launch_bounds__(256) void k_conv_gemm(ConvParams p) {
   const int wm = wave >> 1, wn = wave & 1;
   const int m0 = blockIdx.x * BM;
   const int n0 = blockIdx.y * BN;
+  const int nk_total = (p.K + 31) / 32;
+  const int kt0 = SPLITK ? blockIdx.z * p.steps_per_split : 0;
+  const int kt1 = SPLITK ? min(nk_total, kt0 + p.steps_per_split) : nk_total;
 
   // ---- per-thread gather state for the A operand ----
   int a_row[NA], a_chunk[NA];
-  long a_base[NA];          // element offset of (hi0, wi0, 0) or of row start (1x1)
+  long a_base[NA];
   int a_hi0[NA], a_wi0[NA];
   bool a_ok[NA];
   int a_ci[NA], a_kw[NA], a_kh[NA];
@@ -68,22 +141,18 @@ __global__ __launch_bounds__(256) void k_conv_gemm(ConvParams p) {
     if (IS1X1) {
       a_base[i] = (long)m * p.Cin;
       a_hi0[i] = a_wi0[i] = 0;
+      a_ci[i] = a_kw[i] = a_kh[i] = 0;
     } else {
       const int ho = m / p.Wo, wo = m - ho * p.Wo;
       a_hi0[i] = ho * p.stride - p.pad;
       a_wi0[i] = wo * p.stride - p.pad;
       a_base[i] = 0;
+      const int kidx = kt0 * 32 + a_chunk[i] * 8;
+      const int kk = kidx / p.Cin;
+      a_ci[i] = kidx - kk * p.Cin;
+      a_kh[i] = kk / p.KW;
+      a_kw[i] = kk - a_kh[i] * p.KW;
     }
-    // k position of this chunk in the first k-step
-    int kidx = a_chunk[i] * 8;
-    int ci = kidx, kw = 0, kh = 0;
-    if (!IS1X1) {
-      while (ci >= p.Cin) {
-        ci -= p.Cin;
-        if (++kw == p.KW) { kw = 0; ++kh; }
-      }
-    }
-    a_ci[i] = ci; a_kw[i] = kw; a_kh[i] = kh;
   }
   int b_row[NB], b_chunk[NB];
 #pragma unroll
@@ -128,9 +197,9 @@ __global__ __launch_bounds__(256) void k_conv_gemm(ConvParams p) {
   };
   auto store_tile = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < NA; ++i) *reinterpret_cast<bf16x8*>(&As[buf][swz(a_row[i], a_chunk[i])]) = ra[i];
+    for (int i = 0; i < NA; ++i) *reinterpret_cast<bf16x8*>(&As[buf * BM * 32 + swz(a_row[i], a_chunk[i])]) = ra[i];
 #pragma unroll
-    for (int i = 0; i < NB; ++i) *reinterpret_cast<bf16x8*>(&Bs[buf][swz(b_row[i], b_chunk[i])]) = rb[i];
+    for (int i = 0; i < NB; ++i) *reinterpret_cast<bf16x8*>(&Bs[buf * BN * 32 + swz(b_row[i], b_chunk[i])]) = rb[i];
   };
 
   f32x4 acc[TM][TN];
@@ -139,69 +208,130 @@ __global__ __launch_bounds__(256) void k_conv_gemm(ConvParams p) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nk = (p.K + 31) / 32;
-  load_tile(0);
-  store_tile(0);
-  __syncthreads();
-
   const int fr = lane & 15, fc = lane >> 4;
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) load_tile((kt + 1) * 32);
+  if (kt0 < kt1) {
+    load_tile(kt0 * 32);
+    store_tile(0);
+  }
+  __syncthreads();
+  for (int kt = kt0; kt < kt1; ++kt) {
+    const int cur = (kt - kt0) & 1;
+    if (kt + 1 < kt1) load_tile((kt + 1) * 32);
     bf16x8 af[TM], bfr[TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
-      af[i] = *reinterpret_cast<const bf16x8*>(&As[cur][swz(wm * (BM / 2) + i * 16 + fr, fc)]);
+      af[i] = *reinterpret_cast<const bf16x8*>(&As[cur * BM * 32 + swz(wm * (BM / 2) + i * 16 + fr, fc)]);
 #pragma unroll
     for (int j = 0; j < TN; ++j)
-      bfr[j] = *reinterpret_cast<const bf16x8*>(&Bs[cur][swz(wn * (BN / 2) + j * 16 + fr, fc)]);
+      bfr[j] = *reinterpret_cast<const bf16x8*>(&Bs[cur * BN * 32 + swz(wn * (BN / 2) + j * 16 + fr, fc)]);
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j)
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-    if (kt + 1 < nk) store_tile(cur ^ 1);
+    if (kt + 1 < kt1) store_tile(cur ^ 1);
     __syncthreads();
   }
 
-  // ---- epilogue: bias, optional bf16 copy, residual, ReLU ----
+  // ---- epilogue through LDS: two passes of BM/2 rows ----
   // C/D map of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg.
+  float* Cs = reinterpret_cast<float*>(smem);
+  constexpr int VPR = BN / 8;                       // 8-wide vectors per staged row
 #pragma unroll
-  for (int i = 0; i < TM; ++i) {
+  for (int pass = 0; pass < 2; ++pass) {
+    if (wm == pass) {
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int n = n0 + wn * (BN / 2) + j * 16 + fr;
-      if (n >= p.Cout) continue;
-      const float bn = p.bias ? p.bias[n] : 0.f;
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = m0 + wm * (BM / 2) + i * 16 + fc * 4 + r;
-        if (m >= p.M) continue;
-        float v = acc[i][j][r] + bn;
-        if (p.y2) p.y2[(long)m * p.ld2 + n] = (bf16)v;
-        if (p.res) {
-          v += p.res_f32 ? reinterpret_cast<const float*>(p.res)[(long)m * p.ldr + n]
-                         : (float)reinterpret_cast<const bf16*>(p.res)[(long)m * p.ldr + n];
-        }
-        if (p.relu) v = fmaxf(v, 0.f);
-        if (p.out_f32) reinterpret_cast<float*>(p.y)[(long)m * p.ldo + n] = v;
-        else reinterpret_cast<bf16*>(p.y)[(long)m * p.ldo + n] = (bf16)v;
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) Cs[(i * 16 + fc * 4 + r) * CP + wn * (BN / 2) + j * 16 + fr] = acc[i][j][r];
+    }
+    __syncthreads();
+    for (int vi = tid; vi < (BM / 2) * VPR; vi += 256) {
+      const int row = vi / VPR, cv = vi - row * VPR;
+      const int m = m0 + pass * (BM / 2) + row;
+      const int n = n0 + cv * 8;
+      if (m >= p.M || n >= p.Cout) continue;
+      const float* c = Cs + row * CP + cv * 8;
+      const f32x4 c0 = *reinterpret_cast<const f32x4*>(c), c1 = *reinterpret_cast<const f32x4*>(c + 4);
+      float v[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
+      if (SPLITK) {
+        float* s = p.slabs + ((long)blockIdx.z * p.M + m) * p.Cout + n;    // Cout % 8 == 0 is required for split-K
+        *reinterpret_cast<f32x4*>(s) = c0;
+        *reinterpret_cast<f32x4*>(s + 4) = c1;
+      } else if (p.vec_ok && n + 8 <= p.Cout) {
+        finish8(p, m, n, v);
+      } else {
+        for (int j = 0; j < 8 && n + j < p.Cout; ++j) finish1(p, m, n + j, v[j]);
       }
     }
+    __syncthreads();
   }
 }
 
+// sum the split-K slabs in slice order and apply the fused epilogue; thread = 8 channels of one row
+__global__ __launch_bounds__(256) void k_splitk_epilogue(ConvParams p, int splits) {
+  const int vpr = p.Cout / 8;
+  const long total = (long)p.M * vpr;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int m = (int)(i / vpr), n = (int)(i - (long)m * vpr) * 8;
+  float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int z = 0; z < splits; ++z) {
+    const float* s = p.slabs + ((long)z * p.M + m) * p.Cout + n;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(s), b = *reinterpret_cast<const f32x4*>(s + 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[j] += a[j]; v[4 + j] += b[j]; }
+  }
+  if (p.vec_ok) finish8(p, m, n, v);
+  else
+    for (int j = 0; j < 8; ++j) finish1(p, m, n + j, v[j]);
+}
+
 template <int BM, int BN>
-void launch(const ConvParams& p, bool is1x1, hipStream_t s) {
-  dim3 grid((p.M + BM - 1) / BM, (p.Cout + BN - 1) / BN);
-  if (is1x1) hipLaunchKernelGGL((k_conv_gemm<BM, BN, true>), grid, dim3(256), 0, s, p);
-  else hipLaunchKernelGGL((k_conv_gemm<BM, BN, false>), grid, dim3(256), 0, s, p);
+void launch(const ConvParams& p, bool is1x1, int splits, hipStream_t s) {
+  dim3 grid((p.M + BM - 1) / BM, (p.Cout + BN - 1) / BN, splits);
+  if (splits > 1) {
+    if (is1x1) hipLaunchKernelGGL((k_conv_gemm<BM, BN, true, true>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((k_conv_gemm<BM, BN, false, true>), grid, dim3(256), 0, s, p);
+    const long total = (long)p.M * (p.Cout / 8);
+    hipLaunchKernelGGL(k_splitk_epilogue, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p, splits);
+  } else {
+    if (is1x1) hipLaunchKernelGGL((k_conv_gemm<BM, BN, true, false>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((k_conv_gemm<BM, BN, false, false>), grid, dim3(256), 0, s, p);
+  }
+}
+
+// split-K plan shared by rmem_conv_workspace_bytes and the launcher (64x64 tiles only)
+int plan_splits(int M, int Cout, int K) {
+  if (Cout % 8) return 1;
+  const long tiles = (long)((M + 63) / 64) * ((Cout + 63) / 64);
+  const int nk = (K + 31) / 32;
+  if (tiles >= 192 || nk < 16) return 1;
+  int s = (int)((448 + tiles - 1) / tiles);      // aim at >= ~450 workgroups
+  s = min(s, nk / 8);                            // keep >= 8 k-steps per slice
+  return max(1, min(s, 16));
+}
+
+bool use_small_tiles(int M, int Cout) {
+  const long t128 = (long)((M + 127) / 128) * ((Cout + 127) / 128);
+  const long t12864 = (long)((M + 127) / 128) * ((Cout + 63) / 64);
+  return !((Cout >= 128 && t128 >= 384) || t12864 >= 256);
 }
 
 }  // namespace
 
+extern "C" size_t rmem_conv_workspace_bytes(const rmem_conv_desc* d) {
+  if (!d) return 0;
+  const int M = d->Ho * d->Wo, K = d->KH * d->KW * d->Cin;
+  if (!use_small_tiles(M, d->Cout)) return 0;
+  const int s = plan_splits(M, d->Cout, K);
+  return s > 1 ? (size_t)s * M * d->Cout * sizeof(float) : 0;
+}
+
 extern "C" int rmem_conv2d_nhwc(const rmem_conv_desc* d, const void* x, const void* w, const float* bias,
-                                const void* residual, void* y, void* y2, void* stream) {
+                                const void* residual, void* y, void* y2, void* workspace, void* stream) {
   RMEM_REQUIRE(d && x && w && y, "rmem_conv2d_nhwc: null argument");
   RMEM_REQUIRE(d->Cin > 0 && d->Cin % 8 == 0, "rmem_conv2d_nhwc: Cin must be a positive multiple of 8");
   RMEM_REQUIRE(d->KH > 0 && d->KW > 0 && d->stride > 0 && d->pad >= 0, "rmem_conv2d_nhwc: bad kernel geometry");
@@ -214,18 +344,31 @@ extern "C" int rmem_conv2d_nhwc(const rmem_conv_desc* d, const void* x, const vo
   RMEM_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)w % 16) == 0, "rmem_conv2d_nhwc: x/w must be 16-byte aligned");
   ConvParams p;
   p.x = (const bf16*)x; p.w = (const bf16*)w; p.bias = bias; p.res = residual; p.y = y; p.y2 = (bf16*)y2;
+  p.slabs = nullptr;
   p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Ho = Ho; p.Wo = Wo; p.Cout = d->Cout;
   p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad;
   p.M = Ho * Wo; p.K = d->KH * d->KW * d->Cin;
   p.ldo = d->ldo; p.ldr = d->ldr; p.ld2 = d->ld2;
   p.relu = d->relu; p.out_f32 = d->out_f32; p.res_f32 = d->res_f32;
+  p.steps_per_split = (p.K + 31) / 32;
+  auto al = [](const void* q, int a) { return q == nullptr || ((uintptr_t)q % a) == 0; };
+  p.vec_ok = p.Cout % 8 == 0 && p.ldo % 8 == 0 && al(y, 16) && al(bias, 16) &&
+             (!residual || (p.ldr % 8 == 0 && al(residual, 16))) && (!y2 || (p.ld2 % 8 == 0 && al(y2, 16)));
   const bool is1x1 = d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0;
   hipStream_t s = (hipStream_t)stream;
-  // tile choice: keep >= ~256 workgroups when the problem allows it
   const long t128 = (long)((p.M + 127) / 128) * ((p.Cout + 127) / 128);
-  const long t12864 = (long)((p.M + 127) / 128) * ((p.Cout + 63) / 64);
-  if (p.Cout >= 128 && t128 >= 384) launch<128, 128>(p, is1x1, s);
-  else if (t12864 >= 256) launch<128, 64>(p, is1x1, s);
-  else launch<64, 64>(p, is1x1, s);
+  if (!use_small_tiles(p.M, p.Cout)) {
+    if (p.Cout >= 128 && t128 >= 384) launch<128, 128>(p, is1x1, 1, s);
+    else launch<128, 64>(p, is1x1, 1, s);
+  } else {
+    int splits = workspace ? plan_splits(p.M, p.Cout, p.K) : 1;
+    if (splits > 1) {
+      const int nk = (p.K + 31) / 32;
+      p.steps_per_split = (nk + splits - 1) / splits;
+      splits = (nk + p.steps_per_split - 1) / p.steps_per_split;   // no empty slice
+      p.slabs = (float*)workspace;
+    }
+    launch<64, 64>(p, is1x1, splits, s);
+  }
   return rmem_check_launch("rmem_conv2d_nhwc");
 }

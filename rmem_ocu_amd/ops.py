@@ -54,7 +54,7 @@ def _dev(*ts):
 
 
 def conv2d(x, w, bias, y, *, H, W, Cin, Cout, KH=1, KW=1, stride=1, pad=0, residual=None, y2=None, relu=False,
-           ldo=None, ldr=None, ld2=None) -> Op:
+           ldo=None, ldr=None, ld2=None, ws=None) -> Op:
     """y = act(conv(x, w) + bias (+ residual)); w is [Cout, KH, KW, Cin] bf16, x NHWC bf16."""
     _dev(x, w, bias, y, residual, y2)
     assert x.dtype == BF16 and w.dtype == BF16 and w.is_contiguous()
@@ -69,13 +69,17 @@ def conv2d(x, w, bias, y, *, H, W, Cin, Cout, KH=1, KW=1, stride=1, pad=0, resid
     assert x.numel() >= H * W * Cin and y.numel() >= (Ho * Wo - 1) * ldo + Cout
     d = ConvDesc(H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, ldo, ldr, ld2, int(relu), int(y.dtype == F32),
                  int(residual is not None and residual.dtype == F32))
-    args = (C.byref(d), _ptr(x), _ptr(w), _ptr(bias), _ptr(residual), _ptr(y), _ptr(y2))
-    return Op(_lib.lib().rmem_conv2d_nhwc, args, 'rmem_conv2d_nhwc', (d, x, w, bias, residual, y, y2))
+    if ws is not None:   # split-K workspace: use it only if it is big enough for this problem
+        _dev(ws)
+        if ws.numel() * ws.element_size() < _lib.lib().rmem_conv_workspace_bytes(C.byref(d)):
+            ws = None
+    args = (C.byref(d), _ptr(x), _ptr(w), _ptr(bias), _ptr(residual), _ptr(y), _ptr(y2), _ptr(ws))
+    return Op(_lib.lib().rmem_conv2d_nhwc, args, 'rmem_conv2d_nhwc', (d, x, w, bias, residual, y, y2, ws))
 
 
-def linear(x, w, bias, y, *, M, K, N, residual=None, y2=None, relu=False, ldo=None, ldr=None, ld2=None) -> Op:
+def linear(x, w, bias, y, *, M, K, N, residual=None, y2=None, relu=False, ldo=None, ldr=None, ld2=None, ws=None) -> Op:
     """y[M, N] = x[M, K] @ w[N, K]^T + bias: the 1x1 case of conv2d (x rows contiguous with stride K)."""
-    return conv2d(x, w, bias, y, H=M, W=1, Cin=K, Cout=N, residual=residual, y2=y2, relu=relu, ldo=ldo, ldr=ldr, ld2=ld2)
+    return conv2d(x, w, bias, y, H=M, W=1, Cin=K, Cout=N, residual=residual, y2=y2, relu=relu, ldo=ldo, ldr=ldr, ld2=ld2, ws=ws)
 
 
 def attn_workspace(Lq: int, heads: int, nchunks: int, device) -> torch.Tensor:

@@ -113,6 +113,7 @@ class ClipRuntime:
         self.pos = sine_pos_emb(self.H16, self.W16).to(device)
         self.attn_ws = ops.attn_workspace(L, HEADS, MAX_CHUNKS, device)
         self.gn_ws = ops.groupnorm_workspace(32, device)
+        self.conv_ws = torch.empty(16 * L * D_MODEL, dtype=F32, device=device)      # split-K slabs (<= 16 slices of [HW, 256])
         self.mass = torch.zeros(L, MAX_CHUNKS, dtype=F32, device=device)
         self.scores = torch.zeros(MAX_CHUNKS, dtype=F32, device=device)
         # ---- decoder buffers ----
@@ -182,7 +183,7 @@ class ClipRuntime:
 
     # ------------------------------------------------------------------ programs
     def _lin(self, x, name, y, M, K, N, **kw):
-        return ops.linear(x, self.P[name + '.w'], self.P[name + '.b'], y, M=M, K=K, N=N, **kw)
+        return ops.linear(x, self.P[name + '.w'], self.P[name + '.b'], y, M=M, K=K, N=N, ws=self.conv_ws, **kw)
 
     def prog_encode(self, img: torch.Tensor) -> list:
         """img: fp32 [3, H, W] device tensor at a FIXED address (the caller copies frames into it)."""

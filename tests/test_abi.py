@@ -43,7 +43,7 @@ def test_argument_validation_needs_no_gpu(lib):
     """Bad arguments are rejected on the host before anything is launched."""
     from rmem_ocu_amd._lib import ConvDesc
     d = ConvDesc(8, 8, 12, 8, 8, 16, 1, 1, 1, 0, 16, 16, 16, 0, 0, 0)      # Cin not a multiple of 8
-    rc = lib.rmem_conv2d_nhwc(ctypes.byref(d), 16, 16, None, None, 16, None, None)
+    rc = lib.rmem_conv2d_nhwc(ctypes.byref(d), 16, 16, None, None, 16, None, None, None)
     assert rc != 0 and b'multiple of 8' in lib.rmem_last_error_string()
     rc = lib.rmem_mem_read_attn(16, 256, 16, 16, 0, 256, None, 1, 0, None, None, 10, 8, 16, 256, None, 0, 16, None)
     assert rc != 0 and b'lk_single' in lib.rmem_last_error_string()

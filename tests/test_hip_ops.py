@@ -60,6 +60,10 @@ CONV_CASES = [
     (1674, 1, 256, 1024, 1, 1, 0, False, None, False),
     (500, 1, 128, 11, 1, 1, 0, False, None, True),
     (121, 213, 128, 128, 3, 1, 1, False, None, False),
+    (31, 54, 256, 256, 3, 1, 1, True, None, False),          # layer3 3x3: split-K
+    (1674, 1, 1024, 256, 1, 1, 0, True, 'bf16', False),      # layer3 conv3 + residual: split-K
+    (481, 849, 16, 256, 17, 16, 8, False, None, False),      # id bank at cfg-2 size: split-K, K = 4624
+    (1674, 1, 256, 256, 1, 1, 0, False, 'f32', True),
 ]
 
 
@@ -86,14 +90,19 @@ def test_conv2d(dev, case):
     if r is not None:
         rd = r[0].permute(1, 2, 0).reshape(-1, Cout).contiguous().to(dev)
         rd = rd.to(BF16) if res == 'bf16' else rd
-    op = ops.conv2d(nhwc(x).to(dev), pack_w(w).to(dev), b.to(dev), y, H=H, W=W, Cin=Cin, Cout=Cout, KH=k, KW=k, stride=s, pad=p,
-                    residual=rd, y2=y2, relu=relu, ldo=ldo)
-    ops.run(op)
-    torch.cuda.synchronize()
     refm = ref[0].permute(1, 2, 0).reshape(-1, Cout)
-    assert_close(y[:, :Cout], refm, 1e-2, f'conv {case}')
     pre = F.conv2d(x, w, b, stride=s, padding=p)[0].permute(1, 2, 0).reshape(-1, Cout)
-    assert_close(y2, pre, 1e-2, f'conv y2 {case}')
+    ws = torch.empty(16 * 1674 * 256, dtype=F32, device=dev)
+    for use_ws in (None, ws):          # without / with the split-K workspace (engaged for few-tile, deep-K problems)
+        y.zero_(); y2.zero_()
+        op = ops.conv2d(nhwc(x).to(dev), pack_w(w).to(dev), b.to(dev), y, H=H, W=W, Cin=Cin, Cout=Cout, KH=k, KW=k, stride=s, pad=p,
+                        residual=rd, y2=y2, relu=relu, ldo=ldo, ws=use_ws)
+        ops.run(op)
+        torch.cuda.synchronize()
+        assert_close(y[:, :Cout], refm, 1e-2, f'conv {case} ws={use_ws is not None}')
+        assert_close(y2, pre, 1e-2, f'conv y2 {case}')
+        if ldo > Cout:
+            assert y[:, Cout:].abs().max().item() == 0
 
 
 @pytest.mark.parametrize('T,L', [(1, 42), (2, 42), (5, 42), (8, 42), (12, 42), (3, 300), (8, 1674)])
