@@ -34,8 +34,11 @@ namespace {
 
 constexpr int D = 32;          // head dim
 constexpr int KT = 64;         // keys per LDS tile
-constexpr int VT_LD = KT + 4;  // padded row of the transposed V tile (136 B: 8-byte aligned, conflict-free b64 reads)
 constexpr float NEG_BIG = -1.0e30f;
+constexpr float RESCALE_THR = 8.0f;   // log2 units: P <= 2^8 between rescales (bf16 keeps 8 significant bits at any scale)
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
 struct AttnParams {
   const bf16* q; int ldq;
@@ -49,12 +52,25 @@ struct AttnParams {
 
 __device__ __forceinline__ int kswz(int row, int chunk) { return row * D + ((chunk ^ ((row >> 2) & 3)) << 3); }
 
+// max over the two lanes that share a query (lane, lane ^ 32) without touching LDS
+__device__ __forceinline__ float pair_max(float x) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+
 // MEM = true: memory-read flavour (chunk table, temporal PE); false: one plain key frame.  Two symbols so a
 // kernel trace separates the long-term memory read from the short-term / self attention launches.
+//
+// Softmax bookkeeping is "lazy": the running reference m_ref (not the true max) is folded into the MFMA
+// accumulator's initial value together with the temporal-PE bias, so S' = S - m_ref comes out of the matrix
+// pipe and P = exp2(S') needs no subtraction.  Only when a tile's maximum exceeds m_ref by more than
+// RESCALE_THR (or on the first tile) is m_ref moved and O / l rescaled -- a wave-uniform, rare branch.
+// The row sums l come from the matrix pipe too (a ones A-operand against the same P^T fragments), which
+// leaves max + exp2 + bf16 packing as the only per-score VALU work (the d = 32 bottleneck).
 template <bool MEM>
 __global__ __launch_bounds__(256) void k_attn_partial(AttnParams p) {
-  __shared__ __attribute__((aligned(16))) bf16 Ks[2][KT * D];
-  __shared__ __attribute__((aligned(16))) bf16 Vt[2][D * VT_LD];
+  __shared__ __attribute__((aligned(16))) bf16 Ks[2][KT * D];   // [key][32], 16-byte chunks XOR-swizzled
+  __shared__ __attribute__((aligned(16))) bf16 Vs[2][KT * D];   // [key][32] row-major, read transposed (ds_read_b64_tr_b16)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lq = lane & 31, lh = lane >> 5;
@@ -74,17 +90,24 @@ __global__ __launch_bounds__(256) void k_attn_partial(AttnParams p) {
   const int qrow = min(blockIdx.x * 128 + wave * 32 + lq, p.Lq - 1);
   bf16x8 qf[2];
   float bias = 0.f;
+  const bool has_cur = MEM && p.pe_cur != nullptr;        // workgroup-uniform
+  const bool has_mem = MEM && pe_slot >= 0 && p.pe_mem != nullptr;
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
     const int d0 = head * D + 16 * s + 8 * lh;
     const bf16x8 raw = *reinterpret_cast<const bf16x8*>(p.q + (long)qrow * p.ldq + d0);
+    f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0, m0 = c0, m1 = c0;
+    if (has_cur) { c0 = *reinterpret_cast<const f32x4*>(p.pe_cur + d0); c1 = *reinterpret_cast<const f32x4*>(p.pe_cur + d0 + 4); }
+    if (has_mem) {
+      const float* pm = p.pe_mem + pe_slot * p.C + d0;
+      m0 = *reinterpret_cast<const f32x4*>(pm); m1 = *reinterpret_cast<const f32x4*>(pm + 4);
+    }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      float f = (float)raw[j];
-      if (MEM && p.pe_cur) f += p.pe_cur[d0 + j];
+      const float f = (float)raw[j] + (j < 4 ? c0[j & 3] : c1[j & 3]);
       const bf16 b = (bf16)(f * p.qscale);
       qf[s][j] = b;
-      if (MEM && pe_slot >= 0) bias += (float)b * p.pe_mem[pe_slot * p.C + d0 + j];
+      bias += (float)b * (j < 4 ? m0[j & 3] : m1[j & 3]);
     }
   }
   bias += __shfl_xor(bias, 32, 64);
@@ -104,14 +127,19 @@ __global__ __launch_bounds__(256) void k_attn_partial(AttnParams p) {
   };
   auto store_tile = [&](int buf) {
     *reinterpret_cast<bf16x8*>(&Ks[buf][kswz(skey, schunk)]) = rk;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) Vt[buf][(schunk * 8 + j) * VT_LD + skey] = rv[j];
+    *reinterpret_cast<bf16x8*>(&Vs[buf][skey * D + schunk * 8]) = rv;
   };
 
-  f32x16 oacc;
+  // transposed-read addressing of the V tile: 16-lane group g reads a 4-key x 16-d block; lane 4q+p of the group
+  // supplies the address of key row q, d columns 4p..4p+3 and receives d column (lane & 15), keys 0..3
+  const int tr_off = ((4 * lh + ((lane & 15) >> 2)) * D) + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+
+  const bf16 one = (bf16)1.0f;
+  const bf16x8 ones = {one, one, one, one, one, one, one, one};
+  f32x16 oacc, lacc;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) oacc[r] = 0.f;
-  float m_run = NEG_BIG, l_run = 0.f;
+  for (int r = 0; r < 16; ++r) { oacc[r] = 0.f; lacc[r] = 0.f; }
+  float m_ref = 0.f;
 
   const int ntiles = (kn + KT - 1) / KT;
   load_tile(0);
@@ -122,12 +150,13 @@ __global__ __launch_bounds__(256) void k_attn_partial(AttnParams p) {
     const int cur = t & 1;
     if (t + 1 < ntiles) load_tile(t + 1);
 
-    // S^T for the two 32-key blocks of this tile
+    // S'^T = K . Q^T + (bias - m_ref) for the two 32-key blocks of this tile
+    const float cinit = bias - m_ref;
     f32x16 sacc[2];
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) sacc[b][r] = bias;
+      for (int r = 0; r < 16; ++r) sacc[b][r] = cinit;
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         const bf16x8 a = *reinterpret_cast<const bf16x8*>(&Ks[cur][kswz(b * 32 + lq, 2 * s + lh)]);
@@ -143,47 +172,47 @@ __global__ __launch_bounds__(256) void k_attn_partial(AttnParams p) {
           if (base + b * 32 + (r & 3) + 8 * (r >> 2) >= kn) sacc[b][r] = NEG_BIG;
     }
 
-    // online softmax (query = lane & 31; the other 16 keys of each block sit in lane ^ 32)
-    float tmax = sacc[0][0];
+    // tile maximum per query (the other 16 keys of each block sit in lane ^ 32)
+    float tmax = fmaxf(sacc[0][0], sacc[1][0]);
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int r = 1; r < 16; ++r) tmax = fmaxf(fmaxf(tmax, sacc[0][r]), sacc[1][r]);   // v_max3_f32
+    tmax = pair_max(tmax);
+    const bool need = (t == 0) || (tmax > RESCALE_THR);
+    if (__any(need)) {                       // rare after the first tile: move the reference, rescale O and l
+      const float delta = need ? tmax : 0.f;
+      m_ref += delta;
+      const float sc = __builtin_amdgcn_exp2f(-delta);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, sacc[b][r]);
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-    const float m_new = fmaxf(m_run, tmax);
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-    m_run = m_new;
-    float lsum = 0.f;
+      for (int r = 0; r < 16; ++r) { oacc[r] *= sc; lacc[r] *= sc; }
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[b][r] -= delta;
+    }
     bf16x8 pb[2][2];
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float e = __builtin_amdgcn_exp2f(sacc[b][r] - m_new);
-        lsum += e;
-        pb[b][r >> 3][r & 7] = (bf16)e;
-      }
-    l_run = l_run * alpha + lsum;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) oacc[r] *= alpha;
+      for (int r = 0; r < 16; ++r) pb[b][r >> 3][r & 7] = (bf16)__builtin_amdgcn_exp2f(sacc[b][r]);
 
-    // O^T += V^T . P^T
+    // O^T += V^T . P^T and l += 1^T . P^T (same B fragments)
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
-        const bf16* vrow = &Vt[cur][lq * VT_LD + b * 32 + 16 * s + 4 * lh];
-        const bf16x4 lo = *reinterpret_cast<const bf16x4*>(vrow);
-        const bf16x4 hi = *reinterpret_cast<const bf16x4*>(vrow + 8);
-        const bf16x8 a = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        const bf16* vb = &Vs[cur][(b * 32 + 16 * s) * D + tr_off];
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)vb);
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vb + 8 * D));
+        const __attribute__((ext_vector_type(8))) short a16 = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        const bf16x8 a = __builtin_bit_cast(bf16x8, a16);
         oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pb[b][s], oacc, 0, 0, 0);
+        lacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pb[b][s], lacc, 0, 0, 0);
       }
 
     if (t + 1 < ntiles) store_tile(cur ^ 1);
     __syncthreads();
   }
 
-  l_run += __shfl_xor(l_run, 32, 64);
   const int qg = blockIdx.x * 128 + wave * 32 + lq;
   if (qg < p.Lq) {
     const long row = ((long)c * p.heads + head) * p.Lq + qg;
@@ -191,7 +220,7 @@ __global__ __launch_bounds__(256) void k_attn_partial(AttnParams p) {
 #pragma unroll
     for (int g = 0; g < 4; ++g)  // C/D rows (r&3) + 8(r>>2) + 4h  ->  d = 8g + 4h + (0..3)
       *reinterpret_cast<f32x4*>(o + 8 * g + 4 * lh) = f32x4{oacc[4 * g], oacc[4 * g + 1], oacc[4 * g + 2], oacc[4 * g + 3]};
-    if (lh == 0) *reinterpret_cast<f32x2*>(p.ml + row * 2) = f32x2{m_run, l_run};
+    if (lh == 0) *reinterpret_cast<f32x2*>(p.ml + row * 2) = f32x2{m_ref, lacc[0]};
   }
 }
 

@@ -182,6 +182,9 @@ class ClipRuntime:
             self.chunks.copy_(host, non_blocking=True)
 
     # ------------------------------------------------------------------ programs
+    def _conv(self, *a, **kw):
+        return ops.conv2d(*a, ws=self.conv_ws, **kw)
+
     def _lin(self, x, name, y, M, K, N, **kw):
         return ops.linear(x, self.P[name + '.w'], self.P[name + '.b'], y, M=M, K=K, N=N, ws=self.conv_ws, **kw)
 
@@ -192,7 +195,7 @@ class ClipRuntime:
             return self._prog[key]
         P, o = self.P, []
         o.append(ops.image_to_nhwc8(img, self.img8, H=self.H, W=self.W))
-        o.append(ops.conv2d(self.img8, P['stem.w'], P['stem.b'], self.stem, H=self.H, W=self.W, Cin=8, Cout=64, KH=7, KW=7,
+        o.append(self._conv(self.img8, P['stem.w'], P['stem.b'], self.stem, H=self.H, W=self.W, Cin=8, Cout=64, KH=7, KW=7,
                             stride=2, pad=3, relu=True))
         o.append(ops.maxpool3x3s2(self.stem, self.pool, H=self.H2, W=self.W2, C=64))
         x, (h, w), cin = self.pool, (self.H4, self.W4), 64
@@ -206,20 +209,20 @@ class ClipRuntime:
                 y = outs[li - 1][bi % 2]
                 a = self.mid_a.view(-1)[: h * w * planes]
                 b = self.mid_b.view(-1)[: ho * wo * planes]
-                o.append(ops.conv2d(x, P[p + '.conv1.w'], P[p + '.conv1.b'], a, H=h, W=w, Cin=cin, Cout=planes, relu=True))
-                o.append(ops.conv2d(a, P[p + '.conv2.w'], P[p + '.conv2.b'], b, H=h, W=w, Cin=planes, Cout=planes, KH=3, KW=3,
+                o.append(self._conv(x, P[p + '.conv1.w'], P[p + '.conv1.b'], a, H=h, W=w, Cin=cin, Cout=planes, relu=True))
+                o.append(self._conv(a, P[p + '.conv2.w'], P[p + '.conv2.b'], b, H=h, W=w, Cin=planes, Cout=planes, KH=3, KW=3,
                                     stride=s, pad=1, relu=True))
                 if (p + '.ds.w') in P:
                     r = self.ds.view(-1)[: ho * wo * planes * 4]
-                    o.append(ops.conv2d(x, P[p + '.ds.w'], P[p + '.ds.b'], r, H=h, W=w, Cin=cin, Cout=planes * 4, stride=s))
+                    o.append(self._conv(x, P[p + '.ds.w'], P[p + '.ds.b'], r, H=h, W=w, Cin=cin, Cout=planes * 4, stride=s))
                 else:
                     r = x
-                o.append(ops.conv2d(b, P[p + '.conv3.w'], P[p + '.conv3.b'], y, H=ho, W=wo, Cin=planes, Cout=planes * 4,
+                o.append(self._conv(b, P[p + '.conv3.w'], P[p + '.conv3.b'], y, H=ho, W=wo, Cin=planes, Cout=planes * 4,
                                     residual=r, relu=True))
                 x, (h, w), cin = y, (ho, wo), planes * 4
             setattr(self, f'enc{li}', x)
         # encoder_projector: fp32 residual stream + bf16 copy into the decoder's concat buffer
-        o.append(ops.conv2d(self.enc3, P['proj.w'], P['proj.b'], self.x, H=self.L, W=1, Cin=1024, Cout=D_MODEL,
+        o.append(self._conv(self.enc3, P['proj.w'], P['proj.b'], self.x, H=self.L, W=1, Cin=1024, Cout=D_MODEL,
                             y2=self.dec_in, ld2=4 * D_MODEL))
         self._prog[key] = o
         return o
@@ -289,28 +292,28 @@ class ClipRuntime:
         P, o, L = self.P, [], self.L
         M8, M4 = self.H8 * self.W8, self.H4 * self.W4
         gn = lambda x, name, y, M, C: ops.groupnorm(x, P[name + '.gn.g'], P[name + '.gn.b'], y, self.gn_ws, M=M, C=C, groups=8, act=1)  # noqa: E731
-        o.append(ops.conv2d(self.dec_in, P['dec.conv_in.w'], P['dec.conv_in.b'], self.d16a, H=L, W=1, Cin=1024, Cout=256))
+        o.append(self._conv(self.dec_in, P['dec.conv_in.w'], P['dec.conv_in.b'], self.d16a, H=L, W=1, Cin=1024, Cout=256))
         o.append(gn(self.d16a, 'dec.conv_in', self.d16b, L, 256))
-        o.append(ops.conv2d(self.enc3, P['dec.adapter_16x.w'], P['dec.adapter_16x.b'], self.d16a, H=L, W=1, Cin=1024, Cout=256,
+        o.append(self._conv(self.enc3, P['dec.adapter_16x.w'], P['dec.adapter_16x.b'], self.d16a, H=L, W=1, Cin=1024, Cout=256,
                             residual=self.d16b))
-        o.append(ops.conv2d(self.d16a, P['dec.conv_16x.w'], P['dec.conv_16x.b'], self.d16b, H=self.H16, W=self.W16, Cin=256, Cout=256,
+        o.append(self._conv(self.d16a, P['dec.conv_16x.w'], P['dec.conv_16x.b'], self.d16b, H=self.H16, W=self.W16, Cin=256, Cout=256,
                             KH=3, KW=3, pad=1))
         o.append(gn(self.d16b, 'dec.conv_16x', self.d16a, L, 256))
         o.append(ops.bilinear(self.d16a, self.d8a, Hi=self.H16, Wi=self.W16, Ho=self.H8, Wo=self.W8, C=256, align_corners=self.align))
-        o.append(ops.conv2d(self.enc2, P['dec.adapter_8x.w'], P['dec.adapter_8x.b'], self.d8b, H=M8, W=1, Cin=512, Cout=256,
+        o.append(self._conv(self.enc2, P['dec.adapter_8x.w'], P['dec.adapter_8x.b'], self.d8b, H=M8, W=1, Cin=512, Cout=256,
                             residual=self.d8a))
         d8c = self.d8a.view(-1)[: M8 * 128]
-        o.append(ops.conv2d(self.d8b, P['dec.conv_8x.w'], P['dec.conv_8x.b'], d8c, H=self.H8, W=self.W8, Cin=256, Cout=128,
+        o.append(self._conv(self.d8b, P['dec.conv_8x.w'], P['dec.conv_8x.b'], d8c, H=self.H8, W=self.W8, Cin=256, Cout=128,
                             KH=3, KW=3, pad=1))
         d8d = self.d8b.view(-1)[: M8 * 128]
         o.append(gn(d8c, 'dec.conv_8x', d8d, M8, 128))
         o.append(ops.bilinear(d8d, self.d4a, Hi=self.H8, Wi=self.W8, Ho=self.H4, Wo=self.W4, C=128, align_corners=self.align))
-        o.append(ops.conv2d(self.enc1, P['dec.adapter_4x.w'], P['dec.adapter_4x.b'], self.d4b, H=M4, W=1, Cin=256, Cout=128,
+        o.append(self._conv(self.enc1, P['dec.adapter_4x.w'], P['dec.adapter_4x.b'], self.d4b, H=M4, W=1, Cin=256, Cout=128,
                             residual=self.d4a))
-        o.append(ops.conv2d(self.d4b, P['dec.conv_4x.w'], P['dec.conv_4x.b'], self.d4a, H=self.H4, W=self.W4, Cin=128, Cout=128,
+        o.append(self._conv(self.d4b, P['dec.conv_4x.w'], P['dec.conv_4x.b'], self.d4a, H=self.H4, W=self.W4, Cin=128, Cout=128,
                             KH=3, KW=3, pad=1))
         o.append(gn(self.d4a, 'dec.conv_4x', self.d4b, M4, 128))
-        o.append(ops.conv2d(self.d4b, P['dec.conv_out.w'], P['dec.conv_out.b'], self.logits, H=M4, W=1, Cin=128, Cout=self.nc, ldo=16))
+        o.append(self._conv(self.d4b, P['dec.conv_out.w'], P['dec.conv_out.b'], self.logits, H=M4, W=1, Cin=128, Cout=self.nc, ldo=16))
         self._prog[key] = o
         return o
 
@@ -322,7 +325,7 @@ class ClipRuntime:
         P = self.P
         k, s, p = (17, 16, 8) if self.align else (16, 16, 0)
         o = [ops.label_to_onehot16(label, self.onehot, Hs=hs, Ws=ws, Hd=self.H, Wd=self.W, ncls=self.nc),
-             ops.conv2d(self.onehot, P['idbank.w'], P['idbank.b'], self.id_emb, H=self.H, W=self.W, Cin=16, Cout=D_MODEL,
+             self._conv(self.onehot, P['idbank.w'], P['idbank.b'], self.id_emb, H=self.H, W=self.W, Cin=16, Cout=D_MODEL,
                         KH=k, KW=k, stride=s, pad=p)]
         self._prog[key] = o
         return o

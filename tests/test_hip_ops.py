@@ -178,6 +178,25 @@ def test_attention_forced_rescale(dev):
     assert_close(out, ref, 2e-2, 'rescale branch')
 
 
+def test_attention_slow_ramp_no_rescale(dev):
+    """Lazy-max path: logits that climb a little every tile (below the rescale threshold per step, far above it
+    in total), so P is exponentiated against a stale reference for many tiles."""
+    from rmem_ocu_amd import ops
+    L, C = 640, 256
+    q = rb(seeded(55, (L, C)))
+    k = rb(seeded(56, (L, C)) * 0.3 + q.mean(0, keepdim=True) * torch.linspace(0, 6, L)[:, None])
+    v = rb(seeded(57, (L, C)))
+    Qh = (q / 32 ** 0.5).reshape(L, 8, 32).permute(1, 0, 2)
+    ref = (torch.softmax(Qh @ k.reshape(L, 8, 32).permute(1, 2, 0), -1) @ v.reshape(L, 8, 32).permute(1, 0, 2)).permute(1, 0, 2).reshape(L, C)
+    for nchunks in (1, 3):
+        out = torch.zeros(L, C, dtype=BF16, device=dev)
+        ws = ops.attn_workspace(L, 8, nchunks, dev)
+        ops.run(ops.mem_read_attn(q.to(BF16).to(dev), k.to(BF16).to(dev), v.to(BF16).to(dev), out, ws, Lq=L, ldq=C, ldkv=C, ldo=C,
+                                  nchunks=nchunks, lk_single=L))
+        torch.cuda.synchronize()
+        assert_close(out, ref, 2e-2, f'ramp nchunks={nchunks}')
+
+
 def test_layernorm(dev):
     from rmem_ocu_amd import ops
     M = 1674
