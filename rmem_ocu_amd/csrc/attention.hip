@@ -140,6 +140,11 @@ __global__ __launch_bounds__(256) void k_attn_partial(AttnParams p) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) { oacc[r] = 0.f; lacc[r] = 0.f; }
   float m_ref = 0.f;
+  // bias - m_ref replicated over the 16 accumulator registers; it is the C operand of the first S^T MFMA of
+  // every block and is only rewritten on a rescale, so no per-tile register fill is needed (D != C)
+  f32x16 cinit;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) cinit[r] = bias;
 
   const int ntiles = (kn + KT - 1) / KT;
   load_tile(0);
@@ -151,17 +156,14 @@ __global__ __launch_bounds__(256) void k_attn_partial(AttnParams p) {
     if (t + 1 < ntiles) load_tile(t + 1);
 
     // S'^T = K . Q^T + (bias - m_ref) for the two 32-key blocks of this tile
-    const float cinit = bias - m_ref;
+    asm volatile("" : "+v"(cinit));          // keep it a live register block (do not rematerialise per tile)
     f32x16 sacc[2];
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) sacc[b][r] = cinit;
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        const bf16x8 a = *reinterpret_cast<const bf16x8*>(&Ks[cur][kswz(b * 32 + lq, 2 * s + lh)]);
-        sacc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[s], sacc[b], 0, 0, 0);
-      }
+      const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(&Ks[cur][kswz(b * 32 + lq, lh)]);
+      const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(&Ks[cur][kswz(b * 32 + lq, 2 + lh)]);
+      sacc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, qf[0], cinit, 0, 0, 0);
+      sacc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, qf[1], sacc[b], 0, 0, 0);
     }
     if (t == ntiles - 1 && (kn & (KT - 1))) {
       const int base = t * KT + 4 * lh;
@@ -183,7 +185,7 @@ __global__ __launch_bounds__(256) void k_attn_partial(AttnParams p) {
       m_ref += delta;
       const float sc = __builtin_amdgcn_exp2f(-delta);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { oacc[r] *= sc; lacc[r] *= sc; }
+      for (int r = 0; r < 16; ++r) { oacc[r] *= sc; lacc[r] *= sc; cinit[r] -= delta; }
 #pragma unroll
       for (int b = 0; b < 2; ++b)
 #pragma unroll
@@ -215,12 +217,13 @@ __global__ __launch_bounds__(256) void k_attn_partial(AttnParams p) {
 
   const int qg = blockIdx.x * 128 + wave * 32 + lq;
   if (qg < p.Lq) {
-    const long row = ((long)c * p.heads + head) * p.Lq + qg;
-    float* o = p.opart + row * D;
+    // partial O layout [chunk][head][G = d / 4][q] x float4: a half-wave stores 512 contiguous bytes per instruction
+    const long ch = (long)c * p.heads + head;
+    f32x4* o = reinterpret_cast<f32x4*>(p.opart) + ch * 8 * p.Lq + qg;
 #pragma unroll
-    for (int g = 0; g < 4; ++g)  // C/D rows (r&3) + 8(r>>2) + 4h  ->  d = 8g + 4h + (0..3)
-      *reinterpret_cast<f32x4*>(o + 8 * g + 4 * lh) = f32x4{oacc[4 * g], oacc[4 * g + 1], oacc[4 * g + 2], oacc[4 * g + 3]};
-    if (lh == 0) *reinterpret_cast<f32x2*>(p.ml + row * 2) = f32x2{m_ref, lacc[0]};
+    for (int g = 0; g < 4; ++g)  // C/D rows (r&3) + 8(r>>2) + 4h  ->  d = 8g + 4h + (0..3)  ->  G = 2g + h
+      o[(long)(2 * g + lh) * p.Lq] = f32x4{oacc[4 * g], oacc[4 * g + 1], oacc[4 * g + 2], oacc[4 * g + 3]};
+    if (lh == 0) *reinterpret_cast<f32x2*>(p.ml + (ch * p.Lq + qg) * 2) = f32x2{m_ref, lacc[0]};
   }
 }
 
@@ -232,38 +235,66 @@ struct CombineParams {
   float* mass; int T;
 };
 
-// one block per query row; thread = output channel (head * 32 + d)
+// merge the key chunks.  grid = (query blocks of 64, 16); thread = (query, head, 4 channels): consecutive lanes
+// read consecutive queries of the [chunk][head][G][q] partial layout.  Blocks with blockIdx.y == 0 also
+// reduce the per-chunk (m, l) pairs to the per-memory-frame probability mass (mean over heads).
 __global__ __launch_bounds__(256) void k_attn_combine(CombineParams p) {
-  __shared__ float hm[8][33];
-  const int q = blockIdx.x, tid = threadIdx.x;
-  const int head = tid >> 5, d = tid & 31;
+  const int tid = threadIdx.x;
+  const int ql = tid & 63;
+  const int q = blockIdx.x * 64 + ql;
+  const bool live = q < p.Lq;
+  const int qc = live ? q : p.Lq - 1;
+  const int hg = blockIdx.y * 4 + (tid >> 6);  // 0..63
+  const int head = hg >> 3, G = hg & 7;
   if (head < p.heads) {
+    const f32x4* op = reinterpret_cast<const f32x4*>(p.opart);
     float m = NEG_BIG;
-    for (int c = 0; c < p.nchunks; ++c) m = fmaxf(m, p.ml[(((long)c * p.heads + head) * p.Lq + q) * 2]);
-    float num = 0.f, den = 0.f, mine = 0.f;
+    for (int c = 0; c < p.nchunks; ++c) m = fmaxf(m, p.ml[(((long)c * p.heads + head) * p.Lq + qc) * 2]);
+    f32x4 num = {0.f, 0.f, 0.f, 0.f};
+    float den = 0.f;
     for (int c = 0; c < p.nchunks; ++c) {
-      const long row = ((long)c * p.heads + head) * p.Lq + q;
-      const float w = __builtin_amdgcn_exp2f(p.ml[row * 2] - m);
-      const float wl = w * p.ml[row * 2 + 1];
-      den += wl;
-      num += w * p.opart[row * D + d];
-      if (c == d) mine = wl;
+      const long ch = (long)c * p.heads + head;
+      const f32x2 mlv = *reinterpret_cast<const f32x2*>(p.ml + (ch * p.Lq + qc) * 2);
+      const float w = __builtin_amdgcn_exp2f(mlv[0] - m);
+      den += w * mlv[1];
+      num += op[(ch * 8 + G) * p.Lq + qc] * w;
     }
-    const float inv = 1.f / den;
-    p.out[(long)q * p.ldo + tid] = (bf16)(num * inv);
-    if (p.mass) hm[head][d] = mine * inv;
+    if (live) {
+      const f32x4 o = num * (1.f / den);
+      *reinterpret_cast<bf16x4*>(p.out + (long)q * p.ldo + head * D + 4 * G) = bf16x4{(bf16)o[0], (bf16)o[1], (bf16)o[2], (bf16)o[3]};
+    }
   }
-  if (p.mass) {
-    __syncthreads();
-    if (tid < p.T) {
-      float acc = 0.f;
-      for (int c = 0; c < p.nchunks; ++c) {
-        const int t = p.chunks ? p.chunks[c].t : 0;
-        if (t != tid) continue;
-        for (int h = 0; h < p.heads; ++h) acc += hm[h][c];
-      }
-      p.mass[(long)q * p.T + tid] = acc / (float)p.heads;
+}
+
+// per-memory-frame probability mass from the per-chunk (m, l) pairs: mass[q][t] = mean_h sum_{c in t} w_c l_c / den_h.
+// thread = (query, head pair); 64 queries per block
+__global__ __launch_bounds__(256) void k_attn_mass(CombineParams p) {
+  __shared__ float macc[4][64][33];
+  __shared__ int ct[32];
+  const int tid = threadIdx.x, ql = tid & 63, hq = tid >> 6;
+  const int q = blockIdx.x * 64 + ql;
+  const int qc = q < p.Lq ? q : p.Lq - 1;
+  if (tid < p.nchunks) ct[tid] = p.chunks[tid].t;
+  for (int t = 0; t < 33; ++t) macc[hq][ql][t] = 0.f;
+  __syncthreads();
+  for (int h = hq; h < p.heads; h += 4) {
+    float m = NEG_BIG, den = 0.f;
+    for (int c = 0; c < p.nchunks; ++c) m = fmaxf(m, p.ml[(((long)c * p.heads + h) * p.Lq + qc) * 2]);
+    for (int c = 0; c < p.nchunks; ++c) {
+      const f32x2 mlv = *reinterpret_cast<const f32x2*>(p.ml + (((long)c * p.heads + h) * p.Lq + qc) * 2);
+      den += __builtin_amdgcn_exp2f(mlv[0] - m) * mlv[1];
     }
+    const float inv = 1.f / (den * (float)p.heads);
+    for (int c = 0; c < p.nchunks; ++c) {
+      const f32x2 mlv = *reinterpret_cast<const f32x2*>(p.ml + (((long)c * p.heads + h) * p.Lq + qc) * 2);
+      macc[hq][ql][ct[c]] += __builtin_amdgcn_exp2f(mlv[0] - m) * mlv[1] * inv;
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < 64 * p.T; i += 256) {
+    const int qq = i / p.T, t = i - qq * p.T;
+    const int qo = blockIdx.x * 64 + qq;
+    if (qo < p.Lq) p.mass[(long)qo * p.T + t] = macc[0][qq][t] + macc[1][qq][t] + macc[2][qq][t] + macc[3][qq][t];
   }
 }
 
@@ -364,6 +395,7 @@ extern "C" int rmem_mem_read_attn(const void* q, int ldq, const void* k_bank, co
   CombineParams cp;
   cp.opart = p.opart; cp.ml = p.ml; cp.chunks = chunks; cp.nchunks = nchunks; cp.Lq = Lq; cp.heads = heads;
   cp.out = (bf16*)out; cp.ldo = ldo; cp.mass = attn_mass; cp.T = T;
-  hipLaunchKernelGGL(k_attn_combine, dim3(Lq), dim3(256), 0, s, cp);
+  hipLaunchKernelGGL(k_attn_combine, dim3((Lq + 63) / 64, 16), dim3(256), 0, s, cp);
+  if (attn_mass) hipLaunchKernelGGL(k_attn_mass, dim3((Lq + 63) / 64), dim3(256), 0, s, cp);
   return rmem_check_launch("rmem_mem_read_attn");
 }
