@@ -9,13 +9,13 @@
 // of the reference (encoders/resnet.py:48-68,
 // decoders/fpn.py:36-68, layers/transformer.py:576, 675, 685, models/aot.py:112, 133).
 //
-// Tiling: 256 threads = 4 waves in a 2x2 grid over a BM x BN block tile, BK = 32,
-// v_mfma_f32_16x16x32_bf16 (one MFMA per k-step and 16x16 sub-tile), fp32
-// accumulation.  Global -> register -> LDS staging, double-buffered LDS, the next
-// tile's global loads are issued before the MFMAs of the current one and written to
-// LDS after them (one barrier per k-step).  LDS rows are 64 B (32 bf16); the 16-byte
-// chunk index is XOR-swizzled with (-(row >> 2)) & 3 so that the four 16-lane groups
-// of a ds_read_b128 fragment read hit 16 distinct 16-byte slots of the 256-byte bank row.
+// Tiling: 256 threads = 4 waves in a 2x2 grid over a BM x BN block tile, BK = 64,
+// v_mfma_f32_16x16x32_bf16 (two MFMAs per k-step and 16x16 sub-tile), fp32 accumulation.
+// Global -> register -> LDS staging: a ring of PF register stages keeps PF k-tiles in flight
+// from HBM/L2 (these problems run at ~1 workgroup per CU, so latency is hidden inside the
+// workgroup, not by occupancy); LDS is double-buffered with one barrier per k-step.  LDS rows
+// are 128 B; the 16-byte chunk index is XOR-swizzled with (row >> 1) & 7 so the four 16-lane
+// groups of a ds_read_b128 fragment read hit 16 distinct 16-byte slots of the 256-byte bank row.
 //
 // Epilogue: the accumulators go through LDS (fp32, half a tile at a time) so that every
 // thread finishes 8 consecutive channels of one output row: bias / residual / second
@@ -46,7 +46,10 @@ struct ConvParams {
   int vec_ok;            // all leading dimensions / pointers allow 8-wide vector access
 };
 
-__device__ __forceinline__ int swz(int row, int chunk) { return row * 32 + ((chunk ^ ((-(row >> 2)) & 3)) << 3); }
+// LDS tile rows are 128 B (BK = 64 bf16 = 8 chunks of 16 B).  Physical chunk = chunk ^ ((row >> 1) & 7): the 16 lanes of
+// every ds_read_b128 lane group (rows r..r+3, r+12..r+15 at chunk c and rows r+4..r+11 at chunk c+1) then land on 16
+// distinct 16-byte slots of the 256-byte bank row.
+__device__ __forceinline__ int swz(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 1) & 7)) << 3); }
 
 // finish 8 consecutive channels n..n+7 of output row m (v = accumulator + nothing yet)
 __device__ __forceinline__ void finish8(const ConvParams& p, int m, int n, float (&v)[8]) {
@@ -101,19 +104,20 @@ __device__ __forceinline__ void finish1(const ConvParams& p, int m, int n, float
   else reinterpret_cast<bf16*>(p.y)[(long)m * p.ldo + n] = (bf16)v;
 }
 
-template <int BM, int BN, bool IS1X1, bool SPLITK>
+template <int BM, int BN, int PF, bool IS1X1, bool SPLITK>
 __global__ __launch_bounds__(256) void k_conv_gemm(ConvParams p) {
-  constexpr int NA = BM / 64;  // 16-byte A chunks per thread per k-step
-  constexpr int NB = BN / 64;
+  constexpr int BK = 64;
+  constexpr int NA = BM / 32;  // 16-byte A chunks per thread per k-step (BM rows x 8 chunks / 256 threads)
+  constexpr int NB = BN / 32;
   constexpr int TM = BM / 32;  // 16x16 tiles per wave along M
   constexpr int TN = BN / 32;
   constexpr int CP = BN + 4;   // padded fp32 row of the epilogue staging tile
-  constexpr int AB_BYTES = 2 * (BM + BN) * 32 * 2;
+  constexpr int AB_BYTES = 2 * (BM + BN) * BK * 2;
   constexpr int C_BYTES = (BM / 2) * CP * 4;
   constexpr int SMEM = AB_BYTES > C_BYTES ? AB_BYTES : C_BYTES;
   __shared__ __attribute__((aligned(16))) char smem[SMEM];
-  bf16* As = reinterpret_cast<bf16*>(smem);                 // [2][BM*32]
-  bf16* Bs = As + 2 * BM * 32;                              // [2][BN*32]
+  bf16* As = reinterpret_cast<bf16*>(smem);                 // [2][BM*64]
+  bf16* Bs = As + 2 * BM * BK;                              // [2][BN*64]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -121,85 +125,80 @@ __global__ __launch_bounds__(256) void k_conv_gemm(ConvParams p) {
   const int wm = wave >> 1, wn = wave & 1;
   const int m0 = blockIdx.x * BM;
   const int n0 = blockIdx.y * BN;
-  const int nk_total = (p.K + 31) / 32;
+  const int nk_total = (p.K + BK - 1) / BK;
   const int kt0 = SPLITK ? blockIdx.z * p.steps_per_split : 0;
   const int kt1 = SPLITK ? min(nk_total, kt0 + p.steps_per_split) : nk_total;
 
-  // ---- per-thread gather state for the A operand ----
-  int a_row[NA], a_chunk[NA];
+  // ---- per-thread gather state for the A operand: chunk id = tid + i*256 -> (row = id >> 3, chunk = id & 7) ----
+  const int a_chunk = tid & 7;             // same for every i (256 % 8 == 0)
   long a_base[NA];
   int a_hi0[NA], a_wi0[NA];
   bool a_ok[NA];
-  int a_ci[NA], a_kw[NA], a_kh[NA];
+  int a_ci, a_kw, a_kh;                    // k position of this thread's chunk column (shared by its rows)
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
-    const int id = tid + i * 256;
-    a_row[i] = id >> 2;
-    a_chunk[i] = id & 3;
-    const int m = m0 + a_row[i];
+    const int m = m0 + (tid >> 3) + i * 32;
     a_ok[i] = m < p.M;
     if (IS1X1) {
       a_base[i] = (long)m * p.Cin;
       a_hi0[i] = a_wi0[i] = 0;
-      a_ci[i] = a_kw[i] = a_kh[i] = 0;
     } else {
       const int ho = m / p.Wo, wo = m - ho * p.Wo;
       a_hi0[i] = ho * p.stride - p.pad;
       a_wi0[i] = wo * p.stride - p.pad;
       a_base[i] = 0;
-      const int kidx = kt0 * 32 + a_chunk[i] * 8;
-      const int kk = kidx / p.Cin;
-      a_ci[i] = kidx - kk * p.Cin;
-      a_kh[i] = kk / p.KW;
-      a_kw[i] = kk - a_kh[i] * p.KW;
     }
   }
-  int b_row[NB], b_chunk[NB];
-#pragma unroll
-  for (int i = 0; i < NB; ++i) {
-    const int id = tid + i * 256;
-    b_row[i] = id >> 2;
-    b_chunk[i] = id & 3;
+  if (IS1X1) {
+    a_ci = a_kw = a_kh = 0;
+  } else {
+    const int kidx = kt0 * BK + a_chunk * 8;
+    const int kk = kidx / p.Cin;
+    a_ci = kidx - kk * p.Cin;
+    a_kh = kk / p.KW;
+    a_kw = kk - a_kh * p.KW;
   }
+  const int b_chunk = tid & 7;
 
-  bf16x8 ra[NA], rb[NB];
   const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+  // register ring: PF tiles of (A, B) pieces in flight from HBM/L2 while earlier tiles are being multiplied
+  bf16x8 ra[PF][NA], rb[PF][NB];
 
-  auto load_tile = [&](int k0) {
+  auto load_tile = [&](bf16x8 (&xa)[NA], bf16x8 (&xb)[NB], int k0) {
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       bf16x8 v = zero8;
       if (IS1X1) {
-        const int kidx = k0 + a_chunk[i] * 8;
+        const int kidx = k0 + a_chunk * 8;
         if (a_ok[i] && kidx < p.K) v = *reinterpret_cast<const bf16x8*>(p.x + a_base[i] + kidx);
       } else {
-        const int hi = a_hi0[i] + a_kh[i], wi = a_wi0[i] + a_kw[i];
-        if (a_ok[i] && a_kh[i] < p.KH && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W)
-          v = *reinterpret_cast<const bf16x8*>(p.x + ((long)hi * p.W + wi) * p.Cin + a_ci[i]);
-        // advance this chunk's (ci, kw, kh) by BK = 32 for the next k-step
-        int ci = a_ci[i] + 32, kw = a_kw[i], kh = a_kh[i];
-        while (ci >= p.Cin) {
-          ci -= p.Cin;
-          if (++kw == p.KW) { kw = 0; ++kh; }
-        }
-        a_ci[i] = ci; a_kw[i] = kw; a_kh[i] = kh;
+        const int hi = a_hi0[i] + a_kh, wi = a_wi0[i] + a_kw;
+        if (a_ok[i] && a_kh < p.KH && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W)
+          v = *reinterpret_cast<const bf16x8*>(p.x + ((long)hi * p.W + wi) * p.Cin + a_ci);
       }
-      ra[i] = v;
+      xa[i] = v;
+    }
+    if (!IS1X1) {   // advance this thread's (ci, kw, kh) by BK for the next k-step
+      a_ci += BK;
+      while (a_ci >= p.Cin) {
+        a_ci -= p.Cin;
+        if (++a_kw == p.KW) { a_kw = 0; ++a_kh; }
+      }
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       bf16x8 v = zero8;
-      const int n = n0 + b_row[i];
-      const int kidx = k0 + b_chunk[i] * 8;
+      const int n = n0 + (tid >> 3) + i * 32;
+      const int kidx = k0 + b_chunk * 8;
       if (n < p.Cout && kidx < p.K) v = *reinterpret_cast<const bf16x8*>(p.w + (long)n * p.K + kidx);
-      rb[i] = v;
+      xb[i] = v;
     }
   };
-  auto store_tile = [&](int buf) {
+  auto store_tile = [&](const bf16x8 (&xa)[NA], const bf16x8 (&xb)[NB], int buf) {
 #pragma unroll
-    for (int i = 0; i < NA; ++i) *reinterpret_cast<bf16x8*>(&As[buf * BM * 32 + swz(a_row[i], a_chunk[i])]) = ra[i];
+    for (int i = 0; i < NA; ++i) *reinterpret_cast<bf16x8*>(&As[buf * BM * BK + swz((tid >> 3) + i * 32, a_chunk)]) = xa[i];
 #pragma unroll
-    for (int i = 0; i < NB; ++i) *reinterpret_cast<bf16x8*>(&Bs[buf * BN * 32 + swz(b_row[i], b_chunk[i])]) = rb[i];
+    for (int i = 0; i < NB; ++i) *reinterpret_cast<bf16x8*>(&Bs[buf * BN * BK + swz((tid >> 3) + i * 32, b_chunk)]) = xb[i];
   };
 
   f32x4 acc[TM][TN];
@@ -209,28 +208,39 @@ __global__ __launch_bounds__(256) void k_conv_gemm(ConvParams p) {
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int fr = lane & 15, fc = lane >> 4;
-  if (kt0 < kt1) {
-    load_tile(kt0 * 32);
-    store_tile(0);
-  }
+  // prologue: PF tiles in flight, tile kt0 staged
+#pragma unroll
+  for (int u = 0; u < PF; ++u)
+    if (kt0 + u < kt1) load_tile(ra[u], rb[u], (kt0 + u) * BK);
+  if (kt0 < kt1) store_tile(ra[0], rb[0], 0);
   __syncthreads();
-  for (int kt = kt0; kt < kt1; ++kt) {
-    const int cur = (kt - kt0) & 1;
-    if (kt + 1 < kt1) load_tile((kt + 1) * 32);
-    bf16x8 af[TM], bfr[TN];
+
+  for (int ktb = kt0; ktb < kt1; ktb += PF) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
-      af[i] = *reinterpret_cast<const bf16x8*>(&As[cur * BM * 32 + swz(wm * (BM / 2) + i * 16 + fr, fc)]);
+    for (int u = 0; u < PF; ++u) {        // static ring index (runtime-indexed register arrays would go to scratch)
+      const int kt = ktb + u;
+      if (kt < kt1) {
+        const int cur = (kt - kt0) & 1;
+        if (kt + PF < kt1) load_tile(ra[u], rb[u], (kt + PF) * BK);     // slot u was drained into LDS one step ago
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
-      bfr[j] = *reinterpret_cast<const bf16x8*>(&Bs[cur * BN * 32 + swz(wn * (BN / 2) + j * 16 + fr, fc)]);
+        for (int ks = 0; ks < 2; ++ks) {
+          bf16x8 af[TM], bfr[TN];
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+          for (int i = 0; i < TM; ++i)
+            af[i] = *reinterpret_cast<const bf16x8*>(&As[cur * BM * BK + swz(wm * (BM / 2) + i * 16 + fr, 4 * ks + fc)]);
 #pragma unroll
-      for (int j = 0; j < TN; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-    if (kt + 1 < kt1) store_tile(cur ^ 1);
-    __syncthreads();
+          for (int j = 0; j < TN; ++j)
+            bfr[j] = *reinterpret_cast<const bf16x8*>(&Bs[cur * BN * BK + swz(wn * (BN / 2) + j * 16 + fr, 4 * ks + fc)]);
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < kt1) store_tile(ra[(u + 1) % PF], rb[(u + 1) % PF], cur ^ 1);
+        __syncthreads();
+      }
+    }
   }
 
   // ---- epilogue through LDS: two passes of BM/2 rows ----
@@ -289,17 +299,17 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue(ConvParams p, int split
     for (int j = 0; j < 8; ++j) finish1(p, m, n + j, v[j]);
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int PF>
 void launch(const ConvParams& p, bool is1x1, int splits, hipStream_t s) {
   dim3 grid((p.M + BM - 1) / BM, (p.Cout + BN - 1) / BN, splits);
   if (splits > 1) {
-    if (is1x1) hipLaunchKernelGGL((k_conv_gemm<BM, BN, true, true>), grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((k_conv_gemm<BM, BN, false, true>), grid, dim3(256), 0, s, p);
+    if (is1x1) hipLaunchKernelGGL((k_conv_gemm<BM, BN, PF, true, true>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((k_conv_gemm<BM, BN, PF, false, true>), grid, dim3(256), 0, s, p);
     const long total = (long)p.M * (p.Cout / 8);
     hipLaunchKernelGGL(k_splitk_epilogue, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p, splits);
   } else {
-    if (is1x1) hipLaunchKernelGGL((k_conv_gemm<BM, BN, true, false>), grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((k_conv_gemm<BM, BN, false, false>), grid, dim3(256), 0, s, p);
+    if (is1x1) hipLaunchKernelGGL((k_conv_gemm<BM, BN, PF, true, false>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((k_conv_gemm<BM, BN, PF, false, false>), grid, dim3(256), 0, s, p);
   }
 }
 
@@ -307,10 +317,10 @@ void launch(const ConvParams& p, bool is1x1, int splits, hipStream_t s) {
 int plan_splits(int M, int Cout, int K) {
   if (Cout % 8) return 1;
   const long tiles = (long)((M + 63) / 64) * ((Cout + 63) / 64);
-  const int nk = (K + 31) / 32;
-  if (tiles >= 192 || nk < 16) return 1;
+  const int nk = (K + 63) / 64;
+  if (tiles >= 192 || nk < 8) return 1;
   int s = (int)((448 + tiles - 1) / tiles);      // aim at >= ~450 workgroups
-  s = min(s, nk / 8);                            // keep >= 8 k-steps per slice
+  s = min(s, nk / 4);                            // keep >= 4 k-steps (of 64) per slice
   return max(1, min(s, 16));
 }
 
@@ -350,7 +360,7 @@ extern "C" int rmem_conv2d_nhwc(const rmem_conv_desc* d, const void* x, const vo
   p.M = Ho * Wo; p.K = d->KH * d->KW * d->Cin;
   p.ldo = d->ldo; p.ldr = d->ldr; p.ld2 = d->ld2;
   p.relu = d->relu; p.out_f32 = d->out_f32; p.res_f32 = d->res_f32;
-  p.steps_per_split = (p.K + 31) / 32;
+  p.steps_per_split = (p.K + 63) / 64;
   auto al = [](const void* q, int a) { return q == nullptr || ((uintptr_t)q % a) == 0; };
   p.vec_ok = p.Cout % 8 == 0 && p.ldo % 8 == 0 && al(y, 16) && al(bias, 16) &&
              (!residual || (p.ldr % 8 == 0 && al(residual, 16))) && (!y2 || (p.ld2 % 8 == 0 && al(y2, 16)));
@@ -358,17 +368,17 @@ extern "C" int rmem_conv2d_nhwc(const rmem_conv_desc* d, const void* x, const vo
   hipStream_t s = (hipStream_t)stream;
   const long t128 = (long)((p.M + 127) / 128) * ((p.Cout + 127) / 128);
   if (!use_small_tiles(p.M, p.Cout)) {
-    if (p.Cout >= 128 && t128 >= 384) launch<128, 128>(p, is1x1, 1, s);
-    else launch<128, 64>(p, is1x1, 1, s);
+    if (p.Cout >= 128 && t128 >= 384) launch<128, 128, 2>(p, is1x1, 1, s);
+    else launch<128, 64, 3>(p, is1x1, 1, s);
   } else {
     int splits = workspace ? plan_splits(p.M, p.Cout, p.K) : 1;
     if (splits > 1) {
-      const int nk = (p.K + 31) / 32;
+      const int nk = (p.K + 63) / 64;
       p.steps_per_split = (nk + splits - 1) / splits;
       splits = (nk + p.steps_per_split - 1) / p.steps_per_split;   // no empty slice
       p.slabs = (float*)workspace;
     }
-    launch<64, 64>(p, is1x1, splits, s);
+    launch<64, 64, 4>(p, is1x1, splits, s);
   }
   return rmem_check_launch("rmem_conv2d_nhwc");
 }
