@@ -158,6 +158,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     run_steps(args.steps, args.sample_every)
+    host_enqueue = time.perf_counter() - t0
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -180,7 +181,7 @@ def main():
             'config': {'workload': 'davis17_480p_r50_N8', 'clip_frames': CLIP_LEN, 'video_hw': list(VIDEO_HW), 'network_hw': list(net_hw),
                        'tokens': 1674, 'objects': NUM_OBJS, 'memory_bank': '1+7', 'gap': 5, 'clips_in_flight_per_gpu': C,
                        'parallelism': f'clip-parallel x{world}', 'weights': 'synthetic (no checkpoint offline)',
-                       'hipgraphs': not args.no_graphs},
+                       'hipgraphs': not args.no_graphs, 'host_enqueue_ms_per_step': round(1e3 * host_enqueue / args.steps, 4)},
             'roofline': {'bound': 'mfma', 'kernel': 'k_attn_partial<true>', 'achieved': None if achieved is None else round(achieved, 2),
                          'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': None if achieved is None else round(achieved / PEAK_BF16_TFLOPS, 4),
                          'traffic': None, 'launches_timed': nl.value,

@@ -142,6 +142,11 @@ int rmem_label_to_onehot16(const void* label, int label_is_f32, int Hs, int Ws, 
 int rmem_evict_scores(const float* logits_nhwc, int ldl, int num_classes, int keep_max_id, int Hi, int Wi,
                       int He, int We, const float* attn_mass, int T, float* scores, void* stream);
 
+/* Asynchronous copy on `stream` (device<->device, or pinned host<->device): frame ingest into the fixed input
+ * buffer, bank append of curr_K (layers/transformer.py:319), chunk-table upload, eviction-score readback.
+ * Capturable into a hipGraph (memcpy node). */
+int rmem_copy_async(void* dst, const void* src, size_t bytes, void* stream);
+
 /* ------------------------------------------------------------------ stream capture helpers
  * Thin wrappers over hipStreamBeginCapture / hipGraphInstantiate / hipGraphLaunch so the Python host
  * can replay one frame's launch sequence as a hipGraph. */

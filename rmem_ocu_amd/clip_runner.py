@@ -14,6 +14,8 @@ from typing import List, Optional, Sequence
 
 import torch
 
+from . import ops
+
 
 def shard_clips(num_clips: int, rank: int, world: int, lengths: Optional[Sequence[int]] = None) -> List[int]:
     """Static longest-first assignment of clip ids to ranks (the reference pops a shared queue; with
@@ -75,7 +77,7 @@ class ClipSlot:
         i = self.cursor
         self.engine.propagate_to_label(self.frames[i:i + 1], self.cur_label)
         self.engine.update_memory_from_label_u8(self.cur_label)
-        with torch.cuda.stream(self.engine.aot_engines[0].stream):
-            self.labels[i].copy_(self.cur_label, non_blocking=True)      # the clip's delivered masks stay on the device
+        # the clip's delivered masks stay on the device
+        ops.copy_async(self.labels[i], self.cur_label, self.cur_label.numel())(self.engine.aot_engines[0].stream.cuda_stream)
         self.cursor += 1
         self.done = self.cursor >= self.frames.shape[0]

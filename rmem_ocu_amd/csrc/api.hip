@@ -60,3 +60,9 @@ extern "C" int rmem_graph_destroy(void* graph_exec) {
   HIP_TRY(hipGraphExecDestroy((hipGraphExec_t)graph_exec), "rmem_graph_destroy");
   return 0;
 }
+
+extern "C" int rmem_copy_async(void* dst, const void* src, size_t bytes, void* stream) {
+  RMEM_REQUIRE(dst && src && bytes > 0, "rmem_copy_async: bad argument");
+  HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, (hipStream_t)stream), "rmem_copy_async");
+  return 0;
+}

@@ -89,7 +89,8 @@ class AOTEngine:
         self.input_size_2d = None
         self.enc_size_2d = None
         self.enc_hw = None
-        self.long_memories_indexes: List[int] = []
+        self._indexes: List[int] = []
+        self._pending_evict = None
         self.policy = MemoryPolicy()
         self.drop_trace: List[int] = []
         self.pred_id_logits = None
@@ -99,6 +100,12 @@ class AOTEngine:
 
     def eval(self):
         return self
+
+    @property
+    def long_memories_indexes(self) -> List[int]:
+        """Frame indexes of the bank entries (aot_engine.py:323, 351); resolves a deferred eviction first."""
+        self._resolve_pending()
+        return self._indexes
 
     def update_size(self, input_size, enc_size):
         self.input_size_2d = tuple(int(v) for v in input_size)
@@ -131,6 +138,7 @@ class AOTEngine:
         return self.rt
 
     def _run(self, key: str, prog: list):
+        """Enqueue a launch list on the engine's stream: directly, or (use_graphs) as ONE hipGraph per key."""
         s = self._stream()
         if self.use_graphs:
             g = self._graphs.get(key)
@@ -166,6 +174,7 @@ class AOTEngine:
         rt = self._ensure_runtime(img)
         if self.input_size_2d is None:
             self.update_size(img.shape[2:], (rt.H16, rt.W16))
+        self._pending_evict = None
         with self._scope():
             self.img_in.copy_(img.reshape(3, rt.H, rt.W), non_blocking=True)
             self._set_label(mask)
@@ -174,13 +183,11 @@ class AOTEngine:
             slot = rt.take_slot()
             rt.slots.append(slot)
             rt.upload_chunks(self._stream())
-            self._run('encode', rt.prog_encode(self.img_in))
-            self._run('id_label_in', rt.prog_id_emb(self.label_in, rt.H, rt.W))
-            self._run(f'lstt_ref{slot}', rt.prog_lstt(True, 1, slot))
+            self._run(f'ref{slot}', rt.prog_encode(self.img_in) + rt.prog_id_emb(self.label_in, rt.H, rt.W) +
+                      rt.prog_lstt(True, 1, slot) + rt.prog_decode())
             self.last_mem_step = frame_step
             self.policy = MemoryPolicy()
-            self.long_memories_indexes.append(self.frame_step)
-            self._run('decode', rt.prog_decode())
+            self._indexes.append(self.frame_step)
             self.pred_id_logits = rt.logits
 
     # ------------------------------------------------------------------ propagate
@@ -189,13 +196,12 @@ class AOTEngine:
         if img is None:
             raise ValueError('match_propogate_one_frame needs the frame (offline encoding is a training-only path)')
         rt = self.rt
+        self._resolve_pending()
         with self._scope() as cur:
             self.img_in.copy_(img.reshape(3, rt.H, rt.W), non_blocking=True)
             T = len(rt.slots)
             self._T_at_propagate = T
-            self._run('encode', rt.prog_encode(self.img_in))
-            self._run(f'lstt_prop{T}', rt.prog_lstt(False, T))
-            self._run('decode', rt.prog_decode())
+            self._run(f'prop{T}', rt.prog_encode(self.img_in) + rt.prog_lstt(False, T) + rt.prog_decode())
             self.pred_id_logits = rt.logits
             out = self._logits_out(output_size)
             out.record_stream(cur)
@@ -207,20 +213,19 @@ class AOTEngine:
         softmax -> argmax (managers/evaluator.py:430-441) without materialising [11, Ho, Wo] logits."""
         self.frame_step += 1
         rt = self.rt
+        self._resolve_pending()
         Ho, Wo = int(label_u8.shape[-2]), int(label_u8.shape[-1])
         keep = self.obj_nums[0] if self.obj_nums else self.max_obj_num
         with self._scope():
-            self.img_in.copy_(img.reshape(3, rt.H, rt.W), non_blocking=True)
+            ops.copy_async(self.img_in, img, 3 * rt.H * rt.W * 4)(self._stream())
             T = len(rt.slots)
             self._T_at_propagate = T
-            self._run('encode', rt.prog_encode(self.img_in))
-            self._run(f'lstt_prop{T}', rt.prog_lstt(False, T))
-            self._run('decode', rt.prog_decode())
-            key = f'post_{label_u8.data_ptr()}_{Ho}_{Wo}'
-            if key not in rt._prog:
-                rt._prog[key] = [ops.logits_post(rt.logits, ldl=16, nc=rt.nc, keep=keep, Hi=rt.H4, Wi=rt.W4, Ho=Ho, Wo=Wo,
-                                                 align_corners=self.align_corners, label_u8=label_u8)]
-            self._run(key, rt._prog[key])
+            key = f'propl{T}_{label_u8.data_ptr()}_{Ho}_{Wo}'
+            pk = f'post_{label_u8.data_ptr()}_{Ho}_{Wo}'
+            if pk not in rt._prog:
+                rt._prog[pk] = [ops.logits_post(rt.logits, ldl=16, nc=rt.nc, keep=keep, Hi=rt.H4, Wi=rt.W4, Ho=Ho, Wo=Wo,
+                                                align_corners=self.align_corners, label_u8=label_u8)]
+            self._run(key, rt.prog_encode(self.img_in) + rt.prog_lstt(False, T) + rt.prog_decode() + rt._prog[pk])
             self.pred_id_logits = rt.logits
 
     def decode_current_logits(self, output_size=None):
@@ -256,8 +261,9 @@ class AOTEngine:
             raise NotImplementedError('probability masks (>10 objects soft aggregation) are not built yet')
         with self._scope():
             self._set_label(curr_mask)
-            self._run('id_label_in', rt.prog_id_emb(self.label_in, rt.H, rt.W))
-            self._finish_update()
+            self._finish_update('lab', rt.prog_id_emb(self.label_in, rt.H, rt.W))
+        if self.sync_caller:
+            self._resolve_pending()
 
     def update_memory_from_label_u8(self, label_u8: torch.Tensor):
         """Fast path: argmax labels at the OUTPUT size (uint8 [Ho, Wo], device); the nearest resize to the
@@ -265,10 +271,13 @@ class AOTEngine:
         rt = self.rt
         hs, ws = int(label_u8.shape[-2]), int(label_u8.shape[-1])
         with self._scope():
-            self._run(f'id_u8_{label_u8.data_ptr()}', rt.prog_id_emb(label_u8, hs, ws))
-            self._finish_update()
+            self._finish_update(f'u8_{label_u8.data_ptr()}', rt.prog_id_emb(label_u8, hs, ws))
 
-    def _finish_update(self):
+    def _finish_update(self, id_key: str, id_prog: list):
+        """Memory update of the frame just propagated (aot_engine.py:327-369).  The launch list (identity embedding +
+        short-term update [+ bank append]) is one graph; if the bank now exceeds its size the eviction scores are
+        reduced on the device and read back asynchronously -- the decision itself is taken lazily
+        (_resolve_pending) right before the bank is used again, so the host never waits here."""
         rt, s = self.rt, self._stream()
         update_long = (not getattr(self.cfg, 'NO_LONG_MEMORY', False)) and \
             (self.frame_step - self.last_mem_step >= self.long_term_mem_gap)
@@ -276,26 +285,38 @@ class AOTEngine:
         if update_long:
             self.last_mem_step = self.frame_step
             slot = rt.take_slot()
-        if slot is None:
-            self._run('update_None', rt.prog_update(None))
-        else:
-            ops.run(rt.prog_update(slot), s)
+        self._run(f'upd_{slot}_{id_key}', id_prog + rt.prog_update(slot))
         if not update_long:
             return
         rt.slots.append(slot)
-        self.long_memories_indexes.append(self.frame_step)
+        self._indexes.append(self.frame_step)
         n_keep = self.cfg.FORMER_MEM_LEN + self.cfg.LATTER_MEM_LEN
         if len(rt.slots) > n_keep:
             Tp = self._T_at_propagate
             keep = self.obj_nums[0] if self.obj_nums else self.max_obj_num
-            ops.run(ops.evict_scores(rt.logits, rt.mass, rt.scores, ldl=16, nc=rt.nc, keep=keep, Hi=rt.H4, Wi=rt.W4,
-                                     He=rt.H16, We=rt.W16, T=Tp), s)
-            scores = rt.scores[:Tp].cpu()           # the one host sync of the policy (the reference has it too, transformer.py:353)
-            drop = self.policy.choose(scores, self.long_memories_indexes)
-            self.drop_trace.append(drop)
-            rt.free.append(rt.slots.pop(drop))
-            del self.long_memories_indexes[drop]
-        rt.upload_chunks(s)
+            ops.run([ops.evict_scores(rt.logits, rt.mass, rt.scores, ldl=16, nc=rt.nc, keep=keep, Hi=rt.H4, Wi=rt.W4,
+                                      He=rt.H16, We=rt.W16, T=Tp),
+                     ops.copy_async(rt.scores_host, rt.scores, 4 * Tp)], s)
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+            self._pending_evict = (Tp, ev)
+        else:
+            rt.upload_chunks(s)
+
+    def _resolve_pending(self):
+        """Finish a deferred eviction: wait for the score readback (normally long done), run the policy on the host
+        (layers/transformer.py:353-411), drop the entry from the slot table and upload the new chunk table."""
+        if self._pending_evict is None:
+            return
+        Tp, ev = self._pending_evict
+        self._pending_evict = None
+        ev.synchronize()                      # the one host wait of the policy (the reference syncs here too, transformer.py:353)
+        rt = self.rt
+        drop = self.policy.choose(rt.scores_host[:Tp].clone(), self._indexes)
+        self.drop_trace.append(drop)
+        rt.free.append(rt.slots.pop(drop))
+        del self._indexes[drop]
+        rt.upload_chunks(self._stream())
 
 
 class AOTInferEngine:

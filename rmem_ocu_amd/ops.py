@@ -179,6 +179,13 @@ def evict_scores(logits, mass, scores, *, ldl, nc, keep, Hi, Wi, He, We, T) -> O
     return Op(_lib.lib().rmem_evict_scores, args, 'rmem_evict_scores', (logits, mass, scores))
 
 
+def copy_async(dst, src, nbytes: int) -> Op:
+    """dst/src: torch tensors (device, or pinned host); plain byte copy on the launch stream."""
+    assert dst.is_contiguous() and src.is_contiguous()
+    assert nbytes <= dst.numel() * dst.element_size() and nbytes <= src.numel() * src.element_size()
+    return Op(_lib.lib().rmem_copy_async, (_ptr(dst), _ptr(src), nbytes), 'rmem_copy_async', (dst, src))
+
+
 class Graph:
     """A captured launch list (hipGraph) replayable on any stream."""
 

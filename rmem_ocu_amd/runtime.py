@@ -123,7 +123,9 @@ class ClipRuntime:
         self.logits = torch.zeros(M4, 16, dtype=F32, device=device)
         # ---- memory bank ----
         self.chunks = torch.zeros(MAX_CHUNKS, 8, dtype=torch.int32, device=device)
-        self.chunks_host = torch.zeros(MAX_CHUNKS, 8, dtype=torch.int32).pin_memory() if device.type == 'cuda' else None
+        self.chunks_host = torch.zeros(8, MAX_CHUNKS, 8, dtype=torch.int32).pin_memory()
+        self._chunk_stage = 0
+        self.scores_host = torch.zeros(MAX_CHUNKS, dtype=F32).pin_memory()
         self._alloc_bank(bank_slots)
         self._prog: Dict[str, list] = {}
 
@@ -175,11 +177,12 @@ class ClipRuntime:
             for j in range(splits):
                 kb = j * per
                 rows.append((s, kb, min(per, self.L - kb), pes[t], t))
-        host = self.chunks_host
+        # a fresh pinned staging row per upload: an earlier async upload may still be reading the previous one
+        self._chunk_stage = (self._chunk_stage + 1) % self.chunks_host.shape[0]
+        host = self.chunks_host[self._chunk_stage]
         host.zero_()
         host[:n, :5] = torch.tensor(rows, dtype=torch.int32)
-        with torch.cuda.stream(torch.cuda.ExternalStream(stream)):
-            self.chunks.copy_(host, non_blocking=True)
+        ops.copy_async(self.chunks, host, MAX_CHUNKS * 8 * 4)(stream)
 
     # ------------------------------------------------------------------ programs
     def _conv(self, *a, **kw):
@@ -345,19 +348,6 @@ class ClipRuntime:
             if append_slot is not None:
                 o.append(ops.add_bf16(self.curr_V[i], self.id_emb, self.tmp, L * C))
                 o.append(self._lin(self.tmp, d + '.linear_V', self.bank_V[i][append_slot], L, C, C))
-                o.append(_CopyOp(self.curr_Q[i], self.bank_K[i][append_slot], L * C))
+                o.append(ops.copy_async(self.bank_K[i][append_slot], self.curr_Q[i], L * C * 2))
         self._prog[key] = o
         return o
-
-
-class _CopyOp(ops.Op):
-    """Device-to-device copy on the launch stream (bank append of curr_K)."""
-    __slots__ = ('src', 'dst', 'n')
-
-    def __init__(self, src, dst, n):
-        self.src, self.dst, self.n = src, dst, n
-        self.fn, self.args, self.name, self.keep = None, (), 'copy', (src, dst)
-
-    def __call__(self, stream: int):
-        with torch.cuda.stream(torch.cuda.ExternalStream(stream)):
-            self.dst.view(-1)[: self.n].copy_(self.src.view(-1)[: self.n], non_blocking=True)
