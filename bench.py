@@ -70,7 +70,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=790)
     ap.add_argument('--warmup', type=int, default=79)
-    ap.add_argument('--clips-in-flight', type=int, default=int(os.environ.get('RMEM_CLIPS_IN_FLIGHT', 8)))
+    ap.add_argument('--clips-in-flight', type=int, default=int(os.environ.get('RMEM_CLIPS_IN_FLIGHT', 16)))
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graphs', action='store_true')
     ap.add_argument('--sample-every', type=int, default=8, help='time the memory-read kernel on 1 in N timed frames')

@@ -138,7 +138,8 @@ int rmem_logits_post(const float* logits_nhwc, int ldl, int num_classes, int kee
 int rmem_label_to_onehot16(const void* label, int label_is_f32, int Hs, int Ws, int Hd, int Wd,
                            int num_classes, void* out, void* stream);
 /* scores[t] = sum_q mass[q][t] * (1 - softmax(bilinear_ac(logits -> He x We))[0])
- * (engines/aot_engine.py:355-362 + layers/transformer.py:341-351, the device half of the eviction policy). */
+ * (engines/aot_engine.py:355-362 + layers/transformer.py:341-351, the device half of the eviction policy).
+ * `scores` must hold 32 + 64 * 32 floats: the first T are the result, the rest is reduction scratch. */
 int rmem_evict_scores(const float* logits_nhwc, int ldl, int num_classes, int keep_max_id, int Hi, int Wi,
                       int He, int We, const float* attn_mass, int T, float* scores, void* stream);
 

@@ -27,6 +27,7 @@
 // while applying the same fused epilogue.
 #include "common.h"
 #include "../../include/rmem.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -318,16 +319,17 @@ int plan_splits(int M, int Cout, int K) {
   if (Cout % 8) return 1;
   const long tiles = (long)((M + 63) / 64) * ((Cout + 63) / 64);
   const int nk = (K + 63) / 64;
-  if (tiles >= 192 || nk < 8) return 1;
+  if (tiles >= 192 || nk < 24) return 1;          // measured: K = 1024 (16 steps) is faster unsplit, K >= 2304 split
   int s = (int)((448 + tiles - 1) / tiles);      // aim at >= ~450 workgroups
   s = min(s, nk / 4);                            // keep >= 4 k-steps (of 64) per slice
   return max(1, min(s, 16));
 }
 
+// Measured on MI355X over every conv / linear shape of the path (M = 1674 .. 102425): the 64x64 tile at 4 workgroups
+// per CU beats 128x64 and 128x128 everywhere (these GEMMs are latency-bound, more resident workgroups win); the larger
+// tiles stay available for problems with >= 4096 small tiles.
 bool use_small_tiles(int M, int Cout) {
-  const long t128 = (long)((M + 127) / 128) * ((Cout + 127) / 128);
-  const long t12864 = (long)((M + 127) / 128) * ((Cout + 63) / 64);
-  return !((Cout >= 128 && t128 >= 384) || t12864 >= 256);
+  return (long)((M + 63) / 64) * ((Cout + 63) / 64) < 4096;
 }
 
 }  // namespace
@@ -367,6 +369,10 @@ extern "C" int rmem_conv2d_nhwc(const rmem_conv_desc* d, const void* x, const vo
   const bool is1x1 = d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0;
   hipStream_t s = (hipStream_t)stream;
   const long t128 = (long)((p.M + 127) / 128) * ((p.Cout + 127) / 128);
+  static const int force_tile = getenv("RMEM_GEMM_TILE") ? atoi(getenv("RMEM_GEMM_TILE")) : -1;   // kernel experiments only
+  if (force_tile == 0) { launch<64, 64, 4>(p, is1x1, 1, s); return rmem_check_launch("rmem_conv2d_nhwc"); }
+  if (force_tile == 1) { launch<128, 64, 3>(p, is1x1, 1, s); return rmem_check_launch("rmem_conv2d_nhwc"); }
+  if (force_tile == 2) { launch<128, 128, 2>(p, is1x1, 1, s); return rmem_check_launch("rmem_conv2d_nhwc"); }
   if (!use_small_tiles(p.M, p.Cout)) {
     if (p.Cout >= 128 && t128 >= 384) launch<128, 128, 2>(p, is1x1, 1, s);
     else launch<128, 64, 3>(p, is1x1, 1, s);

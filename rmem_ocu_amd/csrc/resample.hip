@@ -142,15 +142,15 @@ __global__ __launch_bounds__(256) void k_label_onehot(const void* lab, int lab_f
 }
 
 // scores[t] = sum_q mass[q][t] * fg[q],  fg = 1 - softmax(bilinear_ac(logits -> enc size))[0]
-// single block (HW ~ 1.7k tokens, T <= 32): deterministic
-__global__ __launch_bounds__(256) void k_evict_scores(const float* lg, int ldl, int nc, int keep, int Hi, int Wi, int He, int We,
-                                                      const float* mass, int T, float* scores) {
+// pass 1: one block per 256 tokens writes a partial score row; pass 2 (one wave) sums the rows in block order
+// (deterministic).  partial is [nblocks][32].
+__global__ __launch_bounds__(256) void k_evict_partial(const float* lg, int ldl, int nc, int keep, int Hi, int Wi, int He, int We,
+                                                       const float* mass, int T, float* partial) {
   __shared__ float red[4][32];
-  float acc[32];
-#pragma unroll
-  for (int t = 0; t < 32; ++t) acc[t] = 0.f;
+  const int q = blockIdx.x * 256 + threadIdx.x;
   const int total = He * We;
-  for (int q = threadIdx.x; q < total; q += 256) {
+  float fg = 0.f;
+  if (q < total) {
     const int oy = q / We, ox = q - oy * We;
     int y0, y1, x0, x1; float wy, wx;
     src_coord(oy, Hi, He, 1, y0, y1, wy);
@@ -159,24 +159,33 @@ __global__ __launch_bounds__(256) void k_evict_scores(const float* lg, int ldl, 
     const float* b = lg + ((long)y0 * Wi + x1) * ldl;
     const float* c = lg + ((long)y1 * Wi + x0) * ldl;
     const float* d = lg + ((long)y1 * Wi + x1) * ldl;
-    float v[16]; float mx = -3.0e38f;
-    for (int ch = 0; ch < nc; ++ch) {
-      float f;
-      if (ch > keep) f = -1.0e10f;
-      else f = (a[ch] * (1.f - wx) + b[ch] * wx) * (1.f - wy) + (c[ch] * (1.f - wx) + d[ch] * wx) * wy;
+    float v0 = 0.f, mx = -3.0e38f, den = 0.f;
+    float v[16];
+#pragma unroll
+    for (int ch = 0; ch < 16; ++ch) {
+      float f = -3.0e38f;
+      if (ch < nc) f = ch > keep ? -1.0e10f : (a[ch] * (1.f - wx) + b[ch] * wx) * (1.f - wy) + (c[ch] * (1.f - wx) + d[ch] * wx) * wy;
       v[ch] = f; mx = fmaxf(mx, f);
     }
-    float den = 0.f;
-    for (int ch = 0; ch < nc; ++ch) den += expf(v[ch] - mx);
-    const float fg = 1.f - expf(v[0] - mx) / den;
-    for (int t = 0; t < T; ++t) acc[t] += mass[(long)q * T + t] * fg;
+    v0 = v[0];
+#pragma unroll
+    for (int ch = 0; ch < 16; ++ch) den += ch < nc ? expf(v[ch] - mx) : 0.f;
+    fg = 1.f - expf(v0 - mx) / den;
   }
   for (int t = 0; t < T; ++t) {
-    const float s = wave_sum(acc[t]);
+    const float s = wave_sum(q < total ? mass[(long)q * T + t] * fg : 0.f);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][t] = s;
   }
   __syncthreads();
-  if (threadIdx.x < T) scores[threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+  if (threadIdx.x < T) partial[blockIdx.x * 32 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+__global__ void k_evict_final(const float* partial, int nblocks, int T, float* scores) {
+  if ((int)threadIdx.x < T) {
+    float s = 0.f;
+    for (int b = 0; b < nblocks; ++b) s += partial[b * 32 + threadIdx.x];
+    scores[threadIdx.x] = s;
+  }
 }
 
 inline unsigned nblk(long total) { return (unsigned)((total + 255) / 256); }
@@ -220,6 +229,11 @@ extern "C" int rmem_label_to_onehot16(const void* label, int label_is_f32, int H
 extern "C" int rmem_evict_scores(const float* logits_nhwc, int ldl, int num_classes, int keep_max_id, int Hi, int Wi, int He, int We,
                                  const float* attn_mass, int T, float* scores, void* stream) {
   RMEM_REQUIRE(logits_nhwc && attn_mass && scores && T >= 1 && T <= 32 && num_classes >= 1 && num_classes <= 16, "rmem_evict_scores: bad argument");
-  hipLaunchKernelGGL(k_evict_scores, dim3(1), dim3(256), 0, (hipStream_t)stream, logits_nhwc, ldl, num_classes, keep_max_id, Hi, Wi, He, We, attn_mass, T, scores);
+  const int nb = (He * We + 255) / 256;
+  RMEM_REQUIRE(nb <= 64, "rmem_evict_scores: more than 16384 tokens");
+  // partial rows live behind the T scores in the caller's buffer: scores must hold 32 + 64 * 32 floats
+  float* partial = scores + 32;
+  hipLaunchKernelGGL(k_evict_partial, dim3(nb), dim3(256), 0, (hipStream_t)stream, logits_nhwc, ldl, num_classes, keep_max_id, Hi, Wi, He, We, attn_mass, T, partial);
+  hipLaunchKernelGGL(k_evict_final, dim3(1), dim3(64), 0, (hipStream_t)stream, partial, nb, T, scores);
   return rmem_check_launch("rmem_evict_scores");
 }

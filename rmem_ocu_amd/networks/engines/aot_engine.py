@@ -179,6 +179,7 @@ class AOTEngine:
             self.img_in.copy_(img.reshape(3, rt.H, rt.W), non_blocking=True)
             self._set_label(mask)
             # (re)initialise the bank to this frame only (aot_engine.py:322; quirk: long_memories_indexes keeps growing, 323)
+            rt.prepare_pos(self._stream())
             rt.reset_bank()
             slot = rt.take_slot()
             rt.slots.append(slot)

@@ -175,6 +175,7 @@ def label_to_onehot16(label, out, *, Hs, Ws, Hd, Wd, ncls=11) -> Op:
 
 def evict_scores(logits, mass, scores, *, ldl, nc, keep, Hi, Wi, He, We, T) -> Op:
     _dev(logits, mass, scores)
+    assert scores.dtype == F32 and scores.numel() >= 32 + 64 * 32
     args = (_ptr(logits), ldl, nc, keep, Hi, Wi, He, We, _ptr(mass), T, _ptr(scores))
     return Op(_lib.lib().rmem_evict_scores, args, 'rmem_evict_scores', (logits, mass, scores))
 

@@ -62,7 +62,11 @@ def pack_state_dict(sd: Dict[str, torch.Tensor], device, num_lstt: int = 3) -> D
         norm(d + '.ln1', s + '.norm1')
         put(d + '.self_qk.w', torch.cat([sd[s + '.self_attn.linear_Q.weight'], sd[s + '.self_attn.linear_K.weight']], 0).float().to(torch.bfloat16))
         put(d + '.self_qk.b', torch.cat([sd[s + '.self_attn.linear_Q.bias'], sd[s + '.self_attn.linear_K.bias']], 0).float())
-        lin(d + '.self_v', s + '.self_attn.linear_V')
+        # Q | K | V in one GEMM: q = k = LN1(x) + pos and v = LN1(x) differ only by pos @ Wqk^T, a per-clip constant
+        put(d + '.self_qkv.w', torch.cat([sd[s + '.self_attn.linear_Q.weight'], sd[s + '.self_attn.linear_K.weight'],
+                                          sd[s + '.self_attn.linear_V.weight']], 0).float().to(torch.bfloat16))
+        put(d + '.self_qkv.b', torch.cat([sd[s + '.self_attn.linear_Q.bias'], sd[s + '.self_attn.linear_K.bias'],
+                                          sd[s + '.self_attn.linear_V.bias']], 0).float())
         lin(d + '.self_proj', s + '.self_attn.projection')
         norm(d + '.ln2', s + '.norm2')
         for nm in ('linear_Q', 'linear_V', 'linear_QMem', 'linear_VMem', 'linear1', 'linear2'):

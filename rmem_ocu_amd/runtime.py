@@ -111,11 +111,14 @@ class ClipRuntime:
         self.id_emb = e(L, D_MODEL)
         self.onehot = e(H * W, 16)
         self.pos = sine_pos_emb(self.H16, self.W16).to(device)
+        # pos @ [Wq; Wk]^T per layer (fp32, V columns zero): the residual operand of the fused self-attention QKV GEMM
+        self.pos_qk = [torch.zeros(L, 3 * D_MODEL, dtype=F32, device=device) for _ in range(num_lstt)]
+        self._pos_ready = False
         self.attn_ws = ops.attn_workspace(L, HEADS, MAX_CHUNKS, device)
         self.gn_ws = ops.groupnorm_workspace(32, device)
         self.conv_ws = torch.empty(16 * L * D_MODEL, dtype=F32, device=device)      # split-K slabs (<= 16 slices of [HW, 256])
         self.mass = torch.zeros(L, MAX_CHUNKS, dtype=F32, device=device)
-        self.scores = torch.zeros(MAX_CHUNKS, dtype=F32, device=device)
+        self.scores = torch.zeros(32 + 64 * 32, dtype=F32, device=device)     # T scores + reduction scratch
         # ---- decoder buffers ----
         self.d16a, self.d16b = e(L, 256), e(L, 256)
         self.d8a, self.d8b = e(M8, 256), e(M8, 256)
@@ -233,6 +236,17 @@ class ClipRuntime:
     def _attn(self, q, ldq, k, v, ldkv, out, **kw):
         return ops.mem_read_attn(q, k, v, out, self.attn_ws, Lq=self.L, heads=HEADS, ldq=ldq, ldkv=ldkv, ldo=D_MODEL, **kw)
 
+    def prepare_pos(self, stream: int):
+        """One-off per runtime: pos_qk[i][:, :512] = bf16(pos) @ [Wq; Wk]^T (no bias; the QKV GEMM adds it)."""
+        if self._pos_ready:
+            return
+        posb = self.pos.to(BF16)
+        for i in range(self.NL):
+            ops.run(ops.linear(posb, self.P[f'l{i}.self_qk.w'], None, self.pos_qk[i], M=self.L, K=D_MODEL, N=2 * D_MODEL,
+                               ldo=3 * D_MODEL), stream)
+        self._keep_posb = posb
+        self._pos_ready = True
+
     def prog_lstt(self, ref_mode: bool, T: int, ref_slot: int = 0) -> list:
         """The 3-layer LSTT on self.x.  ref_mode: reference frame (id_emb already in self.id_emb,
         K/V go straight into bank slot ``ref_slot``); else propagate against a bank of T frames."""
@@ -245,9 +259,8 @@ class ClipRuntime:
         for i in range(self.NL):
             d = f'l{i}'
             # --- self attention (transformer.py:565-571)
-            o.append(ops.layernorm256(self.x, P[d + '.ln1.g'], P[d + '.ln1.b'], M=L, y=self.t1b, pos=self.pos, ypos=self.t1p))
-            o.append(self._lin(self.t1p, d + '.self_qk', self.qkv, L, C, 2 * C, ldo=3 * C))
-            o.append(self._lin(self.t1b, d + '.self_v', self.qkv.view(-1)[2 * C:], L, C, C, ldo=3 * C))
+            o.append(ops.layernorm256(self.x, P[d + '.ln1.g'], P[d + '.ln1.b'], M=L, y=self.t1b))
+            o.append(self._lin(self.t1b, d + '.self_qkv', self.qkv, L, C, 3 * C, residual=self.pos_qk[i]))
             o.append(self._attn(self.qkv, 3 * C, self.qkv.view(-1)[C:], self.qkv.view(-1)[2 * C:], 3 * C, self.att,
                                 nchunks=4, lk_single=L))
             o.append(self._lin(self.att, d + '.self_proj', self.x, L, C, C, residual=self.x))

@@ -313,7 +313,7 @@ def test_evict_scores(dev):
     mass = seeded(96, (7 * 9, 5)).abs()
     fg = 1 - torch.softmax(F.interpolate(lg, size=(7, 9), mode='bilinear', align_corners=True), 1)[0, 0].flatten()
     ref = (mass * fg[:, None]).sum(0)
-    sc = torch.zeros(32, dtype=F32, device=dev)
+    sc = torch.zeros(32 + 64 * 32, dtype=F32, device=dev)
     ops.run(ops.evict_scores(lgn.to(dev), mass.to(dev), sc, ldl=16, nc=11, keep=10, Hi=25, Wi=33, He=7, We=9, T=5))
     torch.cuda.synchronize()
     assert_close(sc[:5], ref, 1e-4, 'evict scores')
