@@ -141,6 +141,7 @@ class AOTEngine:
         """Enqueue a launch list on the engine's stream: directly, or (use_graphs) as ONE hipGraph per key."""
         s = self._stream()
         if self.use_graphs:
+            key = f'{key}@{self.rt.bank_generation}'
             g = self._graphs.get(key)
             if g is None:
                 ops.run(prog, s)               # warm run (first-touch, lazy module load) outside capture

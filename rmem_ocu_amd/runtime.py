@@ -129,6 +129,7 @@ class ClipRuntime:
         self.chunks_host = torch.zeros(8, MAX_CHUNKS, 8, dtype=torch.int32).pin_memory()
         self._chunk_stage = 0
         self.scores_host = torch.zeros(MAX_CHUNKS, dtype=F32).pin_memory()
+        self.bank_generation = 0             # bumped when the bank is re-allocated: launch lists / graphs built on it are stale
         self._alloc_bank(bank_slots)
         self._prog: Dict[str, list] = {}
 
@@ -155,6 +156,7 @@ class ClipRuntime:
             self.bank_V[i][:old_S].copy_(old_V[i])
         self.free += list(range(old_S, new_S))
         self.S = new_S
+        self.bank_generation += 1
         self._prog = {k: v for k, v in self._prog.items() if not k.startswith(('lstt', 'update'))}
 
     def take_slot(self) -> int:

@@ -158,7 +158,14 @@ def gen_ops(model):
     return out
 
 
-def run_ref_clip(cfg, model, build_engine, frames, first_mask, out_hw, gap, sample_px):
+def new_object_label(out_hw, obj_id):
+    """Synthetic 'new object appears' annotation at the OUTPUT size (stand-in for a YouTube-VOS mid-clip label)."""
+    lab = torch.zeros(1, 1, out_hw[0], out_hw[1])
+    lab[:, :, out_hw[0] // 2:out_hw[0] // 2 + out_hw[0] // 4, out_hw[1] // 8:out_hw[1] // 8 + out_hw[1] // 5] = obj_id
+    return lab
+
+
+def run_ref_clip(cfg, model, build_engine, frames, first_mask, out_hw, gap, sample_px, inject_at=-1):
     """Drives the reference engine exactly as evaluator.py:385-441, 509-523 does."""
     engine = build_engine(cfg.MODEL_ENGINE, phase='eval', aot_model=model, gpu_id=0, long_term_mem_gap=gap)
     engine.eval()
@@ -172,7 +179,14 @@ def run_ref_clip(cfg, model, build_engine, frames, first_mask, out_hw, gap, samp
             logit = engine.match_propogate_one_frame(frames[i:i + 1], output_size=out_hw)
             prob = torch.softmax(logit, dim=1)
             label = torch.argmax(prob, dim=1, keepdim=True).float()
-            engine.update_memory(F.interpolate(label, size=engine.input_size_2d, mode='nearest'))
+            if i == inject_at:      # evaluator.py:484-508: a new object's annotation arrives on this frame
+                new = new_object_label(out_hw, int(first_mask.max()) + 1)
+                keep = (new == 0).float()
+                label = label * keep + new * (1 - keep)
+                engine.add_reference_frame(frames[i:i + 1], F.interpolate(label, size=engine.input_size_2d, mode='nearest'),
+                                           obj_nums=[int(label.max().item())], frame_step=i)
+            else:
+                engine.update_memory(F.interpolate(label, size=engine.input_size_2d, mode='nearest'))
             labels.append(label[0, 0].to(torch.uint8).numpy())
             idx_trace.append(list(engine.aot_engines[0].long_memories_indexes))
             logit_samples.append(logit[0][:, sample_px[0], sample_px[1]].numpy().copy())
@@ -186,16 +200,18 @@ def pack_trace(trace, width):
     return arr
 
 
-def gen_clip(tag, former, latter, n_frames, h, w, out_hw, gap, objs, seed):
+def gen_clip(tag, former, latter, n_frames, h, w, out_hw, gap, objs, seed, inject_at=-1):
     cfg, model, build_engine = load_reference(former, latter)
     frames, mask = make_clip(seed, n_frames, h, w, objs)
     ys = np.linspace(2, out_hw[0] - 3, 12).astype(np.int64)
     xs = np.linspace(2, out_hw[1] - 3, 12).astype(np.int64)
-    labels, trace, samples = run_ref_clip(cfg, model, build_engine, frames, mask, out_hw, gap, (ys, xs))
+    labels, trace, samples = run_ref_clip(cfg, model, build_engine, frames, mask, out_hw, gap, (ys, xs), inject_at)
+    width = max(len(t) for t in trace)
     return {
         'meta': np.array([former, latter, n_frames, h, w, out_hw[0], out_hw[1], gap, objs, seed], dtype=np.int64),
+        'inject_at': np.array(inject_at),
         'frames_sha': np.array(sha(frames)), 'mask_sha': np.array(sha(mask)),
-        'labels': labels, 'indexes': pack_trace(trace, former + latter + 1),
+        'labels': labels, 'indexes': pack_trace(trace, width),
         'sample_y': ys, 'sample_x': xs, 'logit_samples': samples,
     }
 
@@ -210,6 +226,18 @@ if __name__ == '__main__':
         # 161x193 -> 11x13 tokens; bank of 3 with gap 2 so ~20 evictions happen in 48 frames
         np.savez_compressed(os.path.join(HERE, 'clip_small.npz'),
                             **gen_clip('small', 1, 2, 48, 161, 193, (160, 192), 2, 3, 11))
+    if what in ('newobj', 'all'):
+        # cfg-3 protocol: a new object's mask arrives at frame 15 -> the engine re-adds a reference frame mid-clip
+        # (bank re-initialised to one entry while long_memories_indexes keeps growing, aot_engine.py:322-323).
+        # N = 8, 30 frames, gap 2: the bank never exceeds 8 entries.  NB with a smaller bank the REFERENCE raises at the
+        # first eviction after the injection (layers/transformer.py:401: attn_weight has T' entries, frame_times has
+        # len(long_memories_indexes) - 1 > T'), observed here with N = 4, 36 frames.
+        np.savez_compressed(os.path.join(HERE, 'clip_newobj.npz'),
+                            **gen_clip('newobj', 1, 7, 30, 161, 193, (160, 192), 2, 2, 31, inject_at=15))
+    if what in ('unbounded', 'all'):
+        # cfg-4 protocol: unbounded memory (latter_mem_len = 9999, tools/eval.py:92): the bank grows to 20 entries
+        np.savez_compressed(os.path.join(HERE, 'clip_unbounded.npz'),
+                            **gen_clip('unbounded', 1, 9999, 40, 161, 193, (160, 192), 2, 2, 41))
     if what in ('full', 'all'):
         # cfg-2 geometry: 480x854 video at network size 481x849, bank N = 8, gap 2 so the bank fills
         # by frame 14 and evicts from frame 16

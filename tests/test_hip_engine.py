@@ -29,7 +29,7 @@ def _load(name):
     former, latter, n, h, w, oh, ow, gap, objs, seed = g['meta'].tolist()
     frames, mask = make_clip(seed, n, h, w, objs)
     assert hashlib.sha256(frames.numpy().tobytes()).hexdigest() == str(g['frames_sha'])
-    return g, frames, mask, (former, latter, n, h, w, oh, ow, gap)
+    return g, frames, mask, (former, latter, n, h, w, oh, ow, gap, objs)
 
 
 def _engine(former, latter, gap):
@@ -45,7 +45,8 @@ def _engine(former, latter, gap):
 
 
 def _run(name, teacher_forced, use_graphs=False):
-    g, frames, mask, (former, latter, n, h, w, oh, ow, gap) = _load(name)
+    g, frames, mask, (former, latter, n, h, w, oh, ow, gap, objs) = _load(name)
+    inject_at = int(g['inject_at']) if 'inject_at' in g.files else -1
     eng = _engine(former, latter, gap)
     eng.use_graphs = use_graphs
     dev = torch.device('cuda', 0)
@@ -58,7 +59,16 @@ def _run(name, teacher_forced, use_graphs=False):
         prob = torch.softmax(logit, dim=1)
         label = torch.argmax(prob, dim=1, keepdim=True).float()
         fed = torch.from_numpy(g['labels'][i - 1].astype(np.float32)).to(dev)[None, None] if teacher_forced else label
-        eng.update_memory(F.interpolate(fed, size=eng.input_size_2d, mode='nearest'))
+        if i == inject_at:        # evaluator.py:484-508 (the golden label of this frame already contains the new object)
+            if not teacher_forced:
+                new = torch.zeros(1, 1, oh, ow, device=dev)
+                new[:, :, oh // 2:oh // 2 + oh // 4, ow // 8:ow // 8 + ow // 5] = objs + 1
+                fed = label * (new == 0).float() + new
+            eng.add_reference_frame(frames_d[i:i + 1], F.interpolate(fed, size=eng.input_size_2d, mode='nearest'),
+                                    obj_nums=[int(fed.max().item())], frame_step=i)
+            label = fed
+        else:
+            eng.update_memory(F.interpolate(fed, size=eng.input_size_2d, mode='nearest'))
         labels.append(label[0, 0].to(torch.uint8).cpu().numpy())
         samples.append(logit[0][:, ys, xs].cpu().numpy())
         trace.append(list(eng.long_memories_indexes))
@@ -109,5 +119,25 @@ def test_full_clip_cfg2_geometry():
     ref = g['logit_samples']
     err = np.abs(samples - ref).max()
     print('full clip teacher-forced: max |dlogit| =', err, ' logit std =', ref.std(), ' agreement =', (labels == g['labels']).mean())
+    assert err < 0.08 * ref.std() + 0.05
+    assert (_trace_matrix(trace, g['indexes']) == g['indexes']).all()
+
+
+def test_new_object_injection_clip():
+    """cfg-3 protocol (quirk 2): mid-clip add_reference_frame re-initialises the bank, indexes keep growing."""
+    g, labels, samples, trace = _run('clip_newobj.npz', True)
+    ref = g['logit_samples']
+    err = np.abs(samples - ref).max()
+    print('new-object clip: max |dlogit| =', err, ' agreement =', (labels == g['labels']).mean())
+    assert err < 0.08 * ref.std() + 0.05
+    assert (_trace_matrix(trace, g['indexes']) == g['indexes']).all()
+
+
+def test_unbounded_memory_clip():
+    """cfg-4 protocol: the bank grows past its initial ring (grow_bank), T up to 20, chunk table of 20 frames."""
+    g, labels, samples, trace = _run('clip_unbounded.npz', True, use_graphs=True)
+    ref = g['logit_samples']
+    err = np.abs(samples - ref).max()
+    print('unbounded clip: max |dlogit| =', err, ' agreement =', (labels == g['labels']).mean())
     assert err < 0.08 * ref.std() + 0.05
     assert (_trace_matrix(trace, g['indexes']) == g['indexes']).all()

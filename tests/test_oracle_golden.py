@@ -105,10 +105,18 @@ def _run_clip(name):
     eng.long_term_mem_gap = gap
     eng.add_reference_frame(frames[0:1], mask, 0)
     ys, xs = g['sample_y'], g['sample_x']
+    inject_at = int(g['inject_at']) if 'inject_at' in g.files else -1
     for i in range(1, n):
         logit = eng.match_propogate_one_frame(frames[i:i + 1], (oh, ow))
         label = torch.argmax(torch.softmax(logit, 1), 1, keepdim=True).float()
-        eng.update_memory(torch.nn.functional.interpolate(label, size=eng.input_size_2d, mode='nearest'))
+        if i == inject_at:        # evaluator.py:484-508
+            new = torch.zeros(1, 1, oh, ow)
+            new[:, :, oh // 2:oh // 2 + oh // 4, ow // 8:ow // 8 + ow // 5] = objs + 1
+            keep = (new == 0).float()
+            label = label * keep + new * (1 - keep)
+            eng.add_reference_frame(frames[i:i + 1], torch.nn.functional.interpolate(label, size=eng.input_size_2d, mode='nearest'), i)
+        else:
+            eng.update_memory(torch.nn.functional.interpolate(label, size=eng.input_size_2d, mode='nearest'))
         labels.append(label[0, 0].to(torch.uint8).numpy())
         trace.append(list(eng.long_memories_indexes))
         samples.append(logit[0][:, ys, xs].numpy())
@@ -125,3 +133,41 @@ def test_small_clip_matches_reference():
     assert (got == g['indexes']).all()
     assert np.abs(samples - g['logit_samples']).max() < 1e-3
     assert (labels == g['labels']).mean() > 0.9999
+
+
+def _check_clip(name):
+    g, labels, trace, samples = _run_clip(name)
+    got = -np.ones_like(g['indexes'])
+    for i, t in enumerate(trace):
+        got[i, :len(t)] = t
+    assert (got == g['indexes']).all()
+    assert np.abs(samples - g['logit_samples']).max() < 1e-3
+    assert (labels == g['labels']).mean() > 0.9999
+
+
+def test_new_object_clip_matches_reference():
+    """cfg-3 protocol: a new object is injected at frame 15 (mid-clip add_reference_frame, quirk 2)."""
+    _check_clip('clip_newobj.npz')
+
+
+def test_unbounded_memory_clip_matches_reference():
+    """cfg-4 protocol: latter_mem_len = 9999, the bank grows to 20 entries (temporal-PE slots for T > 4)."""
+    _check_clip('clip_unbounded.npz')
+
+
+def test_restricted_bank_after_injection_raises_like_the_reference():
+    """With a small bank the reference raises at the first eviction after a mid-clip reference frame
+    (layers/transformer.py:401); the restatement reproduces the failure instead of inventing a behaviour."""
+    from rmem_ocu_amd.weights import synth_state_dict
+    frames, mask = make_clip(31, 12, 97, 129, 2)
+    eng = O.OracleEngine(synth_state_dict(0), 1, 1, 1)
+    eng.add_reference_frame(frames[0:1], mask, 0)
+    with pytest.raises(RuntimeError):
+        for i in range(1, 12):
+            logit = eng.match_propogate_one_frame(frames[i:i + 1], (96, 128))
+            label = torch.argmax(logit, 1, keepdim=True).float()
+            m = torch.nn.functional.interpolate(label, size=eng.input_size_2d, mode='nearest')
+            if i == 4:
+                eng.add_reference_frame(frames[i:i + 1], m, i)
+            else:
+                eng.update_memory(m)
