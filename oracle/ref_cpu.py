@@ -412,6 +412,57 @@ class OracleEngine:
         del self.long_memories_indexes[drop]
 
 
+class OracleInferEngine:
+    """AOTInferEngine (aot_engine.py:571-725): one OracleEngine per 10 objects, label masks split per engine
+    (604-618), logits merged by soft aggregation (650-673)."""
+
+    def __init__(self, weights: W, former_len=1, latter_len=7, long_term_mem_gap=5, max_aot_obj_num=MAX_OBJ):
+        self.args = (weights, former_len, latter_len, long_term_mem_gap)
+        self.max_aot_obj_num = max_aot_obj_num
+        self.engines: List[OracleEngine] = []
+
+    def separate_mask(self, mask):
+        if len(self.engines) == 1:
+            return [mask]
+        out = []
+        for idx in range(len(self.engines)):
+            start_id = idx * self.max_aot_obj_num + 1
+            end_id = (idx + 1) * self.max_aot_obj_num
+            fg = ((mask >= start_id) & (mask <= end_id)).float()
+            out.append((fg * mask - start_id + 1) * fg)
+        return out
+
+    def soft_logit_aggregation(self, all_logits):
+        if len(all_logits) == 1:
+            return all_logits[0]
+        fg, bg = [], []
+        for logit in all_logits:
+            prob = torch.softmax(logit, dim=1)
+            bg.append(prob[:, 0:1])
+            fg.append(prob[:, 1:1 + self.max_aot_obj_num])
+        bg_prob = torch.prod(torch.cat(bg, dim=1), dim=1, keepdim=True)
+        return torch.logit(torch.cat([bg_prob] + fg, dim=1).clamp(1e-5, 1 - 1e-5))
+
+    def add_reference_frame(self, img, mask, obj_nums, frame_step=0):
+        n = max(int(np.ceil(obj_nums / self.max_aot_obj_num)), 1)
+        while len(self.engines) < n:
+            self.engines.append(OracleEngine(*self.args))
+        for e, m in zip(self.engines, self.separate_mask(mask)):
+            e.add_reference_frame(img, m, frame_step)
+        self.input_size_2d = self.engines[0].input_size_2d
+
+    def match_propogate_one_frame(self, img, output_size=None):
+        return self.soft_logit_aggregation([e.match_propogate_one_frame(img, output_size) for e in self.engines])
+
+    def update_memory(self, mask):
+        for e, m in zip(self.engines, self.separate_mask(mask)):
+            e.update_memory(m)
+
+    @property
+    def long_memories_indexes(self):
+        return self.engines[0].long_memories_indexes
+
+
 def run_clip(engine: OracleEngine, frames: Sequence[Tensor], first_mask: Tensor, output_size: Tuple[int, int],
              gap: Optional[int] = None):
     """The evaluator's per-frame protocol (evaluator.py:330-335, 385-441, 509-523) for one clip.

@@ -238,6 +238,9 @@ if __name__ == '__main__':
         # cfg-4 protocol: unbounded memory (latter_mem_len = 9999, tools/eval.py:92): the bank grows to 20 entries
         np.savez_compressed(os.path.join(HERE, 'clip_unbounded.npz'),
                             **gen_clip('unbounded', 1, 9999, 40, 161, 193, (160, 192), 2, 2, 41))
+    # NB no fixture for > 10 objects: the reference keeps the clip's LSTT memory inside the shared model
+    # (layers/transformer.py:455-463), so its second AOTEngine (objects 11..) overwrites the first one's bank and the run
+    # raises at the first eviction (transformer.py:401) -- observed here with 12 objects, 14 frames, bank 1+2.
     if what in ('full', 'all'):
         # cfg-2 geometry: 480x854 video at network size 481x849, bank N = 8, gap 2 so the bank fills
         # by frame 14 and evicts from frame 16

@@ -141,3 +141,35 @@ def test_unbounded_memory_clip():
     print('unbounded clip: max |dlogit| =', err, ' agreement =', (labels == g['labels']).mean())
     assert err < 0.08 * ref.std() + 0.05
     assert (_trace_matrix(trace, g['indexes']) == g['indexes']).all()
+
+
+def test_more_than_ten_objects_vs_oracle():
+    """12 objects -> two engines (separate_mask + soft_logit_aggregation, aot_engine.py:604-673).  The reference itself
+    cannot run this case (its engines share one LSTT memory and it raises at the first eviction), so the checker is the
+    oracle's per-engine-state restatement: parity for this row is NOT pinned by a reference fixture."""
+    from oracle import ref_cpu as O
+    from rmem_ocu_amd.synth import make_clip
+    from rmem_ocu_amd.weights import synth_state_dict
+    frames, mask = make_clip(51, 8, 161, 193, 12)
+    assert int(mask.max()) == 12
+    dev = torch.device('cuda', 0)
+    eng = _engine(1, 2, 2)
+    ora = O.OracleInferEngine(synth_state_dict(0), 1, 2, 2)
+    eng.add_reference_frame(frames[0:1].to(dev), mask.to(dev), obj_nums=[12], frame_step=0)
+    ora.add_reference_frame(frames[0:1], mask, 12, 0)
+    assert len(eng.aot_engines) == 2
+    worst, agree = 0.0, []
+    for i in range(1, 8):
+        got = eng.match_propogate_one_frame(frames[i:i + 1].to(dev), output_size=(160, 192)).cpu()
+        ref = ora.match_propogate_one_frame(frames[i:i + 1], (160, 192))
+        assert got.shape == ref.shape == (1, 21, 160, 192)
+        pg, pr = torch.softmax(got, 1), torch.softmax(ref, 1)
+        worst = max(worst, (pg - pr).abs().max().item())
+        label = torch.argmax(pr, dim=1, keepdim=True).float()
+        agree.append((pg - pr).abs().mean().item())       # 21 near-tied classes with synthetic weights: compare probabilities, not argmax
+        m = F.interpolate(label, size=(161, 193), mode='nearest')
+        eng.update_memory(m.to(dev))
+        ora.update_memory(m)
+    print('12 objects: max |dprob| =', worst, ' mean |dprob| =', np.mean(agree), '(uniform = %.3f)' % (1 / 21))
+    assert worst < 0.01 and np.mean(agree) < 0.001
+    assert eng.long_memories_indexes == ora.long_memories_indexes
