@@ -93,7 +93,8 @@ int rmem_mem_read_attn(const void* q, int ldq,                     /* bf16 [Lq][
 
 /* Optional timing of the memory-read launches (chunks != NULL) with HIP events on the launch stream:
  * between start and stop every such launch outside a graph capture is bracketed by two events;
- * stop() synchronises on them and returns the summed kernel time, the summed algorithmic FLOPs
+ * start() also calibrates what an event bracket costs around an empty kernel and stop() subtracts that per launch;
+ * stop() synchronises on the events and returns the summed kernel time, the summed algorithmic FLOPs
  * (4 * Lq * keys * C per launch) and the launch count.  Used by bench.py's roofline leg. */
 int rmem_profile_start(int max_launches);
 int rmem_profile_stop(double* total_ms, double* total_flops, int* launches);

@@ -67,7 +67,9 @@ __device__ __forceinline__ float pair_max(float x) {
 // RESCALE_THR (or on the first tile) is m_ref moved and O / l rescaled -- a wave-uniform, rare branch.
 // The row sums l come from the matrix pipe too (a ones A-operand against the same P^T fragments), which
 // leaves max + exp2 + bf16 packing as the only per-score VALU work (the d = 32 bottleneck).
-template <bool MEM>
+// TIMED changes nothing but the symbol: launches bracketed by rmem_profile_* HIP events use the <true, true> instance, so
+// a kernel trace of the same run lists exactly the launches bench.py timed under their own name.
+template <bool MEM, bool TIMED = false>
 __global__ __launch_bounds__(256) void k_attn_partial(AttnParams p) {
   __shared__ __attribute__((aligned(16))) bf16 Ks[2][KT * D];   // [key][32], 16-byte chunks XOR-swizzled
   __shared__ __attribute__((aligned(16))) bf16 Vs[2][KT * D];   // [key][32] row-major, read transposed (ds_read_b64_tr_b16)
@@ -299,9 +301,12 @@ __global__ __launch_bounds__(256) void k_attn_mass(CombineParams p) {
 }
 
 // ---- optional launch timing of the memory-read kernel (bench.py's roofline leg) ----
+__global__ void k_prof_nop() {}
+
 struct ProfState {
   std::mutex mu;
   bool on = false;
+  float bracket_ms = 0.f;       // HIP-event bracket cost around an empty kernel (calibrated in rmem_profile_start)
   std::vector<hipEvent_t> ev;   // pairs
   std::vector<double> flops;
   size_t used = 0;
@@ -320,6 +325,24 @@ extern "C" int rmem_profile_start(int max_launches) {
   }
   g_prof.flops.assign(max_launches, 0.0);
   g_prof.used = 0;
+  // calibrate what two event records around ONE launch cost by themselves: bracket an empty kernel on an idle stream,
+  // keep the minimum of 32 trials; rmem_profile_stop subtracts it from every timed launch
+  {
+    hipStream_t cs;
+    if (hipStreamCreate(&cs) == hipSuccess) {
+      float best = 1e9f;
+      for (int i = 0; i < 32; ++i) {
+        (void)hipEventRecord(g_prof.ev[0], cs);
+        hipLaunchKernelGGL(k_prof_nop, dim3(1), dim3(64), 0, cs);
+        (void)hipEventRecord(g_prof.ev[1], cs);
+        (void)hipEventSynchronize(g_prof.ev[1]);
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, g_prof.ev[0], g_prof.ev[1]) == hipSuccess && t < best) best = t;
+      }
+      (void)hipStreamDestroy(cs);
+      g_prof.bracket_ms = best < 1e8f ? best : 0.f;
+    }
+  }
   g_prof.on = true;
   return 0;
 }
@@ -334,7 +357,7 @@ extern "C" int rmem_profile_stop(double* total_ms, double* total_flops, int* lau
       rmem_set_error("rmem_profile_stop: event query failed");
       return -3;
     }
-    ms += t;
+    ms += fmaxf(t - g_prof.bracket_ms, 0.f);
     fl += g_prof.flops[i];
   }
   if (total_ms) *total_ms = ms;
@@ -384,13 +407,14 @@ extern "C" int rmem_mem_read_attn(const void* q, int ldq, const void* k_bank, co
       }
     }
     if (slot_i >= 0) (void)hipEventRecord(g_prof.ev[2 * slot_i], s);
-    hipLaunchKernelGGL(k_attn_partial<true>, grid, dim3(256), 0, s, p);
+    if (slot_i >= 0) hipLaunchKernelGGL((k_attn_partial<true, true>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((k_attn_partial<true, false>), grid, dim3(256), 0, s, p);
     if (slot_i >= 0) {
       (void)hipEventRecord(g_prof.ev[2 * slot_i + 1], s);
       g_prof.flops[slot_i] = 4.0 * (double)Lq * keys * (double)(heads * D);   // QK^T + PV
     }
   } else {
-    hipLaunchKernelGGL(k_attn_partial<false>, grid, dim3(256), 0, s, p);
+    hipLaunchKernelGGL((k_attn_partial<false, false>), grid, dim3(256), 0, s, p);
   }
   CombineParams cp;
   cp.opart = p.opart; cp.ml = p.ml; cp.chunks = chunks; cp.nchunks = nchunks; cp.Lq = Lq; cp.heads = heads;

@@ -55,3 +55,31 @@ def make_clip(seed: int, num_frames: int, h: int, w: int, num_objs: int = 3):
         y0, x0 = int(rng.integers(0, h - rh)), int(rng.integers(0, w - rw))
         mask[y0:y0 + rh, x0:x0 + rw] = k
     return frames, torch.from_numpy(mask)[None, None]
+
+
+def clip_masks(seed: int, num_frames: int, h: int, w: int, num_objs: int = 3) -> torch.Tensor:
+    """Ground-truth label maps [n, h, w] (int64) of make_clip(seed, ...): the rectangles are anchored to the drifting
+    texture, so frame i shows them shifted by -(offset_i - offset_0).  Replays make_clip's random stream exactly."""
+    rng = np.random.Generator(np.random.PCG64([seed, 0x5EED]))
+    drift = rng.integers(2, 4, size=(num_frames, 2))
+    sign = rng.choice([-1, 1], size=2)
+    off = np.cumsum(drift * sign, axis=0)
+    off -= off.min(axis=0)
+    ch, cw = h + int(off[:, 0].max()), w + int(off[:, 1].max())
+    rng.standard_normal((1, 3, ch // 8 + 2, cw // 8 + 2))
+    for _ in range(num_frames):
+        rng.standard_normal((3, h, w))
+    rects = []
+    for k in range(1, num_objs + 1):
+        rh, rw = int(h * rng.uniform(0.15, 0.35)), int(w * rng.uniform(0.12, 0.3))
+        y0, x0 = int(rng.integers(0, h - rh)), int(rng.integers(0, w - rw))
+        rects.append((k, y0, x0, rh, rw))
+    out = torch.zeros(num_frames, h, w, dtype=torch.int64)
+    for i in range(num_frames):
+        dy, dx = int(off[i, 0] - off[0, 0]), int(off[i, 1] - off[0, 1])
+        for k, y0, x0, rh, rw in rects:
+            ya, xa = max(y0 - dy, 0), max(x0 - dx, 0)
+            yb, xb = min(y0 - dy + rh, h), min(x0 - dx + rw, w)
+            if yb > ya and xb > xa:
+                out[i, ya:yb, xa:xb] = k
+    return out
