@@ -73,9 +73,107 @@ def resnet50(img: Tensor, w: W) -> List[Tensor]:
     return outs
 
 
+# --- Swin-B encoder (cfg 5): encoders/swin/swin_transformer.py, last stage dropped (571) ---------------------
+SWIN_DEPTHS, SWIN_HEADS, SWIN_WS = (2, 2, 18), (4, 8, 16), 7       # encoders/swin/build.py:11-22
+
+
+def _win_part(x: Tensor, ws: int) -> Tensor:
+    """swin_transformer.py:65-79: [B,H,W,C] -> [nW*B, ws*ws, C]."""
+    B, H, Wd, C = x.shape
+    return x.view(B, H // ws, ws, Wd // ws, ws, C).permute(0, 1, 3, 2, 4, 5).reshape(-1, ws * ws, C)
+
+
+def _win_rev(wins: Tensor, ws: int, H: int, Wd: int) -> Tensor:
+    """swin_transformer.py:82-97."""
+    B = wins.shape[0] // ((H // ws) * (Wd // ws))
+    return wins.view(B, H // ws, Wd // ws, ws, ws, -1).permute(0, 1, 3, 2, 4, 5).reshape(B, H, Wd, -1)
+
+
+def swin_shift_mask(H: int, Wd: int, ws: int = SWIN_WS) -> Tensor:
+    """Attention mask of the shifted windows (swin_transformer.py:432-451): [nW, ws*ws, ws*ws], 0 or -100."""
+    sh = ws // 2
+    Hp, Wp = -(-H // ws) * ws, -(-Wd // ws) * ws
+    img = torch.zeros(1, Hp, Wp, 1)
+    cnt = 0
+    for hs in (slice(0, -ws), slice(-ws, -sh), slice(-sh, None)):
+        for wsl in (slice(0, -ws), slice(-ws, -sh), slice(-sh, None)):
+            img[:, hs, wsl, :] = cnt
+            cnt += 1
+    mw = _win_part(img, ws).view(-1, ws * ws)
+    m = mw.unsqueeze(1) - mw.unsqueeze(2)
+    return m.masked_fill(m != 0, -100.0).masked_fill(m == 0, 0.0)
+
+
+def swin_block(x: Tensor, H: int, Wd: int, w: W, p: str, heads: int, shift: int, mask: Optional[Tensor]) -> Tensor:
+    """swin_transformer.py:249-320 (SwinTransformerBlock.forward) with WindowAttention.forward (156-195)."""
+    ws = SWIN_WS
+    B, L, C = x.shape
+    y = F.layer_norm(x, (C,), w[p + '.norm1.weight'], w[p + '.norm1.bias'], 1e-5).view(B, H, Wd, C)
+    pr, pb = (ws - Wd % ws) % ws, (ws - H % ws) % ws
+    y = F.pad(y, (0, 0, 0, pr, 0, pb))                 # zero tokens AFTER the norm: their q/k/v are the qkv bias
+    Hp, Wp = y.shape[1], y.shape[2]
+    if shift > 0:
+        y = torch.roll(y, shifts=(-shift, -shift), dims=(1, 2))
+    xw = _win_part(y, ws)
+    B_, N, _ = xw.shape
+    qkv = F.linear(xw, w[p + '.attn.qkv.weight'], w[p + '.attn.qkv.bias']).reshape(B_, N, 3, heads, C // heads).permute(2, 0, 3, 1, 4)
+    q, k, v = qkv[0] * (C // heads) ** -0.5, qkv[1], qkv[2]
+    attn = q @ k.transpose(-2, -1)
+    bias = w[p + '.attn.relative_position_bias_table'][w[p + '.attn.relative_position_index'].view(-1)].view(N, N, -1)
+    attn = attn + bias.permute(2, 0, 1).unsqueeze(0)
+    if shift > 0:
+        nW = mask.shape[0]
+        attn = (attn.view(B_ // nW, nW, heads, N, N) + mask.unsqueeze(1).unsqueeze(0)).view(-1, heads, N, N)
+    attn = torch.softmax(attn, dim=-1)
+    o = F.linear((attn @ v).transpose(1, 2).reshape(B_, N, C), w[p + '.attn.proj.weight'], w[p + '.attn.proj.bias'])
+    y = _win_rev(o, ws, Hp, Wp)
+    if shift > 0:
+        y = torch.roll(y, shifts=(shift, shift), dims=(1, 2))
+    x = x + y[:, :H, :Wd, :].reshape(B, H * Wd, C)
+    h = F.layer_norm(x, (C,), w[p + '.norm2.weight'], w[p + '.norm2.bias'], 1e-5)
+    h = F.linear(F.gelu(F.linear(h, w[p + '.mlp.fc1.weight'], w[p + '.mlp.fc1.bias'])), w[p + '.mlp.fc2.weight'], w[p + '.mlp.fc2.bias'])
+    return x + h
+
+
+def swin_patch_merge(x: Tensor, H: int, Wd: int, w: W, p: str) -> Tensor:
+    """swin_transformer.py:336-356 (PatchMerging.forward)."""
+    B, L, C = x.shape
+    x = x.view(B, H, Wd, C)
+    if H % 2 or Wd % 2:
+        x = F.pad(x, (0, 0, 0, Wd % 2, 0, H % 2))
+    x = torch.cat([x[:, 0::2, 0::2], x[:, 1::2, 0::2], x[:, 0::2, 1::2], x[:, 1::2, 1::2]], -1).view(B, -1, 4 * C)
+    x = F.layer_norm(x, (4 * C,), w[p + '.norm.weight'], w[p + '.norm.bias'], 1e-5)
+    return F.linear(x, w[p + '.reduction.weight'])
+
+
+def swin_base(img: Tensor, w: W) -> List[Tensor]:
+    """swin_transformer.py:684-716 -> [4x (128 ch), 8x (256), 16x (512)] NCHW."""
+    _, _, H, Wd = img.shape
+    if Wd % 4:
+        img = F.pad(img, (0, 4 - Wd % 4))
+    if H % 4:
+        img = F.pad(img, (0, 0, 0, 4 - H % 4))
+    x = F.conv2d(img, w['encoder.patch_embed.proj.weight'], w['encoder.patch_embed.proj.bias'], stride=4)
+    Wh, Ww = x.shape[2], x.shape[3]
+    x = x.flatten(2).transpose(1, 2)
+    x = F.layer_norm(x, (x.shape[-1],), w['encoder.patch_embed.norm.weight'], w['encoder.patch_embed.norm.bias'], 1e-5)
+    outs = []
+    for li, (depth, heads) in enumerate(zip(SWIN_DEPTHS, SWIN_HEADS)):
+        mask = swin_shift_mask(Wh, Ww)
+        for b in range(depth):
+            x = swin_block(x, Wh, Ww, w, f'encoder.layers.{li}.blocks.{b}', heads, 0 if b % 2 == 0 else SWIN_WS // 2, mask)
+        C = x.shape[-1]
+        o = F.layer_norm(x, (C,), w[f'encoder.norm{li}.weight'], w[f'encoder.norm{li}.bias'], 1e-5)
+        outs.append(o.view(-1, Wh, Ww, C).permute(0, 3, 1, 2).contiguous())
+        if li < len(SWIN_DEPTHS) - 1:
+            x = swin_patch_merge(x, Wh, Ww, w, f'encoder.layers.{li}.downsample')
+            Wh, Ww = (Wh + 1) // 2, (Ww + 1) // 2
+    return outs
+
+
 def encode_image(img: Tensor, w: W) -> List[Tensor]:
     """aot.py:116-134: [4x, 8x, 16x, proj(16x)]."""
-    xs = resnet50(img, w)
+    xs = swin_base(img, w) if 'encoder.patch_embed.proj.weight' in w else resnet50(img, w)
     xs.append(F.conv2d(xs[-1], w['encoder_projector.weight'], w['encoder_projector.bias']))
     return xs
 

@@ -63,19 +63,63 @@ def _norm(sd, seed, prefix, ch):
     sd[prefix + '.bias'] = _normal(seed, prefix + '.bias', (ch,), 0.02)
 
 
+SWIN_B = dict(embed_dim=128, depths=(2, 2, 18), heads=(4, 8, 16), window=7)   # encoders/swin/build.py:11-22, last stage dropped
+
+
+def swin_relative_position_index(ws: int = 7) -> torch.Tensor:
+    """encoders/swin/swin_transformer.py:128-144: index into the (2w-1)^2 bias table for every token pair of a window."""
+    coords = torch.stack(torch.meshgrid([torch.arange(ws), torch.arange(ws)], indexing='ij')).flatten(1)
+    rel = (coords[:, :, None] - coords[:, None, :]).permute(1, 2, 0).contiguous()
+    rel[:, :, 0] += ws - 1
+    rel[:, :, 1] += ws - 1
+    rel[:, :, 0] *= 2 * ws - 1
+    return rel.sum(-1)
+
+
+def _swin_encoder(sd, seed):
+    e, depths, heads, ws = SWIN_B['embed_dim'], SWIN_B['depths'], SWIN_B['heads'], SWIN_B['window']
+    _conv(sd, seed, 'encoder.patch_embed.proj.weight', e, 3, 4)
+    sd['encoder.patch_embed.proj.bias'] = _normal(seed, 'encoder.patch_embed.proj.bias', (e,), 0.02)
+    _norm(sd, seed, 'encoder.patch_embed.norm', e)
+    for li, (depth, nh) in enumerate(zip(depths, heads)):
+        dim = e * 2 ** li
+        for b in range(depth):
+            p = f'encoder.layers.{li}.blocks.{b}'
+            _norm(sd, seed, p + '.norm1', dim)
+            sd[p + '.attn.relative_position_bias_table'] = _normal(seed, p + '.attn.relative_position_bias_table', ((2 * ws - 1) ** 2, nh), 0.5)
+            sd[p + '.attn.relative_position_index'] = swin_relative_position_index(ws)
+            _linear(sd, seed, p + '.attn.qkv', 3 * dim, dim, 1.6)
+            _linear(sd, seed, p + '.attn.proj', dim, dim, 0.7)
+            _norm(sd, seed, p + '.norm2', dim)
+            _linear(sd, seed, p + '.mlp.fc1', 4 * dim, dim)
+            _linear(sd, seed, p + '.mlp.fc2', dim, 4 * dim, 0.7)
+        if li < len(depths) - 1:
+            p = f'encoder.layers.{li}.downsample'
+            bound = math.sqrt(6.0 / (4 * dim + 2 * dim))
+            sd[p + '.reduction.weight'] = _uniform(seed, p + '.reduction.weight', (2 * dim, 4 * dim), -bound, bound)
+            _norm(sd, seed, p + '.norm', 4 * dim)
+    for li in range(len(depths)):
+        _norm(sd, seed, f'encoder.norm{li}', e * 2 ** li)
+
+
 def synth_state_dict(seed: int = 0, num_lstt: int = 3, d_model: int = 256,
-                     max_obj_num: int = 10) -> "OrderedDict[str, torch.Tensor]":
-    """All 362 tensors of the R50-AOTL state_dict, fp32, CPU."""
+                     max_obj_num: int = 10, encoder: str = 'resnet50') -> "OrderedDict[str, torch.Tensor]":
+    """All tensors of the R50-AOTL (362) or SwinB-AOTL (471) state_dict, fp32, CPU."""
     sd: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+    swin = encoder == 'swin_base'
+    enc_dims = (128, 256, 512) if swin else (256, 512, 1024)
     # learned temporal positional embedding, aot.py:95-103 (std raised from .05 so the
     # path is visible in parity tests)
     sd['cur_pos_emb'] = _normal(seed, 'cur_pos_emb', (1, d_model), 0.3)
     sd['mem_pos_emb'] = _normal(seed, 'mem_pos_emb', (4, d_model), 0.3)
 
     # --- encoder (torchvision-style names) ---
-    _conv(sd, seed, 'encoder.conv1.weight', 64, 3, 7)
-    _bn(sd, seed, 'encoder.bn1', 64, 1.0)
-    for idx, planes, blocks, inplanes in _R50_STAGES:
+    if swin:
+        _swin_encoder(sd, seed)
+    else:
+        _conv(sd, seed, 'encoder.conv1.weight', 64, 3, 7)
+        _bn(sd, seed, 'encoder.bn1', 64, 1.0)
+    for idx, planes, blocks, inplanes in (() if swin else _R50_STAGES):
         for b in range(blocks):
             p = f'encoder.layer{idx}.{b}'
             cin = inplanes if b == 0 else planes * 4
@@ -89,7 +133,8 @@ def synth_state_dict(seed: int = 0, num_lstt: int = 3, d_model: int = 256,
                 _conv(sd, seed, p + '.downsample.0.weight', planes * 4, cin, 1)
                 _bn(sd, seed, p + '.downsample.1', planes * 4, 0.7)
     # encoder_projector 1x1 1024->256, aot.py:25-29
-    sd['encoder_projector.weight'] = _normal(seed, 'encoder_projector.weight', (d_model, 1024, 1, 1), 0.042)
+    sd['encoder_projector.weight'] = _normal(seed, 'encoder_projector.weight', (d_model, enc_dims[2], 1, 1),
+                                             0.06 if swin else 0.042)
     sd['encoder_projector.bias'] = _normal(seed, 'encoder_projector.bias', (d_model,), 0.02)
 
     # --- LSTT ---
@@ -124,13 +169,14 @@ def synth_state_dict(seed: int = 0, num_lstt: int = 3, d_model: int = 256,
     convgn('decoder.conv_16x', d_model, d_model, 3)
     convgn('decoder.conv_8x', d_model // 2, d_model, 3)
     convgn('decoder.conv_4x', d_model // 2, d_model // 2, 3)
-    for nm, cout, cin in (('adapter_16x', d_model, 1024), ('adapter_8x', d_model, 512), ('adapter_4x', d_model // 2, 256)):
+    for nm, cout, cin in (('adapter_16x', d_model, enc_dims[2]), ('adapter_8x', d_model, enc_dims[1]), ('adapter_4x', d_model // 2, enc_dims[0])):
         _conv(sd, seed, f'decoder.{nm}.weight', cout, cin, 1, 0.7)
         sd[f'decoder.{nm}.bias'] = _normal(seed, f'decoder.{nm}.bias', (cout,), 0.02)
     _conv(sd, seed, 'decoder.conv_out.weight', max_obj_num + 1, d_model // 2, 1, 1.0)
     sd['decoder.conv_out.bias'] = _normal(seed, 'decoder.conv_out.bias', (max_obj_num + 1,), 0.02)
 
     # --- identity bank Conv2d(12->256, k17, s16, p8), aot.py:68-74 ---
-    sd['patch_wise_id_bank.weight'] = _normal(seed, 'patch_wise_id_bank.weight', (d_model, max_obj_num + 2, 17, 17), 1.0 / 17.0)
+    kid = 16 if swin else 17      # models/aot.py:67-82: k17 s16 p8 (align_corners) or k16 s16 p0
+    sd['patch_wise_id_bank.weight'] = _normal(seed, 'patch_wise_id_bank.weight', (d_model, max_obj_num + 2, kid, kid), 1.0 / kid)
     sd['patch_wise_id_bank.bias'] = _normal(seed, 'patch_wise_id_bank.bias', (d_model,), 0.02)
     return sd

@@ -35,7 +35,7 @@ from rmem_ocu_amd.synth import make_clip  # noqa: E402
 from rmem_ocu_amd.weights import synth_state_dict  # noqa: E402
 
 
-def load_reference(former=1, latter=7):
+def load_reference(former=1, latter=7, encoder='resnet50'):
     sys.path.insert(0, REF)
     tml = types.ModuleType('timm.models.layers')
     tml.trunc_normal_ = lambda t, mean=0., std=1., a=-2., b=2.: torch.nn.init.trunc_normal_(t, mean=mean, std=std, a=a, b=b)
@@ -57,6 +57,10 @@ def load_reference(former=1, latter=7):
     cfg = importlib.import_module('configs.default').EngineConfig('golden', 'r50_aotl')
     cfg.MODEL_LINEAR_Q = False
     cfg.FORMER_MEM_LEN, cfg.LATTER_MEM_LEN = former, latter
+    if encoder == 'swin_base':
+        # cfg 5: configs/models/swinb_aotl.py lacks every RMem attribute AOT.__init__ reads, so the R50 config is kept and
+        # only the three encoder-related values of swinb_aotl.py:10-13 are overlaid
+        cfg.MODEL_ENCODER, cfg.MODEL_ALIGN_CORNERS, cfg.MODEL_ENCODER_DIM = 'swin_base', False, [128, 256, 512, 512]
 
     _zeros = torch.zeros
 
@@ -70,7 +74,7 @@ def load_reference(former=1, latter=7):
     from networks.models import build_vos_model
     from networks.engines import build_engine
     model = build_vos_model(cfg.MODEL_VOS, cfg).eval()
-    missing = model.load_state_dict(synth_state_dict(0), strict=True)
+    missing = model.load_state_dict(synth_state_dict(0, encoder=encoder), strict=True)
     assert not missing.missing_keys and not missing.unexpected_keys
     return cfg, model, build_engine
 
@@ -200,8 +204,19 @@ def pack_trace(trace, width):
     return arr
 
 
-def gen_clip(tag, former, latter, n_frames, h, w, out_hw, gap, objs, seed, inject_at=-1):
-    cfg, model, build_engine = load_reference(former, latter)
+def gen_swin_ops():
+    """Swin-B encoder (cfg 5) on a 96x128 image: stage outputs of the reference module."""
+    _, model, _ = load_reference(encoder='swin_base')
+    out = {}
+    with torch.no_grad():
+        xs = model.encode_image(seeded(2100, (1, 3, 96, 128)))
+        for i, x in enumerate(xs):
+            out[f'swin_x{i}'] = x[0, :, ::2, ::2].numpy() if i < 2 else x[0].numpy()
+    return out
+
+
+def gen_clip(tag, former, latter, n_frames, h, w, out_hw, gap, objs, seed, inject_at=-1, encoder='resnet50'):
+    cfg, model, build_engine = load_reference(former, latter, encoder)
     frames, mask = make_clip(seed, n_frames, h, w, objs)
     ys = np.linspace(2, out_hw[0] - 3, 12).astype(np.int64)
     xs = np.linspace(2, out_hw[1] - 3, 12).astype(np.int64)
@@ -241,6 +256,11 @@ if __name__ == '__main__':
     # NB no fixture for > 10 objects: the reference keeps the clip's LSTT memory inside the shared model
     # (layers/transformer.py:455-463), so its second AOTEngine (objects 11..) overwrites the first one's bank and the run
     # raises at the first eviction (transformer.py:401) -- observed here with 12 objects, 14 frames, bank 1+2.
+    if what in ('swin', 'all'):
+        np.savez_compressed(os.path.join(HERE, 'swin_ops.npz'), **gen_swin_ops())
+        # SwinB-AOTL clip: align_corners False -> network size multiple of 16 (video_transforms.py:616-622), id bank k16 s16
+        np.savez_compressed(os.path.join(HERE, 'clip_swin.npz'),
+                            **gen_clip('swin', 1, 2, 16, 160, 192, (160, 192), 2, 2, 61, encoder='swin_base'))
     if what in ('full', 'all'):
         # cfg-2 geometry: 480x854 video at network size 481x849, bank N = 8, gap 2 so the bank fills
         # by frame 14 and evicts from frame 16

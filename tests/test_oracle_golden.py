@@ -100,7 +100,9 @@ def _run_clip(name):
     frames, mask = make_clip(seed, n, h, wd, objs)
     assert hashlib.sha256(frames.numpy().tobytes()).hexdigest() == str(g['frames_sha'])
     from rmem_ocu_amd.weights import synth_state_dict
-    eng = O.OracleEngine(synth_state_dict(0), former, latter, gap)
+    swin = 'swin' in name
+    eng = O.OracleEngine(synth_state_dict(0, encoder='swin_base' if swin else 'resnet50'), former, latter, gap,
+                         align_corners=not swin)
     trace, labels, samples = [], [], []
     eng.long_term_mem_gap = gap
     eng.add_reference_frame(frames[0:1], mask, 0)
@@ -171,3 +173,18 @@ def test_restricted_bank_after_injection_raises_like_the_reference():
                 eng.add_reference_frame(frames[i:i + 1], m, i)
             else:
                 eng.update_memory(m)
+
+
+def test_swin_encoder_matches_reference():
+    """a16: Swin-B stages (window attention with relative-position bias, shifted-window masks, padding, patch merging)."""
+    from rmem_ocu_amd.weights import synth_state_dict
+    g = np.load(os.path.join(GOLDEN, 'swin_ops.npz'))
+    xs = O.encode_image(seeded(2100, (1, 3, 96, 128)), synth_state_dict(0, encoder='swin_base'))
+    assert [tuple(x.shape[1:]) for x in xs] == [(128, 24, 32), (256, 12, 16), (512, 6, 8), (256, 6, 8)]
+    for i, x in enumerate(xs):
+        close(x[0, :, ::2, ::2] if i < 2 else x[0], g[f'swin_x{i}'], 5e-5)
+
+
+def test_swin_clip_matches_reference():
+    """cfg-5 model (SwinB-AOTL, align_corners False, id bank k16 s16) through the engine protocol."""
+    _check_clip('clip_swin.npz')
