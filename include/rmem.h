@@ -45,7 +45,7 @@ typedef struct rmem_conv_desc {
   int ldo;            /* y row stride  (>= Cout) */
   int ldr;            /* residual row stride */
   int ld2;            /* y2 row stride */
-  int relu;           /* 1: ReLU after bias/residual */
+  int relu;           /* activation after bias/residual: 0 none, 1 ReLU, 2 exact (erf) GELU */
   int out_f32;        /* 1: y is fp32, 0: bf16 */
   int res_f32;        /* 1: residual is fp32, 0: bf16 */
 } rmem_conv_desc;
@@ -107,6 +107,26 @@ int rmem_layernorm256(const void* a, int a_is_f32, int lda, const void* b, int b
                       const float* gamma, const float* beta, float eps, int M,
                       void* y_bf16, int ldy, const float* pos, void* ypos_bf16, int ldyp,
                       float* y_f32, int ldyf, void* stream);
+
+/* LayerNorm over C in {128, 256, 512, 1024} channels; bf16 and/or fp32 output.  Replaces the nn.LayerNorm call sites of the
+ * Swin-B encoder (encoders/swin/swin_transformer.py:266, 318, 354, 538, 704). */
+int rmem_layernorm(const void* a, int a_is_f32, int lda, const float* gamma, const float* beta, float eps, int M, int C,
+                   void* y_bf16, int ldy, float* y_f32, int ldyf, void* stream);
+
+/* Swin patch merging without the linear: gather the 2x2 neighbourhood of every output token of an fp32 [H][W][C] map
+ * (zero beyond an odd border), LayerNorm over 4C, bf16 [ceil(H/2)*ceil(W/2)][4C] (swin_transformer.py:336-355; the
+ * reduction Linear at 356 is a rmem_conv2d_nhwc call).  C in {128, 256}. */
+int rmem_patch_merge_ln(const float* x, int H, int W, int C, const float* gamma, const float* beta, float eps,
+                        void* y_bf16, void* stream);
+
+/* Swin (shifted-)window attention over a [H][W] token map, 7x7 windows, head dim 32: padding, cyclic shift, window
+ * partition / reverse, relative-position bias and the shifted-window mask are index arithmetic inside the kernel.
+ * qkv: bf16 [H*W][3C] (q | k | v); qkv_bias: fp32 [3C] (what a padded zero token projects to);
+ * bias_mask_table: fp32 [4][heads][49][49] = (relative_position_bias + mask of window type t) * log2(e), type = 2 * (last
+ * window row) + (last window column) (only type 0 is read when shift == 0); out: bf16 [H*W][C], pre-projection.
+ * Replaces encoders/swin/swin_transformer.py:156-195 and the token plumbing of 263-305. */
+int rmem_window_attn(const void* qkv, const float* qkv_bias, const float* bias_mask_table, void* out, int H, int W,
+                     int C, int heads, int shift, void* stream);
 
 /* y = a + b (bf16).  Replaces the `curr_v + curr_id_emb` adds of layers/transformer.py:279-285. */
 int rmem_add_bf16(const void* a, const void* b, void* y, long long n, void* stream);

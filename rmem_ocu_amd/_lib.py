@@ -40,6 +40,9 @@ SIGNATURES = {
     'rmem_profile_start': (_i, [_i]),
     'rmem_profile_stop': (_i, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i)]),
     'rmem_layernorm256': (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _f, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _vp]),
+    'rmem_layernorm': (_i, [_vp, _i, _i, _vp, _vp, _f, _i, _i, _vp, _i, _vp, _i, _vp]),
+    'rmem_patch_merge_ln': (_i, [_vp, _i, _i, _i, _vp, _vp, _f, _vp, _vp]),
+    'rmem_window_attn': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'rmem_add_bf16': (_i, [_vp, _vp, _vp, _ll, _vp]),
     'rmem_groupnorm_workspace_bytes': (C.c_size_t, [_i]),
     'rmem_groupnorm_nhwc': (_i, [_vp, _i, _i, _i, _vp, _vp, _f, _i, _vp, _vp, _vp]),

@@ -10,8 +10,9 @@ from __future__ import annotations
 
 class EngineConfig:
     def __init__(self, exp_name: str = 'default', model: str = 'r50_aotl'):
-        if model.lower() != 'r50_aotl':
-            raise NotImplementedError(f'model config {model!r}: only r50_aotl is built so far')
+        model = model.lower()
+        if model not in ('r50_aotl', 'swinb_aotl'):
+            raise NotImplementedError(f'model config {model!r}: built configs are r50_aotl and swinb_aotl')
         self.EXP_NAME = exp_name
         self.MODEL_NAME = 'R50_AOTL_Temp_pe_Slot_4'
         self.MODEL_VOS = 'aot'
@@ -44,6 +45,13 @@ class EngineConfig:
         self.TEST_MAX_SIZE = 800 * 1.3
         self.TEST_FLIP = False
         self.TEST_MULTISCALE = [1.0]
+        if model == 'swinb_aotl':
+            # configs/models/swinb_aotl.py:8-13 overlaid on the RMem attributes above (the reference's own swinb config lacks
+            # them, so it cannot build an AOT model as shipped: SURVEY.md §8 a16)
+            self.MODEL_NAME = 'SwinB_AOTL_Temp_pe_Slot_4'
+            self.MODEL_ENCODER = 'swin_base'
+            self.MODEL_ALIGN_CORNERS = False
+            self.MODEL_ENCODER_DIM = [128, 256, 512, 512]
 
 
 def get_config(stage: str = 'pre_vost', exp_name: str = 'default', model: str = 'r50_aotl') -> EngineConfig:

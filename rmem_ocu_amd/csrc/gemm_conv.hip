@@ -77,9 +77,12 @@ __device__ __forceinline__ void finish8(const ConvParams& p, int m, int n, float
       for (int j = 0; j < 8; ++j) v[j] += (float)r[j];
     }
   }
-  if (p.relu) {
+  if (p.relu == 1) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+  } else if (p.relu == 2) {                 // exact (erf) GELU: Swin MLP, encoders/swin/swin_transformer.py:55-57
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = 0.5f * v[j] * (1.f + erff(v[j] * 0.70710678118654752f));
   }
   if (p.out_f32) {
     float* y = reinterpret_cast<float*>(p.y) + (long)m * p.ldo + n;
@@ -100,7 +103,8 @@ __device__ __forceinline__ void finish1(const ConvParams& p, int m, int n, float
   if (p.res)
     v += p.res_f32 ? reinterpret_cast<const float*>(p.res)[(long)m * p.ldr + n]
                    : (float)reinterpret_cast<const bf16*>(p.res)[(long)m * p.ldr + n];
-  if (p.relu) v = fmaxf(v, 0.f);
+  if (p.relu == 1) v = fmaxf(v, 0.f);
+  else if (p.relu == 2) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
   if (p.out_f32) reinterpret_cast<float*>(p.y)[(long)m * p.ldo + n] = v;
   else reinterpret_cast<bf16*>(p.y)[(long)m * p.ldo + n] = (bf16)v;
 }

@@ -52,6 +52,71 @@ __global__ __launch_bounds__(256) void k_layernorm256(LnParams p) {
   }
 }
 
+// generic channel count (Swin-B stages: 128 / 256 / 512 / 1024): one wave per row, C / 64 consecutive channels per lane
+template <int C>
+__global__ __launch_bounds__(256) void k_layernorm_c(const void* a, int a_f32, int lda, const float* gamma, const float* beta, float eps,
+                                                     int M, bf16* y, int ldy, float* yf, int ldyf) {
+  constexpr int NV = C / 64;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int c0 = lane * NV;
+  float v[NV];
+  if (a_f32) {
+    const float* pa = reinterpret_cast<const float*>(a) + (long)row * lda + c0;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) v[j] = pa[j];
+  } else {
+    const bf16* pa = reinterpret_cast<const bf16*>(a) + (long)row * lda + c0;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) v[j] = (float)pa[j];
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) s += v[j];
+  const float mean = wave_sum(s) * (1.f / C);
+  float ss = 0.f;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) { v[j] -= mean; ss += v[j] * v[j]; }
+  const float rstd = rsqrtf(wave_sum(ss) * (1.f / C) + eps);
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const float o = v[j] * rstd * gamma[c0 + j] + beta[c0 + j];
+    if (y) y[(long)row * ldy + c0 + j] = (bf16)o;
+    if (yf) yf[(long)row * ldyf + c0 + j] = o;
+  }
+}
+
+// Swin patch merging (encoders/swin/swin_transformer.py:336-356): gather the 2x2 neighbourhood of every output token
+// ([even,even], [odd,even], [even,odd], [odd,odd] row/col order, zero beyond an odd border), LayerNorm over 4C, bf16 out.
+// One wave per output token.
+template <int C>
+__global__ __launch_bounds__(256) void k_patch_merge_ln(const float* x, int H, int W, const float* gamma, const float* beta, float eps, bf16* y) {
+  constexpr int C4 = 4 * C, NV = C4 / 64;
+  const int lane = threadIdx.x & 63;
+  const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+  const int tok = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tok >= Ho * Wo) return;
+  const int oy = tok / Wo, ox = tok - oy * Wo;
+  const int c0 = lane * NV;                  // NV consecutive channels of the 4C vector: one source pixel (NV divides C)
+  const int part = c0 / C, cc = c0 - part * C;
+  const int sy = 2 * oy + (part & 1), sx = 2 * ox + (part >> 1);
+  float v[NV];
+  const bool ok = sy < H && sx < W;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) v[j] = ok ? x[((long)sy * W + sx) * C + cc + j] : 0.f;
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) s += v[j];
+  const float mean = wave_sum(s) * (1.f / C4);
+  float ss = 0.f;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) { v[j] -= mean; ss += v[j] * v[j]; }
+  const float rstd = rsqrtf(wave_sum(ss) * (1.f / C4) + eps);
+#pragma unroll
+  for (int j = 0; j < NV; ++j) y[(long)tok * C4 + c0 + j] = (bf16)(v[j] * rstd * gamma[c0 + j] + beta[c0 + j]);
+}
+
 // ------------------------------------------------------------------ add
 __global__ __launch_bounds__(256) void k_add_bf16(const bf16* a, const bf16* b, bf16* y, long n8) {
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
@@ -176,6 +241,32 @@ extern "C" int rmem_layernorm256(const void* a, int a_is_f32, int lda, const voi
   LnParams p{a, a_is_f32, lda, b, b_is_f32, ldb, gamma, beta, eps, M, (bf16*)y_bf16, ldy, pos, (bf16*)ypos_bf16, ldyp, y_f32, ldyf};
   hipLaunchKernelGGL(k_layernorm256, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
   return rmem_check_launch("rmem_layernorm256");
+}
+
+extern "C" int rmem_layernorm(const void* a, int a_is_f32, int lda, const float* gamma, const float* beta, float eps, int M, int C,
+                              void* y_bf16, int ldy, float* y_f32, int ldyf, void* stream) {
+  RMEM_REQUIRE(a && gamma && beta && M > 0 && (y_bf16 || y_f32), "rmem_layernorm: bad argument");
+  const dim3 g((M + 3) / 4), b(256);
+  hipStream_t s = (hipStream_t)stream;
+  switch (C) {
+    case 128: hipLaunchKernelGGL(k_layernorm_c<128>, g, b, 0, s, a, a_is_f32, lda, gamma, beta, eps, M, (bf16*)y_bf16, ldy, y_f32, ldyf); break;
+    case 256: hipLaunchKernelGGL(k_layernorm_c<256>, g, b, 0, s, a, a_is_f32, lda, gamma, beta, eps, M, (bf16*)y_bf16, ldy, y_f32, ldyf); break;
+    case 512: hipLaunchKernelGGL(k_layernorm_c<512>, g, b, 0, s, a, a_is_f32, lda, gamma, beta, eps, M, (bf16*)y_bf16, ldy, y_f32, ldyf); break;
+    case 1024: hipLaunchKernelGGL(k_layernorm_c<1024>, g, b, 0, s, a, a_is_f32, lda, gamma, beta, eps, M, (bf16*)y_bf16, ldy, y_f32, ldyf); break;
+    default: rmem_set_error("rmem_layernorm: C must be 128, 256, 512 or 1024"); return -1;
+  }
+  return rmem_check_launch("rmem_layernorm");
+}
+
+extern "C" int rmem_patch_merge_ln(const float* x, int H, int W, int C, const float* gamma, const float* beta, float eps, void* y_bf16, void* stream) {
+  RMEM_REQUIRE(x && gamma && beta && y_bf16 && H > 0 && W > 0, "rmem_patch_merge_ln: bad argument");
+  const int M = ((H + 1) / 2) * ((W + 1) / 2);
+  const dim3 g((M + 3) / 4), b(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (C == 128) hipLaunchKernelGGL(k_patch_merge_ln<128>, g, b, 0, s, x, H, W, gamma, beta, eps, (bf16*)y_bf16);
+  else if (C == 256) hipLaunchKernelGGL(k_patch_merge_ln<256>, g, b, 0, s, x, H, W, gamma, beta, eps, (bf16*)y_bf16);
+  else { rmem_set_error("rmem_patch_merge_ln: C must be 128 or 256"); return -1; }
+  return rmem_check_launch("rmem_patch_merge_ln");
 }
 
 extern "C" int rmem_add_bf16(const void* a, const void* b, void* y, long long n, void* stream) {

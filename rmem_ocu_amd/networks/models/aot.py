@@ -40,6 +40,7 @@ def _attach(root: nn.Module, key: str, value: torch.Tensor):
     leaf = parts[-1]
     # FrozenBatchNorm2d keeps all four tensors as buffers (layers/normalization.py:13-16)
     is_bn = any(k in key for k in ('.bn1.', '.bn2.', '.bn3.', '.downsample.1.')) and key.startswith('encoder.')
+    is_bn = is_bn or leaf == 'relative_position_index'       # Swin: an int64 buffer (swin_transformer.py:143)
     if leaf in _BUFFER_SUFFIXES or is_bn:
         node.register_buffer(leaf, value.clone())
     else:
@@ -49,8 +50,8 @@ def _attach(root: nn.Module, key: str, value: torch.Tensor):
 class AOT(nn.Module):
     def __init__(self, cfg, encoder='resnet50', decoder='fpn'):
         super().__init__()
-        if encoder != 'resnet50' or decoder != 'fpn':
-            raise NotImplementedError('only the resnet50 encoder + fpn decoder of R50-AOTL are built')
+        if encoder not in ('resnet50', 'swin_base') or decoder != 'fpn':
+            raise NotImplementedError('built encoders: resnet50 (R50-AOTL) and swin_base (SwinB-AOTL); decoder: fpn')
         if cfg.MODEL_LINEAR_Q:
             raise NotImplementedError('MODEL_LINEAR_Q=True: the reference eval path itself crashes there '
                                       '(layers/transformer.py:650-665); use the pre_vost setting False')
@@ -59,7 +60,7 @@ class AOT(nn.Module):
         self.epsilon = cfg.MODEL_EPSILON
         self.use_temporal_pe = cfg.USE_TEMPORAL_POSITIONAL_EMBEDDING
         # same construction-time randomness contract as the reference: fresh weights unless loaded
-        for k, v in synth_state_dict(0, cfg.MODEL_LSTT_NUM, cfg.MODEL_ENCODER_EMBEDDING_DIM, cfg.MODEL_MAX_OBJ_NUM).items():
+        for k, v in synth_state_dict(0, cfg.MODEL_LSTT_NUM, cfg.MODEL_ENCODER_EMBEDDING_DIM, cfg.MODEL_MAX_OBJ_NUM, encoder).items():
             _attach(self, k, v)
         self._packed: Optional[Dict[str, torch.Tensor]] = None
         self._packed_device = None

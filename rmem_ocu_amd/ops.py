@@ -55,7 +55,8 @@ def _dev(*ts):
 
 def conv2d(x, w, bias, y, *, H, W, Cin, Cout, KH=1, KW=1, stride=1, pad=0, residual=None, y2=None, relu=False,
            ldo=None, ldr=None, ld2=None, ws=None) -> Op:
-    """y = act(conv(x, w) + bias (+ residual)); w is [Cout, KH, KW, Cin] bf16, x NHWC bf16."""
+    """y = act(conv(x, w) + bias (+ residual)); w is [Cout, KH, KW, Cin] bf16, x NHWC bf16.
+    relu: False/0 none, True/1 ReLU, 2 exact GELU."""
     _dev(x, w, bias, y, residual, y2)
     assert x.dtype == BF16 and w.dtype == BF16 and w.is_contiguous()
     assert w.numel() == Cout * KH * KW * Cin, (w.shape, Cout, KH, KW, Cin)
@@ -117,6 +118,29 @@ def layernorm256(a, gamma, beta, *, M, lda=256, b=None, ldb=256, y=None, ldy=256
     args = (_ptr(a), int(a.dtype == F32), lda, _ptr(b), int(b is not None and b.dtype == F32), ldb, _ptr(gamma), _ptr(beta),
             eps, M, _ptr(y), ldy, _ptr(pos), _ptr(ypos), ldyp, _ptr(yf), ldyf)
     return Op(_lib.lib().rmem_layernorm256, args, 'rmem_layernorm256', (a, b, gamma, beta, y, pos, ypos, yf))
+
+
+def layernorm(a, gamma, beta, *, M, C, lda=None, y=None, ldy=None, yf=None, ldyf=None, eps=1e-5) -> Op:
+    """LayerNorm over C in {128, 256, 512, 1024}."""
+    _dev(a, gamma, beta, y, yf)
+    assert a.dtype in (BF16, F32) and gamma.dtype == F32 and gamma.numel() == C
+    args = (_ptr(a), int(a.dtype == F32), C if lda is None else lda, _ptr(gamma), _ptr(beta), eps, M, C, _ptr(y),
+            C if ldy is None else ldy, _ptr(yf), C if ldyf is None else ldyf)
+    return Op(_lib.lib().rmem_layernorm, args, 'rmem_layernorm', (a, gamma, beta, y, yf))
+
+
+def patch_merge_ln(x, gamma, beta, y, *, H, W, C, eps=1e-5) -> Op:
+    _dev(x, gamma, beta, y)
+    assert x.dtype == F32 and y.dtype == BF16 and gamma.numel() == 4 * C
+    return Op(_lib.lib().rmem_patch_merge_ln, (_ptr(x), H, W, C, _ptr(gamma), _ptr(beta), eps, _ptr(y)), 'rmem_patch_merge_ln', (x, gamma, beta, y))
+
+
+def window_attn(qkv, qkv_bias, table, out, *, H, W, C, heads, shift) -> Op:
+    _dev(qkv, qkv_bias, table, out)
+    assert qkv.dtype == BF16 and out.dtype == BF16 and qkv_bias.dtype == F32 and table.dtype == F32
+    assert qkv_bias.numel() == 3 * C and table.numel() == 4 * heads * 49 * 49 and table.is_contiguous()
+    return Op(_lib.lib().rmem_window_attn, (_ptr(qkv), _ptr(qkv_bias), _ptr(table), _ptr(out), H, W, C, heads, shift),
+              'rmem_window_attn', (qkv, qkv_bias, table, out))
 
 
 def add_bf16(a, b, y, n: int) -> Op:

@@ -32,15 +32,59 @@ def _fold_bn(sd, conv_key: str, bn_prefix: str, cin_pad: int = 0):
     return _conv_w(w * scale.view(-1, 1, 1, 1), cin_pad), bias.contiguous()
 
 
+SWIN_DEPTHS, SWIN_HEADS, SWIN_WS = (2, 2, 18), (4, 8, 16), 7     # encoders/swin/build.py:11-22, last stage dropped
+LOG2E = 1.4426950408889634
+
+
+def swin_window_masks(ws: int = SWIN_WS) -> torch.Tensor:
+    """Shifted-window attention masks by window type [4, 49, 49] (0 / -100), type = 2 * (last window row) + (last window
+    column).  Restates encoders/swin/swin_transformer.py:432-451: inside the last window row (column) the first
+    ws - shift rows (columns) and the remaining shift rows (columns) come from different image regions after the roll."""
+    sh = ws // 2
+    py, px = torch.arange(ws * ws) // ws, torch.arange(ws * ws) % ws
+    out = torch.zeros(4, ws * ws, ws * ws)
+    for t in range(4):
+        rr = (py >= ws - sh).long() if t & 2 else torch.zeros_like(py)
+        cr = (px >= ws - sh).long() if t & 1 else torch.zeros_like(px)
+        reg = rr * 2 + cr
+        out[t] = (reg[:, None] != reg[None, :]).float() * -100.0
+    return out
+
+
+def _pack_swin(sd, put):
+    put('pe.w', _conv_w(sd['encoder.patch_embed.proj.weight'].float(), cin_pad=8)); put('pe.b', sd['encoder.patch_embed.proj.bias'].float())
+    put('pe.ln.g', sd['encoder.patch_embed.norm.weight'].float()); put('pe.ln.b', sd['encoder.patch_embed.norm.bias'].float())
+    masks = swin_window_masks()
+    for li, (depth, heads) in enumerate(zip(SWIN_DEPTHS, SWIN_HEADS)):
+        for b in range(depth):
+            s, d = f'encoder.layers.{li}.blocks.{b}', f'sw{li}.{b}'
+            for nm in ('norm1', 'norm2'):
+                put(f'{d}.{nm}.g', sd[f'{s}.{nm}.weight'].float()); put(f'{d}.{nm}.b', sd[f'{s}.{nm}.bias'].float())
+            for dst, src in (('qkv', 'attn.qkv'), ('proj', 'attn.proj'), ('fc1', 'mlp.fc1'), ('fc2', 'mlp.fc2')):
+                put(f'{d}.{dst}.w', sd[f'{s}.{src}.weight'].float().to(torch.bfloat16)); put(f'{d}.{dst}.b', sd[f'{s}.{src}.bias'].float())
+            tbl = sd[f'{s}.attn.relative_position_bias_table'].float()[sd[f'{s}.attn.relative_position_index'].view(-1)]
+            bias = tbl.view(49, 49, heads).permute(2, 0, 1)                                   # [heads, q, k]
+            put(f'{d}.table', (bias[None] + masks[:, None].to(bias.device)) * LOG2E)           # [4, heads, 49, 49]
+        if li < len(SWIN_DEPTHS) - 1:
+            s = f'encoder.layers.{li}.downsample'
+            put(f'sw{li}.merge.w', sd[s + '.reduction.weight'].float().to(torch.bfloat16))
+            put(f'sw{li}.merge.g', sd[s + '.norm.weight'].float()); put(f'sw{li}.merge.b', sd[s + '.norm.bias'].float())
+        put(f'sw.norm{li}.g', sd[f'encoder.norm{li}.weight'].float()); put(f'sw.norm{li}.b', sd[f'encoder.norm{li}.bias'].float())
+
+
 def pack_state_dict(sd: Dict[str, torch.Tensor], device, num_lstt: int = 3) -> Dict[str, torch.Tensor]:
     P: Dict[str, torch.Tensor] = {}
 
     def put(name, t):
         P[name] = t.to(device).contiguous()
 
-    w, b = _fold_bn(sd, 'encoder.conv1.weight', 'encoder.bn1', cin_pad=8)
-    put('stem.w', w); put('stem.b', b)
-    for li, nblk in enumerate(R50_BLOCKS, start=1):
+    swin = 'encoder.patch_embed.proj.weight' in sd
+    if swin:
+        _pack_swin(sd, put)
+    else:
+        w, b = _fold_bn(sd, 'encoder.conv1.weight', 'encoder.bn1', cin_pad=8)
+        put('stem.w', w); put('stem.b', b)
+    for li, nblk in enumerate(() if swin else R50_BLOCKS, start=1):
         for bi in range(nblk):
             p = f'encoder.layer{li}.{bi}'
             for j in (1, 2, 3):

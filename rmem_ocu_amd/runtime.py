@@ -74,25 +74,45 @@ class ClipRuntime:
         self.nc = num_classes
         H, W = in_hw
         self.H, self.W = H, W
-        self.H2, self.W2 = _out(H, 7, 2, 3), _out(W, 7, 2, 3)
-        self.H4, self.W4 = _out(self.H2, 3, 2, 1), _out(self.W2, 3, 2, 1)
-        self.H8, self.W8 = _out(self.H4, 3, 2, 1), _out(self.W4, 3, 2, 1)
-        self.H16, self.W16 = _out(self.H8, 3, 2, 1), _out(self.W8, 3, 2, 1)
+        self.swin = 'pe.w' in P
+        e = lambda *shape, dt=BF16: torch.empty(*shape, dtype=dt, device=device)  # noqa: E731
+        self.img8 = e(H * W, 8)
+        if self.swin:
+            # Swin-B (cfg 5): patch 4, then two patch mergings (encoders/swin/swin_transformer.py:500-545, 684-716)
+            if H % 4 or W % 4:
+                raise ops.RmemError('Swin-B path: network size must be a multiple of 4 (the evaluator makes it a multiple of 16)')
+            self.H4, self.W4 = H // 4, W // 4
+            self.H8, self.W8 = (self.H4 + 1) // 2, (self.W4 + 1) // 2
+            self.H16, self.W16 = (self.H8 + 1) // 2, (self.W8 + 1) // 2
+            self.enc_ch = (128, 256, 512)
+        else:
+            self.H2, self.W2 = _out(H, 7, 2, 3), _out(W, 7, 2, 3)
+            self.H4, self.W4 = _out(self.H2, 3, 2, 1), _out(self.W2, 3, 2, 1)
+            self.H8, self.W8 = _out(self.H4, 3, 2, 1), _out(self.W4, 3, 2, 1)
+            self.H16, self.W16 = _out(self.H8, 3, 2, 1), _out(self.W8, 3, 2, 1)
+            self.enc_ch = (256, 512, 1024)
         self.L = self.H16 * self.W16
         L = self.L
-        e = lambda *shape, dt=BF16: torch.empty(*shape, dtype=dt, device=device)  # noqa: E731
+        M4, M8 = self.H4 * self.W4, self.H8 * self.W8
 
         # ---- encoder buffers ----
-        self.img8 = e(H * W, 8)
-        self.stem = e(self.H2 * self.W2, 64)
-        M4, M8 = self.H4 * self.W4, self.H8 * self.W8
-        self.pool = e(M4, 64)
-        self.x4 = [e(M4, 256), e(M4, 256)]          # layer1 ping-pong
-        self.x8 = [e(M8, 512), e(M8, 512)]
-        self.x16 = [e(L, 1024), e(L, 1024)]
-        self.mid_a = e(M4, 128)                     # bottleneck conv1 out (<= M4*64, M4*128 for layer2.0, ...)
-        self.mid_b = e(M4, 64)                      # bottleneck conv2 out
-        self.ds = e(M4, 256)                        # downsample branch
+        if self.swin:
+            self.sx = e(M4, 128, dt=F32)            # fp32 residual stream of the current stage (M4*128 >= M8*256 >= L*512)
+            self.sln = e(M4, 128)                   # LayerNorm output (bf16)
+            self.sqkv = e(M4, 384)
+            self.satt = e(M4, 128)
+            self.smlp = e(M4, 512)
+            self.smerge = e(M8, 512)                # patch-merge LN output [tokens/4, 4C]
+            self.enc1, self.enc2, self.enc3 = e(M4, 128), e(M8, 256), e(L, 512)
+        else:
+            self.stem = e(self.H2 * self.W2, 64)
+            self.pool = e(M4, 64)
+            self.x4 = [e(M4, 256), e(M4, 256)]          # layer1 ping-pong
+            self.x8 = [e(M8, 512), e(M8, 512)]
+            self.x16 = [e(L, 1024), e(L, 1024)]
+            self.mid_a = e(M4, 128)                     # bottleneck conv1 out (<= M4*64, M4*128 for layer2.0, ...)
+            self.mid_b = e(M4, 64)                      # bottleneck conv2 out
+            self.ds = e(M4, 256)                        # downsample branch
         # ---- LSTT buffers ----
         self.x = e(L, D_MODEL, dt=F32)              # residual stream
         self.dec_in = e(L, 4 * D_MODEL)             # cat(enc256, 3 x normed LSTT out), decoders/fpn.py:38-39
@@ -196,10 +216,46 @@ class ClipRuntime:
     def _lin(self, x, name, y, M, K, N, **kw):
         return ops.linear(x, self.P[name + '.w'], self.P[name + '.b'], y, M=M, K=K, N=N, ws=self.conv_ws, **kw)
 
+    def _prog_encode_swin(self, img: torch.Tensor) -> list:
+        """Swin-B: patch embed + LN, 3 stages of (shifted-)window blocks, patch merging, per-stage output norms."""
+        from .pack import SWIN_DEPTHS, SWIN_HEADS
+        P, o = self.P, []
+        o.append(ops.image_to_nhwc8(img, self.img8, H=self.H, W=self.W))
+        h, w, C = self.H4, self.W4, 128
+        x = self.sx.view(-1)
+        o.append(ops.conv2d(self.img8, P['pe.w'], P['pe.b'], x[: h * w * C], H=self.H, W=self.W, Cin=8, Cout=C, KH=4, KW=4, stride=4))
+        o.append(ops.layernorm(x, P['pe.ln.g'], P['pe.ln.b'], M=h * w, C=C, yf=x))
+        outs = (self.enc1, self.enc2, self.enc3)
+        for li, (depth, heads) in enumerate(zip(SWIN_DEPTHS, SWIN_HEADS)):
+            M = h * w
+            ln, qkv, att, mlp = self.sln.view(-1), self.sqkv.view(-1), self.satt.view(-1), self.smlp.view(-1)
+            for b in range(depth):
+                d = f'sw{li}.{b}'
+                o.append(ops.layernorm(x, P[d + '.norm1.g'], P[d + '.norm1.b'], M=M, C=C, y=ln))
+                o.append(self._lin(ln, d + '.qkv', qkv, M, C, 3 * C))
+                o.append(ops.window_attn(qkv, P[d + '.qkv.b'], P[d + '.table'], att, H=h, W=w, C=C, heads=heads, shift=0 if b % 2 == 0 else 3))
+                o.append(self._lin(att, d + '.proj', x, M, C, C, residual=x))
+                o.append(ops.layernorm(x, P[d + '.norm2.g'], P[d + '.norm2.b'], M=M, C=C, y=ln))
+                o.append(self._lin(ln, d + '.fc1', mlp, M, C, 4 * C, relu=2))
+                o.append(self._lin(mlp, d + '.fc2', x, M, 4 * C, C, residual=x))
+            o.append(ops.layernorm(x, P[f'sw.norm{li}.g'], P[f'sw.norm{li}.b'], M=M, C=C, y=outs[li]))
+            if li < len(SWIN_DEPTHS) - 1:
+                mg = self.smerge.view(-1)
+                o.append(ops.patch_merge_ln(x, P[f'sw{li}.merge.g'], P[f'sw{li}.merge.b'], mg, H=h, W=w, C=C))
+                h, w = (h + 1) // 2, (w + 1) // 2
+                o.append(ops.linear(mg, P[f'sw{li}.merge.w'], None, x, M=h * w, K=4 * C, N=2 * C, ws=self.conv_ws))
+                C *= 2
+        o.append(self._conv(self.enc3, P['proj.w'], P['proj.b'], self.x, H=self.L, W=1, Cin=512, Cout=D_MODEL,
+                            y2=self.dec_in, ld2=4 * D_MODEL))
+        return o
+
     def prog_encode(self, img: torch.Tensor) -> list:
         """img: fp32 [3, H, W] device tensor at a FIXED address (the caller copies frames into it)."""
         key = 'encode'
         if key in self._prog:
+            return self._prog[key]
+        if self.swin:
+            self._prog[key] = self._prog_encode_swin(img)
             return self._prog[key]
         P, o = self.P, []
         o.append(ops.image_to_nhwc8(img, self.img8, H=self.H, W=self.W))
@@ -312,13 +368,14 @@ class ClipRuntime:
         gn = lambda x, name, y, M, C: ops.groupnorm(x, P[name + '.gn.g'], P[name + '.gn.b'], y, self.gn_ws, M=M, C=C, groups=8, act=1)  # noqa: E731
         o.append(self._conv(self.dec_in, P['dec.conv_in.w'], P['dec.conv_in.b'], self.d16a, H=L, W=1, Cin=1024, Cout=256))
         o.append(gn(self.d16a, 'dec.conv_in', self.d16b, L, 256))
-        o.append(self._conv(self.enc3, P['dec.adapter_16x.w'], P['dec.adapter_16x.b'], self.d16a, H=L, W=1, Cin=1024, Cout=256,
+        c4, c8, c16 = self.enc_ch
+        o.append(self._conv(self.enc3, P['dec.adapter_16x.w'], P['dec.adapter_16x.b'], self.d16a, H=L, W=1, Cin=c16, Cout=256,
                             residual=self.d16b))
         o.append(self._conv(self.d16a, P['dec.conv_16x.w'], P['dec.conv_16x.b'], self.d16b, H=self.H16, W=self.W16, Cin=256, Cout=256,
                             KH=3, KW=3, pad=1))
         o.append(gn(self.d16b, 'dec.conv_16x', self.d16a, L, 256))
         o.append(ops.bilinear(self.d16a, self.d8a, Hi=self.H16, Wi=self.W16, Ho=self.H8, Wo=self.W8, C=256, align_corners=self.align))
-        o.append(self._conv(self.enc2, P['dec.adapter_8x.w'], P['dec.adapter_8x.b'], self.d8b, H=M8, W=1, Cin=512, Cout=256,
+        o.append(self._conv(self.enc2, P['dec.adapter_8x.w'], P['dec.adapter_8x.b'], self.d8b, H=M8, W=1, Cin=c8, Cout=256,
                             residual=self.d8a))
         d8c = self.d8a.view(-1)[: M8 * 128]
         o.append(self._conv(self.d8b, P['dec.conv_8x.w'], P['dec.conv_8x.b'], d8c, H=self.H8, W=self.W8, Cin=256, Cout=128,
@@ -326,7 +383,7 @@ class ClipRuntime:
         d8d = self.d8b.view(-1)[: M8 * 128]
         o.append(gn(d8c, 'dec.conv_8x', d8d, M8, 128))
         o.append(ops.bilinear(d8d, self.d4a, Hi=self.H8, Wi=self.W8, Ho=self.H4, Wo=self.W4, C=128, align_corners=self.align))
-        o.append(self._conv(self.enc1, P['dec.adapter_4x.w'], P['dec.adapter_4x.b'], self.d4b, H=M4, W=1, Cin=256, Cout=128,
+        o.append(self._conv(self.enc1, P['dec.adapter_4x.w'], P['dec.adapter_4x.b'], self.d4b, H=M4, W=1, Cin=c4, Cout=128,
                             residual=self.d4a))
         o.append(self._conv(self.d4b, P['dec.conv_4x.w'], P['dec.conv_4x.b'], self.d4a, H=self.H4, W=self.W4, Cin=128, Cout=128,
                             KH=3, KW=3, pad=1))

@@ -173,3 +173,50 @@ def test_more_than_ten_objects_vs_oracle():
     print('12 objects: max |dprob| =', worst, ' mean |dprob| =', np.mean(agree), '(uniform = %.3f)' % (1 / 21))
     assert worst < 0.01 and np.mean(agree) < 0.001
     assert eng.long_memories_indexes == ora.long_memories_indexes
+
+
+def test_swin_encoder_and_clip():
+    """cfg-5 model on the GPU: Swin-B stage outputs against the reference fixture, then the SwinB-AOTL clip
+    (align_corners False, id bank k16 s16) teacher-forced against the reference's golden clip."""
+    from rmem_ocu_amd import build_engine, build_vos_model, get_config, ops
+    from rmem_ocu_amd.runtime import ClipRuntime
+    from rmem_ocu_amd.weights import synth_state_dict
+    dev = torch.device('cuda', 0)
+    cfg = get_config('pre_vost', 'test', 'swinb_aotl')
+    cfg.FORMER_MEM_LEN, cfg.LATTER_MEM_LEN = 1, 2
+    model = build_vos_model(cfg.MODEL_VOS, cfg).cuda(0)
+    sd = synth_state_dict(0, encoder='swin_base')
+    model.load_state_dict(sd)
+    # --- encoder stages
+    g = np.load(os.path.join(GOLDEN, 'swin_ops.npz'))
+    rng = np.random.Generator(np.random.PCG64([2100, 0xC0FFEE]))
+    img = torch.from_numpy(rng.standard_normal((1, 3, 96, 128)).astype(np.float32))
+    rt = ClipRuntime(model.packed(), (96, 128), 4, dev, 3, False, 11)
+    imgd = img[0].to(dev).contiguous()
+    ops.run(rt.prog_encode(imgd))
+    torch.cuda.synchronize()
+    for i, (buf, (h, w, c)) in enumerate(zip((rt.enc1, rt.enc2, rt.enc3), ((24, 32, 128), (12, 16, 256), (6, 8, 512)))):
+        got = buf.view(-1)[: h * w * c].float().view(h, w, c).permute(2, 0, 1).cpu().numpy()
+        ref = g[f'swin_x{i}']
+        got = got[:, ::2, ::2] if i < 2 else got
+        err = np.abs(got - ref).max() / (np.abs(ref).max() + 1e-6)
+        print(f'swin stage {i}: rel err {err:.4f}')
+        assert err < 0.04, (i, err)
+    # --- clip
+    gc, frames, mask, (former, latter, n, h, w, oh, ow, gap, objs) = _load('clip_swin.npz')
+    eng = build_engine(cfg.MODEL_ENGINE, phase='eval', aot_model=model, gpu_id=0, long_term_mem_gap=gap)
+    fd = frames.to(dev)
+    eng.add_reference_frame(fd[0:1], mask.to(dev), obj_nums=[objs], frame_step=0)
+    ys, xs = torch.from_numpy(gc['sample_y']).to(dev), torch.from_numpy(gc['sample_x']).to(dev)
+    samples, trace = [], []
+    for i in range(1, n):
+        logit = eng.match_propogate_one_frame(fd[i:i + 1], output_size=(oh, ow))
+        fed = torch.from_numpy(gc['labels'][i - 1].astype(np.float32)).to(dev)[None, None]
+        eng.update_memory(F.interpolate(fed, size=eng.input_size_2d, mode='nearest'))
+        samples.append(logit[0][:, ys, xs].cpu().numpy())
+        trace.append(list(eng.long_memories_indexes))
+    ref = gc['logit_samples']
+    err = np.abs(np.stack(samples) - ref).max()
+    print('swin clip: max |dlogit| =', err, ' logit std =', ref.std())
+    assert err < 0.1 * ref.std() + 0.05
+    assert (_trace_matrix(trace, gc['indexes']) == gc['indexes']).all()

@@ -317,3 +317,73 @@ def test_evict_scores(dev):
     ops.run(ops.evict_scores(lgn.to(dev), mass.to(dev), sc, ldl=16, nc=11, keep=10, Hi=25, Wi=33, He=7, We=9, T=5))
     torch.cuda.synchronize()
     assert_close(sc[:5], ref, 1e-4, 'evict scores')
+
+
+def test_layernorm_generic_and_patch_merge(dev, golden_ops):
+    from oracle import ref_cpu as O
+    from rmem_ocu_amd import ops
+    for C in (128, 256, 512, 1024):
+        a = seeded(300 + C, (333, C)) * 2 + 0.3
+        g, b = 1 + 0.1 * seeded(301, (C,)), 0.1 * seeded(302, (C,))
+        y = torch.zeros(333, C, dtype=BF16, device=dev)
+        yf = torch.zeros(333, C, dtype=F32, device=dev)
+        ops.run(ops.layernorm(a.to(dev), g.to(dev), b.to(dev), M=333, C=C, y=y, yf=yf))
+        torch.cuda.synchronize()
+        ref = F.layer_norm(a, (C,), g, b, 1e-5)
+        assert_close(yf, ref, 2e-5, f'ln{C} f32')
+        assert_close(y, ref, 1e-2, f'ln{C} bf16')
+    for C, (H, W) in ((128, (9, 11)), (256, (6, 8))):
+        x = seeded(310 + C, (1, H * W, C))
+        w = {'m.norm.weight': 1 + 0.1 * seeded(311, (4 * C,)), 'm.norm.bias': 0.1 * seeded(312, (4 * C,)),
+             'm.reduction.weight': torch.eye(2 * C, 4 * C)}
+        xp = x.view(1, H, W, C)
+        xp = F.pad(xp, (0, 0, 0, W % 2, 0, H % 2))
+        cat = torch.cat([xp[:, 0::2, 0::2], xp[:, 1::2, 0::2], xp[:, 0::2, 1::2], xp[:, 1::2, 1::2]], -1).view(-1, 4 * C)
+        ref = F.layer_norm(cat, (4 * C,), w['m.norm.weight'], w['m.norm.bias'], 1e-5)
+        y = torch.zeros(ref.shape[0], 4 * C, dtype=BF16, device=dev)
+        ops.run(ops.patch_merge_ln(x[0].to(dev), w['m.norm.weight'].to(dev), w['m.norm.bias'].to(dev), y, H=H, W=W, C=C))
+        torch.cuda.synchronize()
+        assert_close(y, ref, 1e-2, f'patch merge {C}')
+
+
+@pytest.mark.parametrize('H,W,heads,shift', [(24, 32, 4, 0), (24, 32, 4, 3), (12, 16, 8, 3), (6, 8, 16, 3), (7, 7, 4, 3), (45, 80, 16, 0)])
+def test_window_attention_vs_oracle(dev, H, W, heads, shift):
+    """a16: (shifted-)window attention incl. padding, roll, mask and relative-position bias against the oracle's
+    swin_block pieces (window partition / softmax / reverse on bf16-rounded qkv)."""
+    from oracle import ref_cpu as O
+    from rmem_ocu_amd import ops
+    from rmem_ocu_amd.pack import LOG2E, swin_window_masks
+    from rmem_ocu_amd.weights import swin_relative_position_index
+    C, ws = heads * 32, 7
+    L = H * W
+    qkv = rb(seeded(400 + H, (L, 3 * C)))
+    qkv_bias = seeded(401, (3 * C,), 0.3)
+    table = seeded(402, (169, heads), 0.5)
+    idx = swin_relative_position_index(7)
+    # oracle: qkv of padded tokens = bias; roll; partition; attention; reverse; unroll; crop
+    pr, pb = (ws - W % ws) % ws, (ws - H % ws) % ws
+    g = qkv.view(1, H, W, 3 * C)
+    Hp, Wp = H + pb, W + pr
+    full = rb(qkv_bias).view(1, 1, 1, -1).expand(1, Hp, Wp, 3 * C).clone()
+    full[:, :H, :W] = g
+    if shift:
+        full = torch.roll(full, shifts=(-shift, -shift), dims=(1, 2))
+    xw = O._win_part(full, ws)
+    B_, N = xw.shape[0], 49
+    q, k, v = xw.view(B_, N, 3, heads, 32).permute(2, 0, 3, 1, 4)
+    attn = (q * 32 ** -0.5) @ k.transpose(-2, -1) + table[idx.view(-1)].view(N, N, heads).permute(2, 0, 1).unsqueeze(0)
+    if shift:
+        mask = O.swin_shift_mask(H, W)
+        attn = (attn.view(1, B_, heads, N, N) + mask.unsqueeze(1).unsqueeze(0)).view(-1, heads, N, N)
+    o = (torch.softmax(attn, -1) @ v).transpose(1, 2).reshape(B_, N, C)
+    y = O._win_rev(o, ws, Hp, Wp)
+    if shift:
+        y = torch.roll(y, shifts=(shift, shift), dims=(1, 2))
+    ref = y[:, :H, :W].reshape(L, C)
+    # HIP
+    bias = table[idx.view(-1)].view(49, 49, heads).permute(2, 0, 1)
+    tbl = ((bias[None] + swin_window_masks()[:, None]) * LOG2E).contiguous().to(dev)
+    out = torch.zeros(L, C, dtype=BF16, device=dev)
+    ops.run(ops.window_attn(qkv.to(BF16).to(dev), rb(qkv_bias).to(dev), tbl, out, H=H, W=W, C=C, heads=heads, shift=shift))
+    torch.cuda.synchronize()
+    assert_close(out, ref, 2e-2, f'window attention {H}x{W} shift {shift}')
