@@ -17,6 +17,7 @@ adding or re-ordering keys never changes another tensor.
 from __future__ import annotations
 
 import math
+import os
 import zlib
 from collections import OrderedDict
 
@@ -179,4 +180,19 @@ def synth_state_dict(seed: int = 0, num_lstt: int = 3, d_model: int = 256,
     kid = 16 if swin else 17      # models/aot.py:67-82: k17 s16 p8 (align_corners) or k16 s16 p0
     sd['patch_wise_id_bank.weight'] = _normal(seed, 'patch_wise_id_bank.weight', (d_model, max_obj_num + 2, kid, kid), 1.0 / kid)
     sd['patch_wise_id_bank.bias'] = _normal(seed, 'patch_wise_id_bank.bias', (d_model,), 0.02)
+    return sd
+
+
+TRAINED_DELTA = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'golden', 'trained_delta.pt')
+
+
+def fitted_state_dict(seed: int = 0) -> "OrderedDict[str, torch.Tensor]":
+    """synth_state_dict(seed) with every non-encoder tensor replaced by the values fitted on synthetic clips
+    (tests/golden/train_synth_weights.py -> tests/golden/trained_delta.pt, bf16).  The random ResNet-50 stays; the LSTT,
+    decoder, identity bank and temporal PE were trained to propagate masks, so logits are confident ("trained-like")."""
+    sd = synth_state_dict(seed)
+    delta = torch.load(TRAINED_DELTA, map_location='cpu')
+    for k, v in delta.items():
+        assert k in sd and sd[k].shape == v.shape, k
+        sd[k] = v.float()
     return sd

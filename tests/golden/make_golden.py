@@ -35,7 +35,7 @@ from rmem_ocu_amd.synth import make_clip  # noqa: E402
 from rmem_ocu_amd.weights import synth_state_dict  # noqa: E402
 
 
-def load_reference(former=1, latter=7, encoder='resnet50'):
+def load_reference(former=1, latter=7, encoder='resnet50', fitted=False):
     sys.path.insert(0, REF)
     tml = types.ModuleType('timm.models.layers')
     tml.trunc_normal_ = lambda t, mean=0., std=1., a=-2., b=2.: torch.nn.init.trunc_normal_(t, mean=mean, std=std, a=a, b=b)
@@ -74,7 +74,8 @@ def load_reference(former=1, latter=7, encoder='resnet50'):
     from networks.models import build_vos_model
     from networks.engines import build_engine
     model = build_vos_model(cfg.MODEL_VOS, cfg).eval()
-    missing = model.load_state_dict(synth_state_dict(0, encoder=encoder), strict=True)
+    from rmem_ocu_amd.weights import fitted_state_dict
+    missing = model.load_state_dict(fitted_state_dict(0) if fitted else synth_state_dict(0, encoder=encoder), strict=True)
     assert not missing.missing_keys and not missing.unexpected_keys
     return cfg, model, build_engine
 
@@ -215,8 +216,8 @@ def gen_swin_ops():
     return out
 
 
-def gen_clip(tag, former, latter, n_frames, h, w, out_hw, gap, objs, seed, inject_at=-1, encoder='resnet50'):
-    cfg, model, build_engine = load_reference(former, latter, encoder)
+def gen_clip(tag, former, latter, n_frames, h, w, out_hw, gap, objs, seed, inject_at=-1, encoder='resnet50', fitted=False):
+    cfg, model, build_engine = load_reference(former, latter, encoder, fitted)
     frames, mask = make_clip(seed, n_frames, h, w, objs)
     ys = np.linspace(2, out_hw[0] - 3, 12).astype(np.int64)
     xs = np.linspace(2, out_hw[1] - 3, 12).astype(np.int64)
@@ -261,6 +262,13 @@ if __name__ == '__main__':
         # SwinB-AOTL clip: align_corners False -> network size multiple of 16 (video_transforms.py:616-622), id bank k16 s16
         np.savez_compressed(os.path.join(HERE, 'clip_swin.npz'),
                             **gen_clip('swin', 1, 2, 16, 160, 192, (160, 192), 2, 2, 61, encoder='swin_base'))
+    if what in ('fitted', 'all'):
+        # the same two geometries with the FITTED weights (tests/golden/train_synth_weights.py): confident masks, so
+        # mask IoU is a meaningful parity measure
+        np.savez_compressed(os.path.join(HERE, 'clip_small_fitted.npz'),
+                            **gen_clip('small_fitted', 1, 2, 48, 161, 193, (160, 192), 2, 3, 11, fitted=True))
+        np.savez_compressed(os.path.join(HERE, 'clip_full_fitted.npz'),
+                            **gen_clip('full_fitted', 1, 7, 30, 481, 849, (480, 854), 2, 3, 21, fitted=True))
     if what in ('full', 'all'):
         # cfg-2 geometry: 480x854 video at network size 481x849, bank N = 8, gap 2 so the bank fills
         # by frame 14 and evicts from frame 16

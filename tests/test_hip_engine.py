@@ -32,13 +32,13 @@ def _load(name):
     return g, frames, mask, (former, latter, n, h, w, oh, ow, gap, objs)
 
 
-def _engine(former, latter, gap):
+def _engine(former, latter, gap, fitted=False):
     from rmem_ocu_amd import build_engine, build_vos_model, get_config
-    from rmem_ocu_amd.weights import synth_state_dict
+    from rmem_ocu_amd.weights import fitted_state_dict, synth_state_dict
     cfg = get_config('pre_vost', 'test', 'r50_aotl')
     cfg.FORMER_MEM_LEN, cfg.LATTER_MEM_LEN = former, latter
     model = build_vos_model(cfg.MODEL_VOS, cfg).cuda(0)
-    model.load_state_dict(synth_state_dict(0))
+    model.load_state_dict(fitted_state_dict(0) if fitted else synth_state_dict(0))
     eng = build_engine(cfg.MODEL_ENGINE, phase='eval', aot_model=model, gpu_id=0, long_term_mem_gap=gap)
     eng.eval()
     return eng
@@ -47,7 +47,7 @@ def _engine(former, latter, gap):
 def _run(name, teacher_forced, use_graphs=False):
     g, frames, mask, (former, latter, n, h, w, oh, ow, gap, objs) = _load(name)
     inject_at = int(g['inject_at']) if 'inject_at' in g.files else -1
-    eng = _engine(former, latter, gap)
+    eng = _engine(former, latter, gap, fitted='fitted' in name)
     eng.use_graphs = use_graphs
     dev = torch.device('cuda', 0)
     frames_d = frames.to(dev)
@@ -220,3 +220,29 @@ def test_swin_encoder_and_clip():
     print('swin clip: max |dlogit| =', err, ' logit std =', ref.std())
     assert err < 0.1 * ref.std() + 0.05
     assert (_trace_matrix(trace, gc['indexes']) == gc['indexes']).all()
+
+
+@pytest.mark.parametrize('name', ['clip_small_fitted.npz', 'clip_full_fitted.npz'])
+def test_fitted_weights_mask_iou(name):
+    """Mask parity with the fitted ("trained-like") weights, where the reference's masks are confident.
+    Per-frame (teacher-forced: the reference's mask of frame i-1 is fed back, so every frame is an independent comparison of
+    the same computation): mean IoU over object ids and frames must be >= 0.99 and the eviction trace identical.
+    Free-running (own masks fed back for the whole clip) is reported and loosely bounded: with these weights the reference
+    itself tracks the synthetic objects poorly (80 % agreement with ground truth), so small bf16 differences at mask
+    borders are amplified frame over frame; the north-star 0.999 figure is for trained DAVIS weights (unavailable offline)."""
+    if not os.path.exists(os.path.join(GOLDEN, 'trained_delta.pt')):
+        pytest.skip('tests/golden/trained_delta.pt missing (python tests/golden/train_synth_weights.py)')
+    g, labels, samples, trace = _run(name, True, use_graphs=True)
+    ious = [_iou(a, b) for a, b in zip(g['labels'], labels)]
+    agree = (labels == g['labels']).mean(axis=(1, 2))
+    ref = g['logit_samples']
+    print(f'{name} teacher-forced: mean IoU {np.mean(ious):.5f} min IoU {np.min(ious):.5f}  label agreement {agree.mean():.5f}  '
+          f'max |dlogit| {np.abs(samples - ref).max():.3f} at logit std {ref.std():.2f}')
+    assert (_trace_matrix(trace, g['indexes']) == g['indexes']).all()
+    assert np.mean(ious) >= 0.99 and agree.mean() >= 0.998
+    g, labels, samples, trace = _run(name, False, use_graphs=True)
+    ious = [_iou(a, b) for a, b in zip(g['labels'], labels)]
+    agree = (labels == g['labels']).mean(axis=(1, 2))
+    print(f'{name} free-running: mean IoU {np.mean(ious):.5f} first-frame IoU {ious[0]:.5f} last-frame IoU {ious[-1]:.5f}  '
+          f'label agreement {agree.mean():.5f}')
+    assert ious[0] >= 0.985 and agree.mean() >= 0.9

@@ -101,8 +101,12 @@ def _run_clip(name):
     assert hashlib.sha256(frames.numpy().tobytes()).hexdigest() == str(g['frames_sha'])
     from rmem_ocu_amd.weights import synth_state_dict
     swin = 'swin' in name
-    eng = O.OracleEngine(synth_state_dict(0, encoder='swin_base' if swin else 'resnet50'), former, latter, gap,
-                         align_corners=not swin)
+    if 'fitted' in name:
+        from rmem_ocu_amd.weights import fitted_state_dict
+        weights = fitted_state_dict(0)
+    else:
+        weights = synth_state_dict(0, encoder='swin_base' if swin else 'resnet50')
+    eng = O.OracleEngine(weights, former, latter, gap, align_corners=not swin)
     trace, labels, samples = [], [], []
     eng.long_term_mem_gap = gap
     eng.add_reference_frame(frames[0:1], mask, 0)
@@ -188,3 +192,8 @@ def test_swin_encoder_matches_reference():
 def test_swin_clip_matches_reference():
     """cfg-5 model (SwinB-AOTL, align_corners False, id bank k16 s16) through the engine protocol."""
     _check_clip('clip_swin.npz')
+
+
+def test_fitted_small_clip_matches_reference():
+    """The oracle with the fitted ("trained-like") weights against the reference's free-running clip."""
+    _check_clip('clip_small_fitted.npz')
