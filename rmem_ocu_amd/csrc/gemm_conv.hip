@@ -285,6 +285,162 @@ __global__ __launch_bounds__(256) void k_conv_gemm(ConvParams p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// LDS-DMA variant of the 64x64 tile (the one every shape of this path uses).  Global -> LDS goes through
+// global_load_lds_dwordx4 (no VGPR staging, no ds_write: the ~79 B/clk ds_write path was the per-k-step bottleneck of the
+// register-staged kernel).  Each wave-instruction fills 8 rows x 128 B of the tile linearly, so the XOR swizzle is
+// applied to the per-lane SOURCE address; padded / out-of-range pieces read a 16-byte zero buffer.  3-deep LDS ring,
+// two tiles in flight, counted vmcnt + raw s_barrier (one barrier per k-step, DMA stays in flight across it).
+__device__ uint4 g_zero16[1];
+
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <bool IS1X1, bool SPLITK>
+__global__ __launch_bounds__(256) void k_conv_gemm_dma(ConvParams p) {
+  constexpr int BM = 64, BN = 64, BK = 64, ST = 3, TM = 2, TN = 2;
+  constexpr int CP = BN + 4;
+  constexpr int STAGE_BYTES = (BM + BN) * BK * 2;
+  __shared__ __attribute__((aligned(16))) char smem[ST * STAGE_BYTES];   // the ONLY shared object (epilogue staging aliases it)
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int nk_total = (p.K + BK - 1) / BK;
+  const int kt0 = SPLITK ? blockIdx.z * p.steps_per_split : 0;
+  const int kt1 = SPLITK ? min(nk_total, kt0 + p.steps_per_split) : nk_total;
+
+  // this lane's two (row, chunk) pieces of the A tile and of the B tile: instruction i covers rows 16*wave + 8*i .. +7
+  int a_c[2], a_hi0[2], a_wi0[2], a_ci[2], a_kw[2], a_kh[2];
+  long a_base[2];
+  bool a_ok[2], b_ok[2];
+  long b_base[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = 16 * wave + 8 * i + (lane >> 3);
+    a_c[i] = (lane & 7) ^ ((r >> 1) & 7);              // logical chunk that belongs in physical slot (lane & 7) of row r
+    const int m = m0 + r;
+    a_ok[i] = m < p.M;
+    if (IS1X1) {
+      a_base[i] = (long)m * p.Cin;
+      a_hi0[i] = a_wi0[i] = a_ci[i] = a_kw[i] = a_kh[i] = 0;
+    } else {
+      const int ho = m / p.Wo, wo = m - ho * p.Wo;
+      a_hi0[i] = ho * p.stride - p.pad;
+      a_wi0[i] = wo * p.stride - p.pad;
+      a_base[i] = 0;
+      const int kidx = kt0 * BK + a_c[i] * 8;
+      const int kk = kidx / p.Cin;
+      a_ci[i] = kidx - kk * p.Cin;
+      a_kh[i] = kk / p.KW;
+      a_kw[i] = kk - a_kh[i] * p.KW;
+    }
+    const int n = n0 + r;
+    b_ok[i] = n < p.Cout;
+    b_base[i] = (long)n * p.K;
+  }
+  const char* zero = reinterpret_cast<const char*>(g_zero16);
+
+  auto issue = [&](int kt, int stage) {
+    char* As = smem + stage * STAGE_BYTES;
+    char* Bs = As + BM * BK * 2;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const char* src = zero;
+      if (IS1X1) {
+        const int kidx = kt * BK + a_c[i] * 8;
+        if (a_ok[i] && kidx < p.K) src = reinterpret_cast<const char*>(p.x + a_base[i] + kidx);
+      } else {
+        const int hi = a_hi0[i] + a_kh[i], wi = a_wi0[i] + a_kw[i];
+        if (a_ok[i] && a_kh[i] < p.KH && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W)
+          src = reinterpret_cast<const char*>(p.x + ((long)hi * p.W + wi) * p.Cin + a_ci[i]);
+        a_ci[i] += BK;
+        while (a_ci[i] >= p.Cin) {
+          a_ci[i] -= p.Cin;
+          if (++a_kw[i] == p.KW) { a_kw[i] = 0; ++a_kh[i]; }
+        }
+      }
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(As + (16 * wave + 8 * i) * 128), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int kidx = kt * BK + a_c[i] * 8;
+      const char* src = (b_ok[i] && kidx < p.K) ? reinterpret_cast<const char*>(p.w + b_base[i] + kidx) : zero;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Bs + (16 * wave + 8 * i) * 128), 16, 0, 0);
+    }
+  };
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int fr = lane & 15, fc = lane >> 4;
+  if (kt0 < kt1) issue(kt0, 0);
+  if (kt0 + 1 < kt1) issue(kt0 + 1, 1);
+  int stage = 0;
+  for (int kt = kt0; kt < kt1; ++kt) {
+    // tile kt has landed once at most the 4 DMA pieces of tile kt+1 are still outstanding for this wave
+    if (kt + 1 < kt1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                     // everyone's pieces of tile kt landed; everyone finished reading tile kt-1
+    const int nxt = stage == 0 ? 2 : stage - 1;       // slot of tile kt+2 == slot of tile kt-1
+    if (kt + 2 < kt1) issue(kt + 2, nxt);
+    const bf16* As = reinterpret_cast<const bf16*>(smem + stage * STAGE_BYTES);
+    const bf16* Bs = As + BM * BK;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 af[TM], bfr[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(&As[swz(wm * 32 + i * 16 + fr, 4 * ks + fc)]);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(&Bs[swz(wn * 32 + j * 16 + fr, 4 * ks + fc)]);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+    stage = stage == 2 ? 0 : stage + 1;
+  }
+  __syncthreads();                                     // all DMA drained (vmcnt(0) above) and all fragment reads done
+
+  float* Cs = reinterpret_cast<float*>(smem);
+  constexpr int VPR = BN / 8;
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    if (wm == pass) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) Cs[(i * 16 + fc * 4 + r) * CP + wn * 32 + j * 16 + fr] = acc[i][j][r];
+    }
+    __syncthreads();
+    for (int vi = tid; vi < (BM / 2) * VPR; vi += 256) {
+      const int row = vi / VPR, cv = vi - row * VPR;
+      const int m = m0 + pass * (BM / 2) + row;
+      const int n = n0 + cv * 8;
+      if (m >= p.M || n >= p.Cout) continue;
+      const float* c = Cs + row * CP + cv * 8;
+      const f32x4 c0 = *reinterpret_cast<const f32x4*>(c), c1 = *reinterpret_cast<const f32x4*>(c + 4);
+      float v[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
+      if (SPLITK) {
+        float* s = p.slabs + ((long)blockIdx.z * p.M + m) * p.Cout + n;
+        *reinterpret_cast<f32x4*>(s) = c0;
+        *reinterpret_cast<f32x4*>(s + 4) = c1;
+      } else if (p.vec_ok && n + 8 <= p.Cout) {
+        finish8(p, m, n, v);
+      } else {
+        for (int j = 0; j < 8 && n + j < p.Cout; ++j) finish1(p, m, n + j, v[j]);
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // sum the split-K slabs in slice order and apply the fused epilogue; thread = 8 channels of one row
 __global__ __launch_bounds__(256) void k_splitk_epilogue(ConvParams p, int splits) {
   const int vpr = p.Cout / 8;
@@ -307,6 +463,19 @@ __global__ __launch_bounds__(256) void k_splitk_epilogue(ConvParams p, int split
 template <int BM, int BN, int PF>
 void launch(const ConvParams& p, bool is1x1, int splits, hipStream_t s) {
   dim3 grid((p.M + BM - 1) / BM, (p.Cout + BN - 1) / BN, splits);
+  static const bool use_dma = !(getenv("RMEM_GEMM_DMA") && atoi(getenv("RMEM_GEMM_DMA")) == 0);   // kernel experiments only
+  if (BM == 64 && BN == 64 && use_dma) {
+    if (splits > 1) {
+      if (is1x1) hipLaunchKernelGGL((k_conv_gemm_dma<true, true>), grid, dim3(256), 0, s, p);
+      else hipLaunchKernelGGL((k_conv_gemm_dma<false, true>), grid, dim3(256), 0, s, p);
+      const long total = (long)p.M * (p.Cout / 8);
+      hipLaunchKernelGGL(k_splitk_epilogue, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p, splits);
+    } else {
+      if (is1x1) hipLaunchKernelGGL((k_conv_gemm_dma<true, false>), grid, dim3(256), 0, s, p);
+      else hipLaunchKernelGGL((k_conv_gemm_dma<false, false>), grid, dim3(256), 0, s, p);
+    }
+    return;
+  }
   if (splits > 1) {
     if (is1x1) hipLaunchKernelGGL((k_conv_gemm<BM, BN, PF, true, true>), grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL((k_conv_gemm<BM, BN, PF, false, true>), grid, dim3(256), 0, s, p);
