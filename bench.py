@@ -86,12 +86,20 @@ def main():
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: there is no CPU execution path for the product')
+    ndev = torch.cuda.device_count()
+    if local_rank >= ndev and not os.environ.get('RMEM_SHARE_GPU'):
+        raise SystemExit(f'rank {rank}: LOCAL_RANK {local_rank} but only {ndev} GPU(s) visible')
+    local_rank %= ndev                      # RMEM_SHARE_GPU=1: rehearse the N > 1 code path on fewer GPUs (gloo backend)
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=dev)
+        backend = os.environ.get('RMEM_DIST_BACKEND', 'nccl')       # nccl == RCCL over xGMI on ROCm
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from rmem_ocu_amd import _lib, build_engine, build_vos_model, get_config
     from rmem_ocu_amd.clip_runner import ClipSlot
@@ -175,7 +183,8 @@ def main():
 
     checksum = float(sum(int(s.labels.sum().item()) for s in slots))
     from rmem_ocu_amd.clip_runner import gather_stats
-    agg = gather_stats(float(args.steps), elapsed, checksum, dist, rank, world, dev)   # the one data exchange: 24 bytes per rank
+    gdev = dev if (dist is None or dist.get_backend() == 'nccl') else torch.device('cpu')
+    agg = gather_stats(float(args.steps), elapsed, checksum, dist, rank, world, gdev)   # the one data exchange: 24 bytes per rank
     if rank == 0:
         total_steps, elapsed, _ = agg
 

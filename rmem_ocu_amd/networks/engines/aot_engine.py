@@ -16,6 +16,7 @@ layers/transformer.py:641); the attention-weight top-32 D2H of every layer
 from __future__ import annotations
 
 import contextlib
+import os
 from typing import Dict, List, Optional
 
 import numpy as np
@@ -140,6 +141,9 @@ class AOTEngine:
     def _run(self, key: str, prog: list):
         """Enqueue a launch list on the engine's stream: directly, or (use_graphs) as ONE hipGraph per key."""
         s = self._stream()
+        ab = os.environ.get('RMEM_ABLATE')           # timing experiments only: drop every launch whose name contains the tag
+        if ab:
+            prog = [o for o in prog if not any(t in o.name + ':' + getattr(o, 'tag', '') for t in ab.split(','))]
         if self.use_graphs:
             key = f'{key}@{self.rt.bank_generation}'
             g = self._graphs.get(key)
