@@ -68,6 +68,17 @@ def cpu_baseline(frames, mask, n_timed=8):
             'sample': f'{n_timed} propagated frames at 481x849, bank T=8 (steady state of the 80-frame clip), fp32, after 9 untimed frames'}
 
 
+def pmc_traffic():
+    """HBM bytes per T = 8 launch of the memory-read kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE in separate runs, gfx950 FETCH correction applied): profiles/r01/attn_pmc.json.  bench.py cannot collect
+    counters itself; the figure is per launch like `achieved`."""
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'r01', 'attn_pmc.json')) as f:
+            return json.load(f)['hbm_bytes_per_launch']
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -200,7 +211,7 @@ def main():
                        'hipgraphs': not args.no_graphs, 'host_enqueue_ms_per_step': round(1e3 * host_enqueue / args.steps, 4)},
             'roofline': {'bound': 'mfma', 'kernel': 'k_attn_partial<true, true>', 'achieved': None if achieved is None else round(achieved, 2),
                          'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': None if achieved is None else round(achieved / PEAK_BF16_TFLOPS, 4),
-                         'traffic': None, 'launches_timed': nl.value,
+                         'traffic': pmc_traffic(), 'launches_timed': nl.value,
                          'avg_launch_us': None if not nl.value else round(1e3 * ms.value / nl.value, 2)},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -45,7 +45,7 @@ struct AttnParams {
   const bf16* k; const bf16* v; long slot_stride; int ldkv;
   const rmem_attn_chunk* chunks; int nchunks; int lk; int per_chunk;
   const float* pe_cur; const float* pe_mem;
-  int Lq, heads, C;
+  int Lq, heads, C, nq;
   float* opart; float* ml;
   float qscale;
 };
@@ -76,7 +76,20 @@ __global__ __launch_bounds__(256) void k_attn_partial(AttnParams p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lq = lane & 31, lh = lane >> 5;
-  const int head = blockIdx.y, c = blockIdx.z;
+  // XCD-aware decode of the 1-D grid: hardware deals consecutive block ids round-robin over the 8 XCDs (private 4 MiB
+  // L2 each), so ids that are congruent mod 8 are made to walk (head, chunk) pairs contiguously -- all query tiles that
+  // read the same K/V chunk run on one XCD and share its L2 (speed only; any placement is correct).
+  int qt, head, c;
+  {
+    const int nq = p.nq, total = nq * p.heads * p.nchunks;
+    const int b = blockIdx.x, xcd = b & 7, j = b >> 3;
+    const int qd = total >> 3, rm = total & 7;
+    const int idx = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + j;
+    const int pair = idx / nq;
+    qt = idx - pair * nq;
+    head = pair % p.heads;
+    c = pair / p.heads;
+  }
 
   int slot, kb, kn, pe_slot;
   if (MEM) {
@@ -89,7 +102,7 @@ __global__ __launch_bounds__(256) void k_attn_partial(AttnParams p) {
   const bf16* Vp = p.v + (long)slot * p.slot_stride + head * D;
 
   // ---- Q^T fragment (B operand) and the temporal-PE logit bias ----
-  const int qrow = min(blockIdx.x * 128 + wave * 32 + lq, p.Lq - 1);
+  const int qrow = min(qt * 128 + wave * 32 + lq, p.Lq - 1);
   bf16x8 qf[2];
   float bias = 0.f;
   const bool has_cur = MEM && p.pe_cur != nullptr;        // workgroup-uniform
@@ -217,7 +230,7 @@ __global__ __launch_bounds__(256) void k_attn_partial(AttnParams p) {
     __syncthreads();
   }
 
-  const int qg = blockIdx.x * 128 + wave * 32 + lq;
+  const int qg = qt * 128 + wave * 32 + lq;
   if (qg < p.Lq) {
     // partial O layout [chunk][head][G = d / 4][q] x float4: a half-wave stores 512 contiguous bytes per instruction
     const long ch = (long)c * p.heads + head;
@@ -393,7 +406,8 @@ extern "C" int rmem_mem_read_attn(const void* q, int ldq, const void* k_bank, co
   p.pe_cur = pe_cur; p.pe_mem = pe_mem; p.Lq = Lq; p.heads = heads; p.C = heads * D;
   p.opart = (float*)workspace; p.ml = p.opart + (size_t)nchunks * heads * Lq * D;
   p.qscale = 1.4426950408889634f / sqrtf((float)D);
-  dim3 grid((Lq + 127) / 128, heads, nchunks);
+  p.nq = (Lq + 127) / 128;
+  dim3 grid(p.nq * heads * nchunks);
   if (chunks) {
     // time this launch if asked to (never while the stream is being captured into a graph)
     long slot_i = -1;
