@@ -43,6 +43,12 @@ CLIP_LEN = 80
 VIDEO_HW = (480, 854)
 NUM_OBJS = 3
 PEAK_BF16_TFLOPS = 2500.0
+# --workload: the default is BASELINE.json's cfg 2 (the line the driver records); the others are extra measurements
+WORKLOADS = {
+    'davis17_480p_r50_N8': dict(model='r50_aotl', video=(480, 854), clip=80, objs=3, former=1, latter=7, net=None),
+    # cfg 5 geometry: 720p, Swin-B, bank N = 12 (1 + 11), align_corners False -> network size = video size (multiple of 16)
+    'lvos_720p_swinb_N12': dict(model='swinb_aotl', video=(720, 1280), clip=150, objs=2, former=1, latter=11, net=(720, 1280)),
+}
 
 
 def cpu_baseline(frames, mask, n_timed=8):
@@ -86,6 +92,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=79)
     ap.add_argument('--clips-in-flight', type=int, default=int(os.environ.get('RMEM_CLIPS_IN_FLIGHT', 16)))
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--workload', default='davis17_480p_r50_N8', choices=sorted(WORKLOADS))
     ap.add_argument('--no-graphs', action='store_true')
     ap.add_argument('--sample-every', type=int, default=100, help='time the memory-read kernel on 1 in N timed frames (run in isolation)')
     args = ap.parse_args()
@@ -117,11 +124,14 @@ def main():
     from rmem_ocu_amd.synth import make_clip, network_size
     from rmem_ocu_amd.weights import synth_state_dict
 
-    cfg = get_config('pre_vost', 'bench', 'r50_aotl')
-    cfg.FORMER_MEM_LEN, cfg.LATTER_MEM_LEN = 1, 7
+    global CLIP_LEN, VIDEO_HW, NUM_OBJS
+    wl = WORKLOADS[args.workload]
+    CLIP_LEN, VIDEO_HW, NUM_OBJS = wl['clip'], wl['video'], wl['objs']
+    cfg = get_config('pre_vost', 'bench', wl['model'])
+    cfg.FORMER_MEM_LEN, cfg.LATTER_MEM_LEN = wl['former'], wl['latter']
     model = build_vos_model(cfg.MODEL_VOS, cfg).cuda(local_rank)
-    model.load_state_dict(synth_state_dict(0))
-    net_hw = network_size(*VIDEO_HW)
+    model.load_state_dict(synth_state_dict(0, encoder=cfg.MODEL_ENCODER))
+    net_hw = wl['net'] or network_size(*VIDEO_HW)
 
     # two distinct synthetic clips per rank, reused round-robin by the clip slots
     clips_host = [make_clip(1000 * rank + j, CLIP_LEN, net_hw[0], net_hw[1], NUM_OBJS) for j in range(2)]
@@ -202,19 +212,21 @@ def main():
     if rank == 0:
         achieved = (fl.value / (ms.value * 1e-3)) / 1e12 if nl.value and ms.value > 0 else None
         out = {
-            'metric': 'frames/sec (whole node) 480p VOS, N=8 memory bank', 'value': round(total_steps / elapsed, 2), 'unit': 'frames/s',
+            'metric': 'frames/sec (whole node) 480p VOS, N=8 memory bank' if args.workload == 'davis17_480p_r50_N8'
+            else f'frames/sec (whole node) {args.workload}', 'value': round(total_steps / elapsed, 2), 'unit': 'frames/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * elapsed / args.steps, 4),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
-            'config': {'workload': 'davis17_480p_r50_N8', 'clip_frames': CLIP_LEN, 'video_hw': list(VIDEO_HW), 'network_hw': list(net_hw),
-                       'tokens': 1674, 'objects': NUM_OBJS, 'memory_bank': '1+7', 'gap': 5, 'clips_in_flight_per_gpu': C,
+            'config': {'workload': args.workload, 'clip_frames': CLIP_LEN, 'video_hw': list(VIDEO_HW), 'network_hw': list(net_hw),
+                       'tokens': (net_hw[0] // 16 if wl['net'] else 31) * (net_hw[1] // 16 if wl['net'] else 54), 'objects': NUM_OBJS,
+                       'memory_bank': f"{wl['former']}+{wl['latter']}", 'gap': max(int(round(CLIP_LEN / 30)), 5), 'clips_in_flight_per_gpu': C,
                        'parallelism': f'clip-parallel x{world}', 'weights': 'synthetic (no checkpoint offline)',
                        'hipgraphs': not args.no_graphs, 'host_enqueue_ms_per_step': round(1e3 * host_enqueue / args.steps, 4)},
             'roofline': {'bound': 'mfma', 'kernel': 'k_attn_partial<true, true>', 'achieved': None if achieved is None else round(achieved, 2),
                          'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': None if achieved is None else round(achieved / PEAK_BF16_TFLOPS, 4),
-                         'traffic': pmc_traffic(), 'launches_timed': nl.value,
+                         'traffic': pmc_traffic() if args.workload == 'davis17_480p_r50_N8' else None, 'launches_timed': nl.value,
                          'avg_launch_us': None if not nl.value else round(1e3 * ms.value / nl.value, 2)},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload == 'davis17_480p_r50_N8':
             out['cpu_baseline'] = cpu_baseline(*clips_host[0])
         else:
             out['cpu_baseline'] = None

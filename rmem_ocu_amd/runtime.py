@@ -211,10 +211,14 @@ class ClipRuntime:
 
     # ------------------------------------------------------------------ programs
     def _conv(self, *a, **kw):
-        return ops.conv2d(*a, ws=self.conv_ws, **kw)
+        return ops.conv2d(*a, ws=self._ws(), **kw)
+
+    def _ws(self):
+        import os
+        return None if os.environ.get('RMEM_NO_SPLITK') else self.conv_ws
 
     def _lin(self, x, name, y, M, K, N, **kw):
-        return ops.linear(x, self.P[name + '.w'], self.P[name + '.b'], y, M=M, K=K, N=N, ws=self.conv_ws, **kw)
+        return ops.linear(x, self.P[name + '.w'], self.P[name + '.b'], y, M=M, K=K, N=N, ws=self._ws(), **kw)
 
     def _prog_encode_swin(self, img: torch.Tensor) -> list:
         """Swin-B: patch embed + LN, 3 stages of (shifted-)window blocks, patch merging, per-stage output norms."""
