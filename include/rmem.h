@@ -169,6 +169,18 @@ int rmem_evict_scores(const float* logits_nhwc, int ldl, int num_classes, int ke
  * Capturable into a hipGraph (memcpy node). */
 int rmem_copy_async(void* dst, const void* src, size_t bytes, void* stream);
 
+/* Test-time-augmentation merge: softmax of each augmentation's NCHW logits (read horizontally flipped where flips[a] != 0),
+ * mean over the <= 4 augmentations, argmax; writes any of uint8 labels, fp32 labels, NCHW mean probabilities.
+ * logits_nchw / flips are HOST arrays of n_aug entries.  Replaces managers/evaluator.py:427-441 (flip / multi-scale TTA). */
+int rmem_tta_merge(const float* const* logits_nchw, const int* flips, int n_aug, int num_classes, int H, int W,
+                   unsigned char* label_u8, float* label_f32, float* prob_nchw, void* stream);
+
+/* Region-similarity (Jaccard) counts per object id for one mask pair: counts[2*id] += |pred==id & gt==id|,
+ * counts[2*id+1] += |pred==id | gt==id| over the n pixels whose ground truth is not `void_label`; the caller zeroes
+ * counts (uint64 [2 * num_ids]).  Replaces evaluation/source/metrics.py:6-37 (db_eval_iou) per object. */
+int rmem_mask_iou_counts(const unsigned char* pred, const unsigned char* gt, long long n, int num_ids, int void_label,
+                         unsigned long long* counts, void* stream);
+
 /* ------------------------------------------------------------------ stream capture helpers
  * Thin wrappers over hipStreamBeginCapture / hipGraphInstantiate / hipGraphLaunch so the Python host
  * can replay one frame's launch sequence as a hipGraph. */

@@ -582,6 +582,39 @@ def run_clip(engine: OracleEngine, frames: Sequence[Tensor], first_mask: Tensor,
     return labels, all_logits
 
 
+def evaluate_sequence(weights: W, frames: Tensor, labels: Dict[int, Tensor], out_hw, former=1, latter=7, flip=False):
+    """managers/evaluator.py:330-523 for one sequence (gap heuristic, flip TTA with probability averaging, new-object
+    reference frames, memory update), on OracleInferEngine(s).  Returns (label maps, mean probabilities) per frame > 0."""
+    n = frames.shape[0]
+    gap = max(int(round(n / 30)), 5)
+    augs = [False, True] if flip else [False]
+    net_hw = tuple(frames.shape[2:])
+    engines = [OracleInferEngine(weights, former, latter, gap) for _ in augs]
+    for e, fl in zip(engines, augs):
+        lab = F.interpolate(labels[0], size=net_hw, mode='nearest')
+        e.add_reference_frame(frames[0:1].flip(3) if fl else frames[0:1], lab.flip(3) if fl else lab, int(labels[0].max()), 0)
+    outs, probs = [], []
+    for t in range(1, n):
+        ps = []
+        for e, fl in zip(engines, augs):
+            lg = e.match_propogate_one_frame(frames[t:t + 1].flip(3) if fl else frames[t:t + 1], out_hw)
+            ps.append(torch.softmax(lg.flip(3) if fl else lg, dim=1))
+        prob = torch.mean(torch.cat(ps, 0), dim=0, keepdim=True)
+        label = torch.argmax(prob, dim=1, keepdim=True).float()
+        if t in labels:
+            keep = (labels[t] == 0).float()
+            label = label * keep + labels[t] * (1 - keep)
+            for e, fl in zip(engines, augs):
+                lab = F.interpolate(label.flip(3) if fl else label, size=e.input_size_2d, mode='nearest')
+                e.add_reference_frame(frames[t:t + 1].flip(3) if fl else frames[t:t + 1], lab, int(label.max()), t)
+        else:
+            for e, fl in zip(engines, augs):
+                e.update_memory(F.interpolate(label.flip(3) if fl else label, size=e.input_size_2d, mode='nearest'))
+        outs.append(label[0, 0].to(torch.uint8))
+        probs.append(prob)
+    return outs, probs
+
+
 def db_eval_iou(annotation: np.ndarray, segmentation: np.ndarray) -> float:
     """evaluation/source/metrics.py:6-37 (single frame, no void)."""
     a = annotation.astype(bool)

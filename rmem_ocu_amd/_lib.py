@@ -53,6 +53,8 @@ SIGNATURES = {
     'rmem_logits_post': (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     'rmem_label_to_onehot16': (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     'rmem_evict_scores': (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp]),
+    'rmem_tta_merge': (_i, [C.POINTER(_vp), C.POINTER(_i), _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    'rmem_mask_iou_counts': (_i, [_vp, _vp, _ll, _i, _i, _vp, _vp]),
     'rmem_copy_async': (_i, [_vp, _vp, C.c_size_t, _vp]),
     'rmem_graph_begin': (_i, [_vp]),
     'rmem_graph_end': (_i, [_vp, C.POINTER(_vp)]),

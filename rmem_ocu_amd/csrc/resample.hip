@@ -188,6 +188,64 @@ __global__ void k_evict_final(const float* partial, int nblocks, int T, float* s
   }
 }
 
+// test-time augmentation merge (managers/evaluator.py:427-441): softmax of every augmentation's logits (horizontally
+// flipped back where that augmentation was flipped), mean over augmentations, argmax.  logits: up to 4 NCHW fp32 maps.
+struct TtaParams { const float* lg[4]; int flip[4]; int n_aug, nc, H, W; uint8_t* label; float* label_f32; float* prob; };
+
+__global__ __launch_bounds__(256) void k_tta_merge(TtaParams p) {
+  const long total = (long)p.H * p.W;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int y = (int)(i / p.W), x = (int)(i - (long)y * p.W);
+  float acc[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) acc[c] = 0.f;
+  for (int a = 0; a < p.n_aug; ++a) {
+    const long src = (long)y * p.W + (p.flip[a] ? p.W - 1 - x : x);
+    float v[16], mx = -3.0e38f, den = 0.f;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) { v[c] = c < p.nc ? p.lg[a][(long)c * total + src] : -3.0e38f; mx = fmaxf(mx, v[c]); }
+#pragma unroll
+    for (int c = 0; c < 16; ++c) { v[c] = c < p.nc ? expf(v[c] - mx) : 0.f; den += v[c]; }
+    const float inv = 1.f / den;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) acc[c] += v[c] * inv;
+  }
+  const float sc = 1.f / (float)p.n_aug;
+  float best = -1.f; int arg = 0;
+#pragma unroll
+  for (int c = 0; c < 16; ++c) {
+    if (c < p.nc) {
+      const float pr = acc[c] * sc;
+      if (p.prob) p.prob[(long)c * total + i] = pr;
+      if (pr > best) { best = pr; arg = c; }
+    }
+  }
+  if (p.label) p.label[i] = (uint8_t)arg;
+  if (p.label_f32) p.label_f32[i] = (float)arg;
+}
+
+// Jaccard counts per object id (evaluation/source/metrics.py:6-37 applied per id): counts[id] = {|pred == id & gt == id|,
+// |pred == id | gt == id|}, pixels whose ground truth is the void label are skipped.  Integer atomics: deterministic.
+__global__ __launch_bounds__(256) void k_mask_iou(const uint8_t* pred, const uint8_t* gt, long n, int num_ids, int void_label,
+                                                  unsigned long long* counts) {
+  __shared__ unsigned int sh[32][2];
+  for (int i = threadIdx.x; i < 64; i += 256) sh[i >> 1][i & 1] = 0;
+  __syncthreads();
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int a = pred[i], b = gt[i];
+    if (b == void_label) continue;
+    if (a == b) { if (a > 0 && a < num_ids) { atomicAdd(&sh[a][0], 1u); atomicAdd(&sh[a][1], 1u); } }
+    else {
+      if (a > 0 && a < num_ids) atomicAdd(&sh[a][1], 1u);
+      if (b > 0 && b < num_ids) atomicAdd(&sh[b][1], 1u);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * num_ids; i += 256)
+    if (sh[i >> 1][i & 1]) atomicAdd(&counts[i], (unsigned long long)sh[i >> 1][i & 1]);
+}
+
 inline unsigned nblk(long total) { return (unsigned)((total + 255) / 256); }
 
 }  // namespace
@@ -236,4 +294,23 @@ extern "C" int rmem_evict_scores(const float* logits_nhwc, int ldl, int num_clas
   hipLaunchKernelGGL(k_evict_partial, dim3(nb), dim3(256), 0, (hipStream_t)stream, logits_nhwc, ldl, num_classes, keep_max_id, Hi, Wi, He, We, attn_mass, T, partial);
   hipLaunchKernelGGL(k_evict_final, dim3(1), dim3(64), 0, (hipStream_t)stream, partial, nb, T, scores);
   return rmem_check_launch("rmem_evict_scores");
+}
+
+extern "C" int rmem_tta_merge(const float* const* logits_nchw, const int* flips, int n_aug, int num_classes, int H, int W,
+                              unsigned char* label_u8, float* label_f32, float* prob_nchw, void* stream) {
+  RMEM_REQUIRE(logits_nchw && flips && n_aug >= 1 && n_aug <= 4 && num_classes >= 1 && num_classes <= 16, "rmem_tta_merge: 1..4 augmentations, <= 16 classes");
+  RMEM_REQUIRE(label_u8 || label_f32 || prob_nchw, "rmem_tta_merge: no output requested");
+  TtaParams p;
+  for (int a = 0; a < 4; ++a) { p.lg[a] = a < n_aug ? logits_nchw[a] : nullptr; p.flip[a] = a < n_aug ? flips[a] : 0; }
+  p.n_aug = n_aug; p.nc = num_classes; p.H = H; p.W = W; p.label = label_u8; p.label_f32 = label_f32; p.prob = prob_nchw;
+  hipLaunchKernelGGL(k_tta_merge, dim3(nblk((long)H * W)), dim3(256), 0, (hipStream_t)stream, p);
+  return rmem_check_launch("rmem_tta_merge");
+}
+
+extern "C" int rmem_mask_iou_counts(const unsigned char* pred, const unsigned char* gt, long long n, int num_ids, int void_label,
+                                    unsigned long long* counts, void* stream) {
+  RMEM_REQUIRE(pred && gt && counts && n > 0 && num_ids >= 2 && num_ids <= 32, "rmem_mask_iou_counts: bad argument");
+  const unsigned blocks = (unsigned)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+  hipLaunchKernelGGL(k_mask_iou, dim3(blocks), dim3(256), 0, (hipStream_t)stream, pred, gt, (long)n, num_ids, void_label, counts);
+  return rmem_check_launch("rmem_mask_iou_counts");
 }

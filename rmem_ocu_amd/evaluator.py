@@ -1,0 +1,135 @@
+"""Per-sequence evaluation protocol on top of the engines (the caller of the hot path).
+
+Mirrors what networks/managers/evaluator.py:330-568 does for one sequence, without its dataset plumbing:
+  * per-sequence gap = max(round(n / 30), 5) (330-335), assigned to every engine (356);
+  * one engine per test-time augmentation (342-355): horizontal flip and/or extra scales; every augmentation's
+    logits are resized to the original size, flipped back, soft-maxed and averaged, then arg-maxed (427-441)
+    -- rmem_tta_merge;
+  * a ground-truth label that arrives on a later frame (a new object) is merged over the prediction and the frame is
+    re-added as a reference frame to every engine (484-508); otherwise the prediction updates the memory (509-523);
+  * masks can be written as palette PNGs (utils/image.py:90-106) and scored with the region similarity J
+    (evaluation/source/metrics.py:6-37) -- rmem_mask_iou_counts.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import _lib
+from .networks.engines import build_engine
+
+
+def _davis_palette() -> List[int]:
+    """The 256-colour DAVIS palette (bit-reversal colour map; the same table utils/image.py:8-62 hard-codes)."""
+    pal = []
+    for i in range(256):
+        r = g = b = 0
+        c = i
+        for j in range(8):
+            r |= ((c >> 0) & 1) << (7 - j)
+            g |= ((c >> 1) & 1) << (7 - j)
+            b |= ((c >> 2) & 1) << (7 - j)
+            c >>= 3
+        pal += [r, g, b]
+    return pal
+
+
+def save_mask(mask_u8: np.ndarray, path: str, squeeze_idx: Optional[Sequence[int]] = None):
+    """utils/image.py:90-101: optional un-squeeze of object ids, then an indexed PNG with the DAVIS palette."""
+    from PIL import Image
+    mask = np.asarray(mask_u8, dtype=np.uint8)
+    if squeeze_idx is not None:
+        out = np.zeros_like(mask)
+        for idx in range(1, len(squeeze_idx)):
+            out += ((mask == idx) * squeeze_idx[idx]).astype(np.uint8)
+        mask = out
+    im = Image.fromarray(mask).convert('P')
+    im.putpalette(_davis_palette())
+    im.save(path)
+
+
+def tta_merge(logits: Sequence[torch.Tensor], flips: Sequence[bool], want_prob: bool = False):
+    """logits: per-augmentation [1, nc, H, W] fp32 device tensors -> (label uint8 [H, W], label fp32 [1,1,H,W], prob or None)."""
+    n = len(logits)
+    nc, H, W = logits[0].shape[1:]
+    dev = logits[0].device
+    label = torch.empty(H, W, dtype=torch.uint8, device=dev)
+    label_f = torch.empty(1, 1, H, W, dtype=torch.float32, device=dev)
+    prob = torch.empty(1, nc, H, W, dtype=torch.float32, device=dev) if want_prob else None
+    ptrs = (C.c_void_p * n)(*[t.contiguous().data_ptr() for t in logits])
+    fl = (C.c_int * n)(*[int(f) for f in flips])
+    _lib.check(_lib.lib().rmem_tta_merge(ptrs, fl, n, nc, H, W, label.data_ptr(), label_f.data_ptr(),
+                                         None if prob is None else prob.data_ptr(), torch.cuda.current_stream(dev).cuda_stream),
+               'rmem_tta_merge')
+    return label, label_f, prob
+
+
+def region_similarity(pred_u8: torch.Tensor, gt_u8: torch.Tensor, num_ids: int = 11, void_label: int = 255) -> Dict[int, float]:
+    """J per object id for one mask pair (device uint8 tensors of equal shape); ids absent from both masks are skipped."""
+    assert pred_u8.dtype == torch.uint8 and gt_u8.dtype == torch.uint8 and pred_u8.shape == gt_u8.shape
+    counts = torch.zeros(2 * num_ids, dtype=torch.int64, device=pred_u8.device)
+    _lib.check(_lib.lib().rmem_mask_iou_counts(pred_u8.contiguous().data_ptr(), gt_u8.contiguous().data_ptr(), pred_u8.numel(),
+                                               num_ids, void_label, counts.data_ptr(),
+                                               torch.cuda.current_stream(pred_u8.device).cuda_stream), 'rmem_mask_iou_counts')
+    c = counts.cpu().view(num_ids, 2)
+    return {i: (1.0 if c[i, 1] == 0 else float(c[i, 0]) / float(c[i, 1])) for i in range(1, num_ids) if c[i, 1] > 0}
+
+
+class SequenceEvaluator:
+    """Runs one sequence through the engine(s) exactly as the reference evaluator would."""
+
+    def __init__(self, model, gpu_id: int = 0, flip: bool = False):
+        self.model, self.gpu_id, self.flip = model, gpu_id, flip
+        self.cfg = model.cfg
+        self.engines = []
+
+    def _engine(self, i):
+        while len(self.engines) <= i:
+            e = build_engine(self.cfg.MODEL_ENGINE, phase='eval', aot_model=self.model, gpu_id=self.gpu_id,
+                             long_term_mem_gap=self.cfg.TEST_LONG_TERM_MEM_GAP)
+            self.engines.append(e.eval())
+        return self.engines[i]
+
+    def run(self, frames: torch.Tensor, labels: Dict[int, torch.Tensor], out_hw: Tuple[int, int]) -> List[torch.Tensor]:
+        """frames: [n, 3, H, W] fp32 device (network size, normalised); labels: {frame index: [1,1,Ho,Wo] fp32 label map at the
+        ORIGINAL size}; labels[0] is the first-frame annotation, later entries are newly appearing objects.
+        Returns the uint8 label map of every frame after the first, at the original size."""
+        n = frames.shape[0]
+        gap = max(int(round(n / 30)), 5)
+        augs = [False, True] if self.flip else [False]
+        net_hw = tuple(frames.shape[2:])
+        outs: List[torch.Tensor] = []
+        for i, flipped in enumerate(augs):
+            e = self._engine(i)
+            e.restart_engine()
+            e.long_term_mem_gap = gap
+            img = frames[0:1].flip(3) if flipped else frames[0:1]
+            lab = F.interpolate(labels[0], size=net_hw, mode='nearest')
+            lab = lab.flip(3) if flipped else lab
+            e.add_reference_frame(img, lab, obj_nums=[int(labels[0].max().item())], frame_step=0)
+        for t in range(1, n):
+            logits = []
+            for i, flipped in enumerate(augs):
+                img = frames[t:t + 1].flip(3) if flipped else frames[t:t + 1]
+                logits.append(self.engines[i].match_propogate_one_frame(img, output_size=out_hw))
+            label_u8, label_f, _ = tta_merge(logits, augs)
+            if t in labels:                                   # evaluator.py:484-508
+                new = labels[t]
+                keep = (new == 0).float()
+                label_f = label_f * keep + new * (1 - keep)
+                label_u8 = label_f[0, 0].to(torch.uint8)
+                nobj = [int(label_f.max().item())]
+                for i, flipped in enumerate(augs):
+                    lab = F.interpolate(label_f.flip(3) if flipped else label_f, size=self.engines[i].input_size_2d, mode='nearest')
+                    img = frames[t:t + 1].flip(3) if flipped else frames[t:t + 1]
+                    self.engines[i].add_reference_frame(img, lab, obj_nums=nobj, frame_step=t)
+            else:
+                for i, flipped in enumerate(augs):
+                    lab = F.interpolate(label_f.flip(3) if flipped else label_f, size=self.engines[i].input_size_2d, mode='nearest')
+                    self.engines[i].update_memory(lab)
+            outs.append(label_u8)
+        return outs

@@ -246,3 +246,42 @@ def test_fitted_weights_mask_iou(name):
     print(f'{name} free-running: mean IoU {np.mean(ious):.5f} first-frame IoU {ious[0]:.5f} last-frame IoU {ious[-1]:.5f}  '
           f'label agreement {agree.mean():.5f}')
     assert ious[0] >= 0.985 and agree.mean() >= 0.9
+
+
+def test_sequence_evaluator_flip_tta_and_metrics(tmp_path):
+    """f3 / f4: the evaluator protocol with horizontal-flip TTA (two engines, probabilities averaged on the device), J per
+    object from the device counts, palette PNG output -- against the oracle's evaluate_sequence on the fitted weights."""
+    if not os.path.exists(os.path.join(GOLDEN, 'trained_delta.pt')):
+        pytest.skip('fitted weights missing')
+    from oracle import ref_cpu as O
+    from rmem_ocu_amd import build_vos_model, get_config
+    from rmem_ocu_amd.evaluator import SequenceEvaluator, region_similarity, save_mask
+    from rmem_ocu_amd.synth import make_clip
+    from rmem_ocu_amd.weights import fitted_state_dict
+    dev = torch.device('cuda', 0)
+    sd = fitted_state_dict(0)
+    cfg = get_config('pre_vost', 'test', 'r50_aotl')
+    cfg.FORMER_MEM_LEN, cfg.LATTER_MEM_LEN = 1, 2
+    model = build_vos_model(cfg.MODEL_VOS, cfg).cuda(0)
+    model.load_state_dict(sd)
+    frames, mask = make_clip(71, 7, 161, 193, 2)
+    first = F.interpolate(mask.float(), size=(160, 192), mode='nearest')
+    ref_labels, ref_probs = O.evaluate_sequence(sd, frames, {0: first}, (160, 192), 1, 2, flip=True)
+    ev = SequenceEvaluator(model, 0, flip=True)
+    got = ev.run(frames.to(dev), {0: first.to(dev)}, (160, 192))
+    assert len(got) == len(ref_labels) == 6 and len(ev.engines) == 2
+    agree = [(g.cpu() == r).float().mean().item() for g, r in zip(got, ref_labels)]
+    print('flip-TTA sequence: label agreement per frame', [round(a, 4) for a in agree])
+    assert agree[0] > 0.997 and min(agree) > 0.97
+    # J from the device counts equals the numpy metric
+    j = region_similarity(got[0], ref_labels[0].to(dev))
+    for i, v in j.items():
+        assert abs(v - O.db_eval_iou((ref_labels[0].numpy() == i), (got[0].cpu().numpy() == i))) < 1e-9
+    assert min(j.values()) > 0.98
+    # palette PNG round trip
+    p = str(tmp_path / 'm.png')
+    save_mask(got[0].cpu().numpy(), p)
+    from PIL import Image
+    im = Image.open(p)
+    assert im.mode == 'P' and np.array_equal(np.array(im), got[0].cpu().numpy())
+    assert im.getpalette()[:9] == [0, 0, 0, 128, 0, 0, 0, 128, 0]

@@ -96,3 +96,15 @@ def test_oracle_iou_metric():
     a = np.zeros((4, 4), int); b = np.zeros((4, 4), int)
     a[:2] = 1; b[:3] = 1
     assert abs(O.db_eval_iou(a, b) - 8 / 12) < 1e-9 and O.db_eval_iou(np.zeros((2, 2)), np.zeros((2, 2))) == 1.0
+
+
+def test_davis_palette_and_png_writer(tmp_path):
+    """utils/image.py:8-62 palette head (background black, id 1 maroon, id 2 green, ...) and the indexed PNG writer."""
+    from PIL import Image
+    from rmem_ocu_amd.evaluator import _davis_palette, save_mask
+    pal = _davis_palette()
+    assert pal[:15] == [0, 0, 0, 128, 0, 0, 0, 128, 0, 128, 128, 0, 0, 0, 128] and len(pal) == 768
+    m = np.zeros((5, 7), np.uint8); m[1:3, 2:5] = 2
+    save_mask(m, str(tmp_path / 'a.png'), squeeze_idx=[0, 4, 9])
+    back = np.array(Image.open(str(tmp_path / 'a.png')))
+    assert back.max() == 9 and (back == 9).sum() == 6
