@@ -144,6 +144,10 @@ int rmem_dwconv5x5_nhwc(const void* x, const float* w_t, void* y, int H, int W, 
 /* ------------------------------------------------------------------ layout / resampling */
 /* fp32 [3][H][W] image -> bf16 [H][W][8] (channels 3..7 zero): input of encoders/resnet.py:179. */
 int rmem_image_to_nhwc8(const float* img_chw, void* out, int H, int W, void* stream);
+/* Frame ingest: decoded uint8 RGB [Hs][Ws][3] -> bicubic resize to the network size (OpenCV INTER_CUBIC semantics) ->
+ * ImageNet normalise -> fp32 [3][Hd][Wd] (the engine API's input) and/or bf16 [Hd][Wd][8] (the encoder's input).
+ * Replaces dataloaders/video_transforms.py:648-652 (cv2.resize) + 676-680 (normalise) on the host. */
+int rmem_ingest_rgb8(const unsigned char* rgb_hwc, int Hs, int Ws, int Hd, int Wd, float* out_chw, void* out_nhwc8, void* stream);
 /* 3x3 stride-2 pad-1 max-pool (encoders/resnet.py:105, 182). */
 int rmem_maxpool3x3s2_nhwc(const void* x, void* y, int H, int W, int C, void* stream);
 /* bilinear resize, NHWC bf16 (decoders/fpn.py:49-52, 57-60). */

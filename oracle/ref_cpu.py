@@ -615,6 +615,35 @@ def evaluate_sequence(weights: W, frames: Tensor, labels: Dict[int, Tensor], out
     return outs, probs
 
 
+def ingest_rgb8(rgb: np.ndarray, hd: int, wd: int) -> np.ndarray:
+    """Frame ingest of the reference data path: float32 image -> cv2.resize(INTER_CUBIC) -> /255, ImageNet mean/std
+    (dataloaders/eval_datasets.py:57-64; video_transforms.py:648-652, 676-680).  cv2 is absent here, so the resize is a
+    restatement of OpenCV's published bicubic (a = -0.75, fx = (dx + 0.5) * scale - 0.5, taps clamped to the border):
+    PARITY UNPINNED for this function.  rgb: uint8 [Hs, Ws, 3] -> float32 [3, hd, wd]."""
+    hs, ws = rgb.shape[:2]
+    img = rgb.astype(np.float32)
+
+    def taps(n_dst, n_src):
+        f = (np.arange(n_dst, dtype=np.float32) + 0.5) * np.float32(n_src / n_dst) - 0.5
+        s0 = np.floor(f).astype(np.int64)
+        t = (f - s0).astype(np.float32)
+        A = np.float32(-0.75)
+        w0 = ((A * (t + 1) - 5 * A) * (t + 1) + 8 * A) * (t + 1) - 4 * A
+        w1 = ((A + 2) * t - (A + 3)) * t * t + 1
+        w2 = ((A + 2) * (1 - t) - (A + 3)) * (1 - t) * (1 - t) + 1
+        w3 = 1 - w0 - w1 - w2
+        idx = np.clip(s0[:, None] + np.arange(-1, 3)[None, :], 0, n_src - 1)
+        return idx, np.stack([w0, w1, w2, w3], 1).astype(np.float32)
+
+    if (hs, ws) != (hd, wd):
+        iy, wy = taps(hd, hs)
+        ix, wx = taps(wd, ws)
+        rows = (img[:, ix, :] * wx[None, :, :, None]).sum(2)          # [hs, wd, 3]
+        img = (rows[iy, :, :] * wy[:, :, None, None]).sum(1)          # [hd, wd, 3]
+    img = (img / np.float32(255.) - np.array([0.485, 0.456, 0.406], np.float32)) / np.array([0.229, 0.224, 0.225], np.float32)
+    return img.transpose(2, 0, 1).astype(np.float32)
+
+
 def db_eval_iou(annotation: np.ndarray, segmentation: np.ndarray) -> float:
     """evaluation/source/metrics.py:6-37 (single frame, no void)."""
     a = annotation.astype(bool)

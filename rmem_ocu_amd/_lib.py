@@ -48,6 +48,7 @@ SIGNATURES = {
     'rmem_groupnorm_nhwc': (_i, [_vp, _i, _i, _i, _vp, _vp, _f, _i, _vp, _vp, _vp]),
     'rmem_dwconv5x5_nhwc': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     'rmem_image_to_nhwc8': (_i, [_vp, _vp, _i, _i, _vp]),
+    'rmem_ingest_rgb8': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     'rmem_maxpool3x3s2_nhwc': (_i, [_vp, _vp, _i, _i, _i, _vp]),
     'rmem_bilinear_nhwc': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'rmem_logits_post': (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),

@@ -246,6 +246,60 @@ __global__ __launch_bounds__(256) void k_mask_iou(const uint8_t* pred, const uin
     if (sh[i >> 1][i & 1]) atomicAdd(&counts[i], (unsigned long long)sh[i >> 1][i & 1]);
 }
 
+// frame ingest: uint8 RGB HWC [Hs][Ws][3] -> bicubic resize (OpenCV INTER_CUBIC: a = -0.75, pixel-centre mapping, clamped taps)
+// -> /255, ImageNet mean/std -> fp32 CHW [3][Hd][Wd] and/or NHWC8 bf16 (dataloaders/eval_datasets.py:57-64,
+// video_transforms.py:648-652, 676-680).  One thread per destination pixel.
+__device__ __forceinline__ void cubic_w(float t, float (&w)[4]) {
+  const float A = -0.75f;
+  w[0] = ((A * (t + 1.f) - 5.f * A) * (t + 1.f) + 8.f * A) * (t + 1.f) - 4.f * A;
+  w[1] = ((A + 2.f) * t - (A + 3.f)) * t * t + 1.f;
+  w[2] = ((A + 2.f) * (1.f - t) - (A + 3.f)) * (1.f - t) * (1.f - t) + 1.f;
+  w[3] = 1.f - w[0] - w[1] - w[2];
+}
+
+__global__ __launch_bounds__(256) void k_ingest(const uint8_t* src, int Hs, int Ws, int Hd, int Wd, float* out_chw, bf16* out_nhwc8) {
+  const long total = (long)Hd * Wd;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int dy = (int)(i / Wd), dx = (int)(i - (long)dy * Wd);
+  float rgb[3];
+  if (Hs == Hd && Ws == Wd) {                       // the evaluator skips the resize when the size is unchanged (video_transforms.py:624-625)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) rgb[c] = (float)src[i * 3 + c];
+  } else {
+    const float fy = ((float)dy + 0.5f) * ((float)Hs / (float)Hd) - 0.5f;
+    const float fx = ((float)dx + 0.5f) * ((float)Ws / (float)Wd) - 0.5f;
+    const int sy = (int)floorf(fy), sx = (int)floorf(fx);
+    float wy[4], wx[4];
+    cubic_w(fy - (float)sy, wy);
+    cubic_w(fx - (float)sx, wx);
+    rgb[0] = rgb[1] = rgb[2] = 0.f;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int yy = min(max(sy - 1 + a, 0), Hs - 1);
+      float row[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int xx = min(max(sx - 1 + b, 0), Ws - 1);
+        const uint8_t* px = src + ((long)yy * Ws + xx) * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) row[c] += wx[b] * (float)px[c];
+      }
+#pragma unroll
+      for (int c = 0; c < 3; ++c) rgb[c] += wy[a] * row[c];
+    }
+  }
+  const float mean[3] = {0.485f, 0.456f, 0.406f}, istd[3] = {1.f / 0.229f, 1.f / 0.224f, 1.f / 0.225f};
+  bf16x8 o = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float v = (rgb[c] * (1.f / 255.f) - mean[c]) * istd[c];
+    if (out_chw) out_chw[(long)c * total + i] = v;
+    o[c] = (bf16)v;
+  }
+  if (out_nhwc8) reinterpret_cast<bf16x8*>(out_nhwc8)[i] = o;
+}
+
 inline unsigned nblk(long total) { return (unsigned)((total + 255) / 256); }
 
 }  // namespace
@@ -313,4 +367,10 @@ extern "C" int rmem_mask_iou_counts(const unsigned char* pred, const unsigned ch
   const unsigned blocks = (unsigned)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
   hipLaunchKernelGGL(k_mask_iou, dim3(blocks), dim3(256), 0, (hipStream_t)stream, pred, gt, (long)n, num_ids, void_label, counts);
   return rmem_check_launch("rmem_mask_iou_counts");
+}
+
+extern "C" int rmem_ingest_rgb8(const unsigned char* rgb_hwc, int Hs, int Ws, int Hd, int Wd, float* out_chw, void* out_nhwc8, void* stream) {
+  RMEM_REQUIRE(rgb_hwc && (out_chw || out_nhwc8) && Hs > 0 && Ws > 0 && Hd > 0 && Wd > 0, "rmem_ingest_rgb8: bad argument");
+  hipLaunchKernelGGL(k_ingest, dim3(nblk((long)Hd * Wd)), dim3(256), 0, (hipStream_t)stream, rgb_hwc, Hs, Ws, Hd, Wd, out_chw, (bf16*)out_nhwc8);
+  return rmem_check_launch("rmem_ingest_rgb8");
 }

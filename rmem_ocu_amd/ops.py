@@ -172,6 +172,14 @@ def image_to_nhwc8(img, out, *, H, W) -> Op:
     return Op(_lib.lib().rmem_image_to_nhwc8, (_ptr(img), _ptr(out), H, W), 'rmem_image_to_nhwc8', (img, out))
 
 
+def ingest_rgb8(rgb, *, Hs, Ws, Hd, Wd, out_chw=None, out_nhwc8=None) -> Op:
+    """uint8 RGB [Hs, Ws, 3] device tensor -> resized, normalised fp32 [3, Hd, Wd] and/or bf16 [Hd*Wd, 8]."""
+    _dev(rgb, out_chw, out_nhwc8)
+    assert rgb.dtype == torch.uint8 and rgb.is_contiguous() and rgb.numel() == Hs * Ws * 3
+    assert (out_chw is None or out_chw.dtype == F32) and (out_nhwc8 is None or out_nhwc8.dtype == BF16)
+    return Op(_lib.lib().rmem_ingest_rgb8, (_ptr(rgb), Hs, Ws, Hd, Wd, _ptr(out_chw), _ptr(out_nhwc8)), 'rmem_ingest_rgb8', (rgb, out_chw, out_nhwc8))
+
+
 def maxpool3x3s2(x, y, *, H, W, C) -> Op:
     _dev(x, y)
     return Op(_lib.lib().rmem_maxpool3x3s2_nhwc, (_ptr(x), _ptr(y), H, W, C), 'rmem_maxpool3x3s2_nhwc', (x, y))

@@ -387,3 +387,23 @@ def test_window_attention_vs_oracle(dev, H, W, heads, shift):
     ops.run(ops.window_attn(qkv.to(BF16).to(dev), rb(qkv_bias).to(dev), tbl, out, H=H, W=W, C=C, heads=heads, shift=shift))
     torch.cuda.synchronize()
     assert_close(out, ref, 2e-2, f'window attention {H}x{W} shift {shift}')
+
+
+@pytest.mark.parametrize('src,dst', [((480, 854), (481, 849)), ((1080, 1920), (577, 1041)), ((120, 160), (120, 160)), ((50, 70), (97, 129))])
+def test_frame_ingest(dev, src, dst):
+    """f2: uint8 RGB -> bicubic resize -> normalise, fp32 CHW and NHWC8 bf16, against the oracle's restatement of the
+    reference data path (cv2 is absent in this image: the oracle side is unpinned for this row)."""
+    from oracle import ref_cpu as O
+    from rmem_ocu_amd import ops
+    rng = np.random.default_rng(5)
+    base = rng.integers(0, 256, size=(src[0] // 8 + 2, src[1] // 8 + 2, 3)).astype(np.float32)
+    img = np.clip(F.interpolate(torch.from_numpy(base).permute(2, 0, 1)[None], size=src, mode='bilinear')[0].permute(1, 2, 0).numpy()
+                  + rng.normal(0, 8, size=(*src, 3)), 0, 255).astype(np.uint8)
+    ref = torch.from_numpy(O.ingest_rgb8(img, *dst))
+    chw = torch.zeros(3, *dst, dtype=F32, device=dev)
+    n8 = torch.zeros(dst[0] * dst[1], 8, dtype=BF16, device=dev)
+    ops.run(ops.ingest_rgb8(torch.from_numpy(img).to(dev), Hs=src[0], Ws=src[1], Hd=dst[0], Wd=dst[1], out_chw=chw, out_nhwc8=n8))
+    torch.cuda.synchronize()
+    assert_close(chw, ref, 2e-5, f'ingest {src}->{dst}')
+    assert_close(n8[:, :3], rb(ref).permute(1, 2, 0).reshape(-1, 3), 1e-2, 'ingest nhwc8')
+    assert n8[:, 3:].abs().max().item() == 0
