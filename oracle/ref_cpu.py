@@ -456,6 +456,9 @@ class OracleEngine:
             logits = F.interpolate(logits, size=output_size, mode='bilinear', align_corners=self.align_corners)
         return logits
 
+    def _assign_identity(self, oh, ign):
+        return assign_identity(oh, ign, self.w, self.align_corners)
+
     def add_reference_frame(self, img: Tensor, mask: Tensor, frame_step: int = 0):
         xs = encode_image(img, self.w)
         if self.input_size_2d is None:
@@ -464,11 +467,11 @@ class OracleEngine:
         if self.pos_emb is None:
             self.pos_emb = sine_pos_emb(*self.enc_size_2d)
         oh, ign = one_hot_mask(mask)
-        id_emb = assign_identity(oh, None, self.w, self.align_corners)   # ignore mask not forwarded (305)
+        id_emb = self._assign_identity(oh, None)                        # ignore mask not forwarded (305)
         outs = self._lstt(xs, id_emb, False)
         self.last_mem_step = frame_step
-        self.long_mem = [[k, v] for k, v in self.lstt_long]             # init_memory, transformer.py:438-443
-        self.short_mem = [[k, v] for k, v in self.lstt_short]
+        self.long_mem = [list(m) for m in self.lstt_long]               # init_memory, transformer.py:438-443
+        self.short_mem = [list(m) for m in self.lstt_short]
         self.evict = EvictionState()
         self.long_memories_indexes.append(self.frame_step)              # quirk: self.frame_step (323)
         return self._decode(xs, outs, None)
@@ -485,10 +488,13 @@ class OracleEngine:
             oh, ign = one_hot_mask(curr_mask)
         else:
             oh, ign = curr_mask, None
-        id_emb = assign_identity(oh, ign, self.w, self.align_corners)
+        id_emb = self._assign_identity(oh, ign)
         update_long = (self.frame_step - self.last_mem_step) >= self.long_term_mem_gap
         if update_long:
             self.last_mem_step = self.frame_step
+        self._update_memories(id_emb, update_long)
+
+    def _update_memories(self, id_emb, update_long):
         for i in range(self.L):
             p = f'LSTT.layers.{i}'
             self.curr_mem[i][1] = F.linear(self.curr_mem[i][1] + id_emb, self.w[p + '.linear_V.weight'], self.w[p + '.linear_V.bias'])

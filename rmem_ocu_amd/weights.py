@@ -103,16 +103,49 @@ def _swin_encoder(sd, seed):
         _norm(sd, seed, f'encoder.norm{li}', e * 2 ** li)
 
 
+def _deaot_gpm(sd, seed, num_lstt, d_model):
+    """DualBranchGPM (layers/transformer.py:700-763) of R50-DeAOTL: att/self heads 1, d_att = d_model / 2, expand ratio 2
+    (transformer.py:1011-1082; layers/attention.py:93-136, 220-279)."""
+    d_att, e1, e2 = d_model // 2, 2 * d_model, 4 * d_model
+    for i in range(num_lstt):
+        p = f'LSTT.layers.{i}'
+        _norm(sd, seed, p + '.norm1', d_model)
+        _linear(sd, seed, p + '.linear_QV', d_att + e1, d_model, 1.6)
+        _linear(sd, seed, p + '.linear_U', e1, d_model, 1.6)
+        if i == 0:
+            _linear(sd, seed, p + '.linear_ID_V', e1, d_model, 1.6)
+        else:
+            _norm(sd, seed, p + '.id_norm1', d_model)
+            _linear(sd, seed, p + '.linear_ID_V', e1, 2 * d_model, 1.6)
+            _linear(sd, seed, p + '.linear_ID_U', e1, d_model, 1.6)
+        for nm in ('long_term_attn', 'short_term_attn'):
+            if nm == 'short_term_attn':
+                sd[f'{p}.{nm}.relative_emb_k.weight'] = _normal(seed, f'{p}.{nm}.relative_emb_k.weight', (225, d_att, 1, 1), 0.08)
+                sd[f'{p}.{nm}.relative_emb_k.bias'] = _normal(seed, f'{p}.{nm}.relative_emb_k.bias', (225,), 0.3)
+            sd[f'{p}.{nm}.dw_conv.conv.weight'] = _normal(seed, f'{p}.{nm}.dw_conv.conv.weight', (e2, 1, 5, 5), 0.25)
+            _linear(sd, seed, f'{p}.{nm}.projection', e1, e2, 1.6)
+        _norm(sd, seed, p + '.norm2', d_model)
+        _norm(sd, seed, p + '.id_norm2', d_model)
+        _linear(sd, seed, p + '.self_attn.linear_QK', d_att, e1, 1.6)
+        for nm in ('linear_V1', 'linear_V2', 'linear_U1', 'linear_U2'):
+            _linear(sd, seed, f'{p}.self_attn.{nm}', e1, d_model, 1.6)
+        sd[p + '.self_attn.dw_conv.conv.weight'] = _normal(seed, p + '.self_attn.dw_conv.conv.weight', (e2, 1, 5, 5), 0.25)
+        _linear(sd, seed, p + '.self_attn.projection', e1, e2, 1.6)
+    _norm(sd, seed, 'LSTT.decoder_norms.0.gn', 2 * d_model)      # final GroupNorm1D(512, 2), transformer.py:755-758
+
+
 def synth_state_dict(seed: int = 0, num_lstt: int = 3, d_model: int = 256,
-                     max_obj_num: int = 10, encoder: str = 'resnet50') -> "OrderedDict[str, torch.Tensor]":
-    """All tensors of the R50-AOTL (362) or SwinB-AOTL (471) state_dict, fp32, CPU."""
+                     max_obj_num: int = 10, encoder: str = 'resnet50', model: str = 'aot') -> "OrderedDict[str, torch.Tensor]":
+    """All tensors of the R50-AOTL (362), SwinB-AOTL (471) or R50-DeAOTL (356, model='deaot') state_dict, fp32, CPU."""
     sd: "OrderedDict[str, torch.Tensor]" = OrderedDict()
     swin = encoder == 'swin_base'
+    deaot = model == 'deaot'
     enc_dims = (128, 256, 512) if swin else (256, 512, 1024)
-    # learned temporal positional embedding, aot.py:95-103 (std raised from .05 so the
+    # learned temporal positional embedding, aot.py:95-103 / deaot.py:46-53 (half width) (std raised from .05 so the
     # path is visible in parity tests)
-    sd['cur_pos_emb'] = _normal(seed, 'cur_pos_emb', (1, d_model), 0.3)
-    sd['mem_pos_emb'] = _normal(seed, 'mem_pos_emb', (4, d_model), 0.3)
+    pe_dim = d_model // 2 if deaot else d_model
+    sd['cur_pos_emb'] = _normal(seed, 'cur_pos_emb', (1, pe_dim), 0.3)
+    sd['mem_pos_emb'] = _normal(seed, 'mem_pos_emb', (4, pe_dim), 0.3)
 
     # --- encoder (torchvision-style names) ---
     if swin:
@@ -139,7 +172,9 @@ def synth_state_dict(seed: int = 0, num_lstt: int = 3, d_model: int = 256,
     sd['encoder_projector.bias'] = _normal(seed, 'encoder_projector.bias', (d_model,), 0.02)
 
     # --- LSTT ---
-    for i in range(num_lstt):
+    if deaot:
+        _deaot_gpm(sd, seed, num_lstt, d_model)
+    for i in range(0 if deaot else num_lstt):
         p = f'LSTT.layers.{i}'
         _norm(sd, seed, p + '.norm1', d_model)
         for nm in ('linear_Q', 'linear_K', 'linear_V', 'projection'):
@@ -158,7 +193,7 @@ def synth_state_dict(seed: int = 0, num_lstt: int = 3, d_model: int = 256,
         _norm(sd, seed, p + '.activation.gn', 4 * d_model)
         sd[p + '.activation.conv.weight'] = _normal(seed, p + '.activation.conv.weight', (4 * d_model, 1, 5, 5), 0.2)
         _linear(sd, seed, p + '.linear2', d_model, 4 * d_model)
-    for i in range(num_lstt):
+    for i in range(0 if deaot else num_lstt):
         _norm(sd, seed, f'LSTT.decoder_norms.{i}', d_model)
 
     # --- FPN decoder, decoders/fpn.py:22-32 ---
@@ -166,7 +201,7 @@ def synth_state_dict(seed: int = 0, num_lstt: int = 3, d_model: int = 256,
         _conv(sd, seed, prefix + '.conv.weight', cout, cin, k, 0.7)
         sd[prefix + '.conv.bias'] = _normal(seed, prefix + '.conv.bias', (cout,), 0.02)
         _norm(sd, seed, prefix + '.gn', cout)
-    convgn('decoder.conv_in', d_model, d_model * (num_lstt + 1), 1)
+    convgn('decoder.conv_in', d_model, 2 * d_model if deaot else d_model * (num_lstt + 1), 1)   # deaot.py:28-31
     convgn('decoder.conv_16x', d_model, d_model, 3)
     convgn('decoder.conv_8x', d_model // 2, d_model, 3)
     convgn('decoder.conv_4x', d_model // 2, d_model // 2, 3)
@@ -180,6 +215,8 @@ def synth_state_dict(seed: int = 0, num_lstt: int = 3, d_model: int = 256,
     kid = 16 if swin else 17      # models/aot.py:67-82: k17 s16 p8 (align_corners) or k16 s16 p0
     sd['patch_wise_id_bank.weight'] = _normal(seed, 'patch_wise_id_bank.weight', (d_model, max_obj_num + 2, kid, kid), 1.0 / kid)
     sd['patch_wise_id_bank.bias'] = _normal(seed, 'patch_wise_id_bank.bias', (d_model,), 0.02)
+    if deaot:
+        _norm(sd, seed, 'id_norm', d_model)          # deaot.py:42
     return sd
 
 

@@ -35,7 +35,7 @@ from rmem_ocu_amd.synth import make_clip  # noqa: E402
 from rmem_ocu_amd.weights import synth_state_dict  # noqa: E402
 
 
-def load_reference(former=1, latter=7, encoder='resnet50', fitted=False):
+def load_reference(former=1, latter=7, encoder='resnet50', fitted=False, model_name='r50_aotl'):
     sys.path.insert(0, REF)
     tml = types.ModuleType('timm.models.layers')
     tml.trunc_normal_ = lambda t, mean=0., std=1., a=-2., b=2.: torch.nn.init.trunc_normal_(t, mean=mean, std=std, a=a, b=b)
@@ -54,7 +54,7 @@ def load_reference(former=1, latter=7, encoder='resnet50', fitted=False):
     tv.transforms = tvt
     sys.modules.update({'torchvision': tv, 'torchvision.transforms': tvt, 'torchvision.transforms.functional': tvf})
 
-    cfg = importlib.import_module('configs.default').EngineConfig('golden', 'r50_aotl')
+    cfg = importlib.import_module('configs.default').EngineConfig('golden', model_name)   # r50_aotl | r50_deaotl
     cfg.MODEL_LINEAR_Q = False
     cfg.FORMER_MEM_LEN, cfg.LATTER_MEM_LEN = former, latter
     if encoder == 'swin_base':
@@ -75,7 +75,8 @@ def load_reference(former=1, latter=7, encoder='resnet50', fitted=False):
     from networks.engines import build_engine
     model = build_vos_model(cfg.MODEL_VOS, cfg).eval()
     from rmem_ocu_amd.weights import fitted_state_dict
-    missing = model.load_state_dict(fitted_state_dict(0) if fitted else synth_state_dict(0, encoder=encoder), strict=True)
+    kind = 'deaot' if model_name == 'r50_deaotl' else 'aot'
+    missing = model.load_state_dict(fitted_state_dict(0) if fitted else synth_state_dict(0, encoder=encoder, model=kind), strict=True)
     assert not missing.missing_keys and not missing.unexpected_keys
     return cfg, model, build_engine
 
@@ -216,8 +217,82 @@ def gen_swin_ops():
     return out
 
 
-def gen_clip(tag, former, latter, n_frames, h, w, out_hw, gap, objs, seed, inject_at=-1, encoder='resnet50', fitted=False):
-    cfg, model, build_engine = load_reference(former, latter, encoder, fitted)
+def gen_deaot_ops(model):
+    """Op-level fixtures of the DeAOT propagation block: the reference's own GatedPropagation / LocalGatedPropagation /
+    GatedPropagationModule modules (layers/attention.py:93-413, layers/transformer.py:1011-1249) on seeded inputs."""
+    out = {}
+    temporal = torch.cat((model.cur_pos_emb, model.mem_pos_emb), dim=0).detach()
+    h, w = 9, 11
+    L, C = h * w, 256
+    with torch.no_grad():
+        for li in (0, 1):
+            blk = model.LSTT.layers[li]
+            for T in (1, 3, 5, 9):
+                tgt = seeded(3000 + 10 * T + li, (L, 1, C))
+                tgt_id = None if li == 0 else seeded(3100 + T, (L, 1, C))
+                long_mem = [seeded(3200 + T, (T, L, 1, 128)), torch.nn.functional.silu(seeded(3300 + T, (T, L, 1, 512))), None,
+                            torch.nn.functional.silu(seeded(3400 + T, (T, L, 1, 512)))]
+                short_mem = [seeded(3500 + T, (1, 128, h, w)), torch.nn.functional.silu(seeded(3600 + T, (1, 512, h, w))), None,
+                             torch.nn.functional.silu(seeded(3700 + T, (1, 512, h, w)))]
+                y, yid, mems = blk(tgt, tgt_id, long_mem, short_mem, curr_id_emb=None, size_2d=(h, w),
+                                   temporal_encoding=temporal, save_atten_weights=True)
+                out[f'gpm{li}_T{T}_out'] = y[:, 0][::3].numpy()
+                out[f'gpm{li}_T{T}_outid'] = yid[:, 0][::3].numpy()
+                out[f'gpm{li}_T{T}_curK'] = mems[0][0][:, 0][::3].numpy()
+                out[f'gpm{li}_T{T}_curV'] = mems[0][1][:, 0][::3].numpy()
+                out[f'gpm{li}_T{T}_mass'] = blk.record_attn_weight.numpy()
+            # reference-frame mode (curr_id_emb given) -> SDPA path, memories of the frame itself
+            tgt = seeded(3800 + li, (L, 1, C))
+            tgt_id = None if li == 0 else seeded(3810, (L, 1, C))
+            idemb = seeded(3820, (L, 1, C), 0.5)
+            y, yid, mems = blk(tgt, tgt_id, None, None, curr_id_emb=idemb, size_2d=(h, w), temporal_encoding=temporal)
+            out[f'gpm{li}_ref_out'] = y[:, 0].numpy()
+            out[f'gpm{li}_ref_outid'] = yid[:, 0].numpy()
+            out[f'gpm{li}_ref_gIDV'] = mems[1][3][0, :, 0].numpy()
+        blk = model.LSTT.layers[0]
+        # the two attention modules alone
+        for T in (1, 4, 9):
+            q = seeded(4000 + T, (L, 1, 128))
+            k = seeded(4100 + T, (T * L, 1, 128))
+            v = seeded(4200 + T, (T * L, 1, 1024))
+            u = seeded(4300 + T, (L, 1, 1024))
+            o, attn = blk.long_term_attn(q, k, v, u, (h, w), is_return_attn_weight=True)
+            out[f'gp_T{T}_out'] = o[:, 0].numpy()
+            out[f'gp_T{T}_mass'] = attn.view(1, 1, L, T, L).mean(1)[0].sum(2).numpy()
+        q2 = seeded(4400, (1, 128, h, w))
+        k2 = seeded(4401, (1, 128, h, w))
+        v2 = seeded(4402, (1, 1024, h, w))
+        u2 = seeded(4403, (L, 1, 1024))
+        o, _ = blk.short_term_attn(q2, k2, v2, u2, (h, w))
+        out['lgp_out'] = o[:, 0].numpy()
+        # a map larger than the 15x15 window in both directions (cfg-2 token grid is 31x54)
+        hb, wb = 18, 23
+        q2 = seeded(4410, (1, 128, hb, wb))
+        k2 = seeded(4411, (1, 128, hb, wb))
+        v2 = seeded(4412, (1, 1024, hb, wb))
+        u2 = seeded(4413, (hb * wb, 1, 1024))
+        o, _ = blk.short_term_attn(q2, k2, v2, u2, (hb, wb))
+        out['lgp_big_out'] = o[::2, 0].numpy()
+        x = seeded(4500, (L, 1, 512))
+        o, _ = blk.self_attn(x, x, x, x, (h, w))
+        out['gp_self_out'] = o[:, 0].numpy()
+        # identity embedding with id_norm, and the decoder on a 512-wide input (models/deaot.py:56-68)
+        img = seeded(1100, (1, 3, 97, 129))
+        xs = model.encode_image(img)
+        embs = [seeded(4600 + i, (7 * 9, 1, 512)) for i in range(3)]
+        out['dec_logits'] = model.decode_id_logits(embs, xs)[0].numpy()
+        mask = torch.zeros(1, 1, 97, 129, dtype=torch.int32)
+        mask[:, :, 10:50, 20:70] = 1
+        mask[:, :, 40:90, 60:120] = 3
+        oh = (mask == torch.arange(11).view(1, -1, 1, 1)).float()
+        oh = torch.cat((oh, torch.zeros(1, 1, 97, 129)), 1)
+        out['id_emb'] = model.get_id_emb(oh)[0].numpy()
+    return out
+
+
+def gen_clip(tag, former, latter, n_frames, h, w, out_hw, gap, objs, seed, inject_at=-1, encoder='resnet50', fitted=False,
+             model_name='r50_aotl'):
+    cfg, model, build_engine = load_reference(former, latter, encoder, fitted, model_name)
     frames, mask = make_clip(seed, n_frames, h, w, objs)
     ys = np.linspace(2, out_hw[0] - 3, 12).astype(np.int64)
     xs = np.linspace(2, out_hw[1] - 3, 12).astype(np.int64)
@@ -269,6 +344,15 @@ if __name__ == '__main__':
                             **gen_clip('small_fitted', 1, 2, 48, 161, 193, (160, 192), 2, 3, 11, fitted=True))
         np.savez_compressed(os.path.join(HERE, 'clip_full_fitted.npz'),
                             **gen_clip('full_fitted', 1, 7, 30, 481, 849, (480, 854), 2, 3, 21, fitted=True))
+    if what in ('deaot', 'all'):
+        # R50-DeAOTL (the model eval_vost.sh:11 runs): block-level fixtures and two clips
+        _, model, _ = load_reference(1, 8, model_name='r50_deaotl')
+        np.savez_compressed(os.path.join(HERE, 'deaot_ops.npz'), **gen_deaot_ops(model))
+        np.savez_compressed(os.path.join(HERE, 'deaot_clip_small.npz'),
+                            **gen_clip('deaot_small', 1, 2, 48, 161, 193, (160, 192), 2, 3, 11, model_name='r50_deaotl'))
+        # cfg-2 geometry with the shipped bank size 1 + 8 (configs/models/r50_deaotl.py:8-9, eval_vost.sh:28)
+        np.savez_compressed(os.path.join(HERE, 'deaot_clip_full.npz'),
+                            **gen_clip('deaot_full', 1, 8, 30, 481, 849, (480, 854), 2, 3, 21, model_name='r50_deaotl'))
     if what in ('full', 'all'):
         # cfg-2 geometry: 480x854 video at network size 481x849, bank N = 8, gap 2 so the bank fills
         # by frame 14 and evicts from frame 16

@@ -105,8 +105,12 @@ def _run_clip(name):
         from rmem_ocu_amd.weights import fitted_state_dict
         weights = fitted_state_dict(0)
     else:
-        weights = synth_state_dict(0, encoder='swin_base' if swin else 'resnet50')
-    eng = O.OracleEngine(weights, former, latter, gap, align_corners=not swin)
+        weights = synth_state_dict(0, encoder='swin_base' if swin else 'resnet50', model='deaot' if 'deaot' in name else 'aot')
+    if 'deaot' in name:
+        from oracle.deaot_cpu import OracleDeAOTEngine
+        eng = OracleDeAOTEngine(weights, former, latter, gap)
+    else:
+        eng = O.OracleEngine(weights, former, latter, gap, align_corners=not swin)
     trace, labels, samples = [], [], []
     eng.long_term_mem_gap = gap
     eng.add_reference_frame(frames[0:1], mask, 0)
