@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define RMEM_ABI_VERSION 2
+#define RMEM_ABI_VERSION 3
 
 int rmem_abi_version(void);
 const char* rmem_last_error_string(void);
@@ -45,9 +45,13 @@ typedef struct rmem_conv_desc {
   int ldo;            /* y row stride  (>= Cout) */
   int ldr;            /* residual row stride */
   int ld2;            /* y2 row stride */
-  int relu;           /* activation after bias/residual: 0 none, 1 ReLU, 2 exact (erf) GELU */
+  int relu;           /* activation after bias/residual: 0 none, 1 ReLU, 2 exact (erf) GELU, 3 SiLU (layers/attention.py:89) */
   int out_f32;        /* 1: y is fp32, 0: bf16 */
   int res_f32;        /* 1: residual is fp32, 0: bf16 */
+  int ldx;            /* 1x1 stride-1 problems only: input row stride in elements (0 = Cin); lets a GEMM read a column
+                         range of a wider activation buffer (the torch.split / torch.cat of transformer.py:1104-1124) */
+  int act_begin;      /* the activation applies to output channels >= act_begin (multiple of 8; 0 = all): one GEMM for
+                         linear_QV, whose Q half is raw and whose V half goes through SiLU (transformer.py:1104-1110) */
 } rmem_conv_desc;
 
 /* Problems with few output tiles are cut along K (split-K) when a workspace of at least
@@ -140,6 +144,39 @@ int rmem_groupnorm_nhwc(const void* x, int M, int C, int groups, const float* ga
 
 /* Depth-wise 5x5, pad 2, NHWC bf16; w_t is [25][C] fp32.  Replaces layers/basic.py:19-25, 33. */
 int rmem_dwconv5x5_nhwc(const void* x, const float* w_t, void* y, int H, int W, int C, void* stream);
+
+/* ------------------------------------------------------------------ DeAOT gated propagation attention
+ * Single head, d_att = 128, values DV wide (1024 in R50-DeAOTL):
+ *   out[q, :] = ( softmax_k( (Q[q]+pe_cur) . (K[k]+pe_mem[slot(k)]) / sqrt(128) ) V[k, :] ) * U[q, :]
+ * Replaces layers/attention.py:138-208 (GatedPropagation.forward through `outputs * U`; use_linear False) as called from
+ * layers/transformer.py:1183-1184 (long-term attention over the restricted bank: the K + temporal-embedding
+ * materialisation of 1141-1177 and the [V | ID_V] concatenation of 1179 happen by indexing; attn_mass is
+ * record_attn_weight of 1185-1192) and from 1229 (self-attention, after the linear_QK / V / U GEMMs of attention.py:151-173).
+ * The depth-wise 5x5 and the projection (attention.py:210-211) are rmem_dwconv5x5_nhwc / rmem_conv2d_nhwc calls.
+ * chunks: the rmem_attn_chunk table (<= 64 rows, key_begin a multiple of 64) or NULL for ONE key frame of
+ * keys_per_frame keys cut into nchunks ranges.  The gate U is given as two column ranges: u_a covers [0, usplit),
+ * u_b covers [usplit, DV) or is NULL for all ones (layer 0, transformer.py:1117-1118).
+ * out: bf16 [Lq][ldo]; attn_mass: fp32 [Lq][frames] or NULL. */
+size_t rmem_gated_attn_workspace_bytes(int Lq, int DV, int frames, int keys_per_frame, int nchunks);
+int rmem_gated_attn(const void* q, int ldq,                                        /* bf16 [Lq][ldq], 128 used */
+                    const void* k_bank, long long k_slot_stride, int ldk,          /* bf16 rows of 128 */
+                    const void* v_bank, long long v_slot_stride, int ldv,          /* bf16 rows of DV */
+                    const rmem_attn_chunk* chunks, int nchunks, int frames, int keys_per_frame,
+                    const float* pe_cur, const float* pe_mem,                      /* fp32 [128], [4][128] or NULL */
+                    int Lq, int DV, const void* u_a, int ldua, const void* u_b, int ldub, int usplit,
+                    void* out, int ldo, float* attn_mass, void* workspace, void* stream);
+/* 15x15 local window flavour (layers/attention.py:281-349, use_linear False, one head): keys/values are the previous
+ * frame's [H*W] tokens; a key contributes to a query iff |dy| <= 7 and |dx| <= 7 (the zero padding + 1e8 mask of
+ * 299-303, 338); rel: fp32 [H*W][ldrel] = relative_emb_k(q) (attention.py:305, a rmem_conv2d_nhwc call with fp32 output),
+ * column (dy+7)*15 + (dx+7).  Workspace: rmem_gated_attn_workspace_bytes(H*W, DV, 1, H*W, 8). */
+int rmem_local_gated_attn(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const float* rel, int ldrel,
+                          int H, int W, int DV, const void* u_a, int ldua, const void* u_b, int ldub, int usplit,
+                          void* out, int ldo, void* workspace, void* stream);
+/* HIP-event timing of the k_gp_pv launches of rmem_gated_attn calls that carry a chunk table (bench.py's roofline leg) */
+int rmem_gated_profile_start(void);
+int rmem_gated_profile_stop(double* total_ms, double* total_flops, int* launches);
+/* strided 2-D device copy (rows of row_bytes): the torch.cat / slice bookkeeping of transformer.py:840-872 */
+int rmem_copy2d_async(void* dst, long long dst_pitch, const void* src, long long src_pitch, long long row_bytes, int rows, void* stream);
 
 /* ------------------------------------------------------------------ layout / resampling */
 /* fp32 [3][H][W] image -> bf16 [H][W][8] (channels 3..7 zero): input of encoders/resnet.py:179. */

@@ -11,7 +11,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('RMEM_LIB_PATH') or os.path.join(_HERE, 'librmem_hip.so')   # override: kernel experiments only
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class RmemError(RuntimeError):
@@ -20,7 +20,7 @@ class RmemError(RuntimeError):
 
 class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int) for n in ('H', 'W', 'Cin', 'Ho', 'Wo', 'Cout', 'KH', 'KW', 'stride', 'pad',
-                                       'ldo', 'ldr', 'ld2', 'relu', 'out_f32', 'res_f32')]
+                                       'ldo', 'ldr', 'ld2', 'relu', 'out_f32', 'res_f32', 'ldx', 'act_begin')]
 
 
 class AttnChunk(C.Structure):
@@ -57,6 +57,13 @@ SIGNATURES = {
     'rmem_tta_merge': (_i, [C.POINTER(_vp), C.POINTER(_i), _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     'rmem_mask_iou_counts': (_i, [_vp, _vp, _ll, _i, _i, _vp, _vp]),
     'rmem_copy_async': (_i, [_vp, _vp, C.c_size_t, _vp]),
+    'rmem_copy2d_async': (_i, [_vp, _ll, _vp, _ll, _ll, _i, _vp]),
+    'rmem_gated_attn_workspace_bytes': (C.c_size_t, [_i, _i, _i, _i, _i]),
+    'rmem_gated_attn': (_i, [_vp, _i, _vp, _ll, _i, _vp, _ll, _i, _vp, _i, _i, _i, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _i, _vp, _i,
+                             _vp, _vp, _vp]),
+    'rmem_local_gated_attn': (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _i, _vp, _i, _vp, _vp]),
+    'rmem_gated_profile_start': (_i, []),
+    'rmem_gated_profile_stop': (_i, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i)]),
     'rmem_graph_begin': (_i, [_vp]),
     'rmem_graph_end': (_i, [_vp, C.POINTER(_vp)]),
     'rmem_graph_launch': (_i, [_vp, _vp]),

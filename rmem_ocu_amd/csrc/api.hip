@@ -66,3 +66,12 @@ extern "C" int rmem_copy_async(void* dst, const void* src, size_t bytes, void* s
   HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, (hipStream_t)stream), "rmem_copy_async");
   return 0;
 }
+
+extern "C" int rmem_copy2d_async(void* dst, long long dst_pitch, const void* src, long long src_pitch, long long row_bytes, int rows,
+                                 void* stream) {
+  RMEM_REQUIRE(dst && src && row_bytes > 0 && rows > 0 && dst_pitch >= row_bytes && src_pitch >= row_bytes,
+               "rmem_copy2d_async: bad argument");
+  HIP_TRY(hipMemcpy2DAsync(dst, (size_t)dst_pitch, src, (size_t)src_pitch, (size_t)row_bytes, (size_t)rows, hipMemcpyDeviceToDevice,
+                           (hipStream_t)stream), "rmem_copy2d_async");
+  return 0;
+}

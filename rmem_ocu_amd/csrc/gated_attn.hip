@@ -1,0 +1,670 @@
+// Gated propagation attention of the DeAOT path for gfx950 (CDNA4): single head, d_att = 128, values DV = 1024 wide.
+//
+// Replaces layers/attention.py:138-216 (GatedPropagation.forward up to `outputs * U`; the depth-wise 5x5 and the projection
+// that follow are rmem_dwconv5x5_nhwc / rmem_conv2d_nhwc calls) as called from layers/transformer.py:1183-1184 (long-term:
+// keys = the restricted memory bank + temporal embedding, with the attention-weight recording of 1185-1192) and 1229
+// (self-attention), and layers/attention.py:281-349 (LocalGatedPropagation: 15x15 window, learned relative embedding).
+//
+// With one head the value side (2 * Lq * Lk * 1024 flop) outweighs the score side (2 * Lq * Lk * 128) eight to one, and
+// one 128 x Lk score matrix serves all 1024 value columns.  So, unlike the d = 32 memory read (attention.hip), the
+// probabilities are materialised ONCE in bf16 and the value side runs as a plain tiled GEMM:
+//   k_gp_scores<., 0>  S = Q K^T (+ temporal-PE bias | window mask + relative embedding)  ->  per-chunk row maxima
+//   k_gp_scores<., 1>  same S again (6.5 GFLOP at cfg 2, cheaper than storing fp32 S)     ->  P = exp2(S - max) in bf16,
+//                      [Lq][frames * Lp] with every 64-key tile fully written (zeros past a frame's end); per-chunk row sums
+//   k_gp_pv            O = P V: 128 x 256 output tile per workgroup, 4 waves of 64 x 128, 64-key steps, P and V tiles
+//                      through a 3-deep LDS ring filled by global_load_lds (source-side XOR swizzle), V read transposed
+//                      (ds_read_b64_tr_b16); key groups give split-K slabs
+//   k_gp_combine       sum the slabs, 1 / row sum, gate by U, bf16 (and the per-memory-frame probability mass)
+// Scores live in the log2 domain (Q pre-scaled by log2(e) / sqrt(128)).  Exact softmax: the maximum is the true row
+// maximum, so P <= 1 and the bf16 P keeps 8 significant bits at every magnitude.
+#include "common.h"
+#include "../../include/rmem.h"
+#include <math.h>
+
+namespace {
+
+constexpr int DQ = 128;    // d_att
+constexpr int KT = 64;     // keys per tile
+constexpr int QT = 128;    // queries per workgroup
+constexpr int CW = 256;    // value columns per k_gp_pv workgroup
+constexpr int MAX_ROWS = 64;
+constexpr float NEG_BIG = -1.0e30f;
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr int WIN_R = 7, WIN = 15;
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+__device__ uint4 g_gp_zero16[1];
+
+struct GpRow { int slot, kb, kn, pe_slot, t; };
+
+struct GpParams {
+  const bf16* q; int ldq;
+  const bf16* k; long k_slot_stride; int ldk;
+  const bf16* v; long v_slot_stride; int ldv;
+  const rmem_attn_chunk* rows; int nrows; int lk; int per;
+  const float* pe_cur; const float* pe_mem;
+  int Lq, Lqp;             // Lqp: Lq rounded up to QT (row count of P, mpart, lpart, slabs)
+  int Lp; int ldp;         // P columns per memory frame (multiple of 64), P row stride
+  float* mpart; float* lpart; bf16* P;
+  float qscale;
+  int H, W; const float* rel; int ldrel;      // local-window mode
+  int DV, nq, ncs, groups, rows_per_group;
+  float* slabs;
+};
+
+// MODE 0: one key frame split into nrows ranges of `per` keys; 1: chunk table over the memory bank; 2: as 0 with the 15x15
+// window mask and the relative embedding
+template <int MODE>
+__device__ __forceinline__ GpRow get_row(const GpParams& p, int r) {
+  GpRow o;
+  if (MODE == 1) {
+    const rmem_attn_chunk c = p.rows[r];
+    o.slot = c.slot; o.kb = c.key_begin; o.kn = c.key_count; o.pe_slot = c.pe_slot; o.t = c.t;
+  } else {
+    o.slot = 0; o.kb = r * p.per; o.kn = min(p.per, p.lk - o.kb); o.pe_slot = -1; o.t = 0;
+  }
+  return o;
+}
+
+__device__ __forceinline__ float half_max(float v) {      // over the 32 lanes that share lane >> 5
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float half_sum(float v) {
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// PASS 0: partial row maxima of one (query tile, table row); PASS 1: probabilities and partial row sums.
+// 4 waves = (query half qh) x (key half kh): a wave owns 64 queries x 32 keys of every 64-key tile.  S = Q K^T with the
+// query on the MFMA row: A = Q fragments (registers, whole kernel), B = K rows from LDS ([key][128], 16-byte chunks
+// XOR-swizzled by key & 15).  The accumulator then has the KEY on the lane and 16 query rows per block in registers, so a
+// row of P leaves as 32 consecutive bf16.
+template <int MODE, int PASS>
+__global__ __launch_bounds__(256) void k_gp_scores(GpParams p) {
+  __shared__ __attribute__((aligned(16))) bf16 Ks[2][KT * DQ];
+  __shared__ float red[2][QT];
+  __shared__ float biasq[QT];
+  __shared__ float mq[QT];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int qh = wave >> 1, kh = wave & 1, lq = lane & 31, kg = lane >> 5;
+  const int q0 = blockIdx.x * QT;
+  const GpRow row = get_row<MODE>(p, blockIdx.y);
+  const bf16* Kp = p.k + (long)row.slot * p.k_slot_stride + (long)row.kb * p.ldk;
+  const bool has_cur = MODE == 1 && p.pe_cur != nullptr;
+  const bool has_mem = MODE == 1 && row.pe_slot >= 0 && p.pe_mem != nullptr;
+
+  // ---- Q fragments (A operand): query rows 64 qh + 32 b + (lane & 31), d = 16 s + 8 kg .. + 7 ----
+  bf16x8 qf[2][8];
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const int qrow = min(q0 + 64 * qh + 32 * b + lq, p.Lq - 1);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const int d0 = 16 * s + 8 * kg;
+      const bf16x8 raw = *reinterpret_cast<const bf16x8*>(p.q + (long)qrow * p.ldq + d0);
+      f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0;
+      if (has_cur) { c0 = *reinterpret_cast<const f32x4*>(p.pe_cur + d0); c1 = *reinterpret_cast<const f32x4*>(p.pe_cur + d0 + 4); }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) qf[b][s][j] = (bf16)(((float)raw[j] + (j < 4 ? c0[j & 3] : c1[j & 3])) * p.qscale);
+    }
+  }
+
+  // ---- per-query constants in LDS: temporal-PE logit bias of this table row, final row maximum (PASS 1) ----
+  {
+    const int ql = tid & (QT - 1), hf = tid >> 7;
+    const int qrow = min(q0 + ql, p.Lq - 1);
+    float part = 0.f;
+    if (has_mem) {
+      const bf16* qp = p.q + (long)qrow * p.ldq + 64 * hf;
+      const float* pm = p.pe_mem + row.pe_slot * DQ + 64 * hf;
+      const float* pc = p.pe_cur ? p.pe_cur + 64 * hf : nullptr;
+      for (int d = 0; d < 64; ++d) {
+        const bf16 qs = (bf16)(((float)qp[d] + (pc ? pc[d] : 0.f)) * p.qscale);
+        part += (float)qs * pm[d];
+      }
+    }
+    red[hf][ql] = part;
+    __syncthreads();
+    if (tid < QT) biasq[tid] = red[0][tid] + red[1][tid];
+    __syncthreads();
+    if (PASS == 1) {
+      float m = NEG_BIG;
+      for (int r = hf; r < p.nrows; r += 2) m = fmaxf(m, p.mpart[(long)r * p.Lqp + q0 + ql]);
+      red[hf][ql] = m;
+      __syncthreads();
+      if (tid < QT) mq[tid] = fmaxf(red[0][tid], red[1][tid]);
+      __syncthreads();
+    }
+  }
+  // this lane's 2 x 16 query rows: ql(b, r) = 64 qh + 32 b + (r & 3) + 8 (r >> 2) + 4 kg
+  float off[2][16];      // PASS 0: bias; PASS 1: bias - row maximum
+  int qyx[2][16];        // MODE 2: (qy << 16) | qx
+#pragma unroll
+  for (int b = 0; b < 2; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ql = 64 * qh + 32 * b + (r & 3) + 8 * (r >> 2) + 4 * kg;
+      off[b][r] = PASS == 1 ? biasq[ql] - mq[ql] : biasq[ql];
+      if (MODE == 2) {
+        const int qg = min(q0 + ql, p.Lq - 1);
+        const int qy = qg / p.W;
+        qyx[b][r] = (qy << 16) | (qg - qy * p.W);
+      }
+    }
+
+  // ---- tile range: in window mode only key tiles that can intersect a window of this query tile are visited ----
+  const int ntiles = (row.kn + KT - 1) / KT;
+  int t_lo = 0, t_hi = ntiles;
+  if (MODE == 2) {
+    const int y0 = q0 / p.W, y1 = min(q0 + QT - 1, p.Lq - 1) / p.W;
+    const int key_lo = max(0, (y0 - WIN_R) * p.W), key_hi = min(p.lk, (y1 + WIN_R + 1) * p.W);   // [key_lo, key_hi)
+    t_lo = max(0, (key_lo - row.kb) / KT);
+    t_hi = min(ntiles, (key_hi - row.kb + KT - 1) / KT);
+    if (key_hi <= row.kb || key_lo >= row.kb + row.kn) { t_lo = 0; t_hi = 0; }
+    if (t_hi < t_lo) t_hi = t_lo;
+  }
+  bf16* Pq = p.P + (long)row.t * p.Lp + row.kb;       // + q * ldp + key index inside the row
+  if (MODE == 2 && PASS == 1) {                       // tiles outside the window band: probability zero
+    const bf16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int t = 0; t < ntiles; ++t) {
+      if (t >= t_lo && t < t_hi) continue;
+      for (int i = tid; i < QT * 8; i += 256)
+        *reinterpret_cast<bf16x8*>(Pq + (long)(q0 + (i >> 3)) * p.ldp + t * KT + (i & 7) * 8) = z8;
+    }
+  }
+
+  float mx[2][16], ls[2][16];
+#pragma unroll
+  for (int b = 0; b < 2; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { mx[b][r] = NEG_BIG; ls[b][r] = 0.f; }
+
+  // staging: thread -> 4 x (key, 16-byte chunk) of the 64 x 256 B tile
+  bf16x8 rk[4];
+  const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+  auto load_tile = [&](int t) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int id = tid + 256 * i, key = id >> 4, chunk = id & 15;
+      const int kidx = t * KT + key;
+      rk[i] = kidx < row.kn ? *reinterpret_cast<const bf16x8*>(Kp + (long)kidx * p.ldk + chunk * 8) : zero8;
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int id = tid + 256 * i, key = id >> 4, chunk = id & 15;
+      *reinterpret_cast<bf16x8*>(&Ks[buf][key * DQ + ((chunk ^ (key & 15)) << 3)]) = rk[i];
+    }
+  };
+
+  if (t_lo < t_hi) {
+    load_tile(t_lo);
+    store_tile(0);
+  }
+  __syncthreads();
+  const int kl = 32 * kh + lq;                        // this lane's key inside a tile
+  for (int t = t_lo; t < t_hi; ++t) {
+    const int cur = (t - t_lo) & 1;
+    if (t + 1 < t_hi) load_tile(t + 1);
+    f32x16 acc[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const bf16x8 kf = *reinterpret_cast<const bf16x8*>(&Ks[cur][kl * DQ + (((2 * s + kg) ^ (kl & 15)) << 3)]);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[0][s], kf, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[1][s], kf, acc[1], 0, 0, 0);
+    }
+    const int kidx = t * KT + kl;
+    const bool kvalid = kidx < row.kn;
+    int ky = 0, kx = 0;
+    if (MODE == 2) {
+      const int kgl = row.kb + kidx;
+      ky = kgl / p.W;
+      kx = kgl - ky * p.W;
+    }
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        bool ok = kvalid;
+        float sv = acc[b][r] + off[b][r];
+        if (MODE == 2) {
+          const int dy = ky - (qyx[b][r] >> 16) + WIN_R, dx = kx - (qyx[b][r] & 0xffff) + WIN_R;
+          ok = ok && (unsigned)dy < (unsigned)WIN && (unsigned)dx < (unsigned)WIN;
+          if (ok) {
+            const int ql = 64 * qh + 32 * b + (r & 3) + 8 * (r >> 2) + 4 * kg;
+            sv += p.rel[(long)min(q0 + ql, p.Lq - 1) * p.ldrel + dy * WIN + dx] * LOG2E;
+          }
+        }
+        if (PASS == 0) {
+          mx[b][r] = fmaxf(mx[b][r], ok ? sv : NEG_BIG);
+        } else {
+          const bf16 pb = (bf16)(ok ? __builtin_amdgcn_exp2f(sv) : 0.f);
+          ls[b][r] += (float)pb;
+          const int ql = 64 * qh + 32 * b + (r & 3) + 8 * (r >> 2) + 4 * kg;
+          Pq[(long)(q0 + ql) * p.ldp + kidx] = pb;
+        }
+      }
+    if (t + 1 < t_hi) store_tile(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- reduce over the keys (lanes) and over the two key halves (waves) ----
+#pragma unroll
+  for (int b = 0; b < 2; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float v = PASS == 0 ? half_max(mx[b][r]) : half_sum(ls[b][r]);
+      if (lq == 0) red[kh][64 * qh + 32 * b + (r & 3) + 8 * (r >> 2) + 4 * kg] = v;
+    }
+  __syncthreads();
+  if (tid < QT) {
+    float* dst = (PASS == 0 ? p.mpart : p.lpart) + (long)blockIdx.y * p.Lqp + q0 + tid;
+    if (PASS == 0) {
+      const float m = fmaxf(red[0][tid], red[1][tid]);       // the bias / relative embedding is already inside every score
+      *dst = m > 0.5f * NEG_BIG ? m : NEG_BIG;
+    } else {
+      *dst = red[0][tid] + red[1][tid];
+    }
+  }
+}
+
+// O = P V for one (query tile of 128, value slice of 256, key group).  Tiles of 64 keys stream through a 3-deep LDS ring
+// by LDS-DMA: P tile [128 q][64 keys] (16-byte chunk c of row r at slot c ^ ((r >> 1) & 7)), V tile [64 keys][256 c]
+// (chunk c of key row k at slot c ^ ((k & 3) << 1), which spreads the four key rows of a transposed read over four
+// 32-byte bank groups).  The swizzles are applied to the per-lane SOURCE address, the LDS side of a DMA is linear.
+// Waves = (query half qh) x (column half ch), 64 x 128 outputs each = 8 accumulator tiles of 32 x 32.
+template <int MODE, bool TIMED>
+__global__ __launch_bounds__(256) void k_gp_pv(GpParams p) {
+  constexpr int ST = 3, PB = QT * KT * 2, VB = KT * CW * 2, SB = PB + VB;
+  __shared__ __attribute__((aligned(16))) char smem[ST * SB];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int qh = wave >> 1, ch = wave & 1, lq = lane & 31, kg = lane >> 5;
+  // XCD-aware decode (hardware deals block ids round-robin over 8 XCDs): ids congruent mod 8 walk (group, query tile,
+  // value slice) with the value slice fastest, so one XCD's L2 sees few distinct P and V tiles at a time
+  int g, qt, cs;
+  {
+    const int total = p.nq * p.ncs * p.groups;
+    const int b = blockIdx.x, xcd = b & 7, j = b >> 3;
+    const int qd = total >> 3, rm = total & 7;
+    const int idx = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + j;
+    cs = idx % p.ncs;
+    const int rest = idx / p.ncs;
+    qt = rest % p.nq;
+    g = rest / p.nq;
+  }
+  const int q0 = qt * QT, c0 = cs * CW;
+  const int r_begin = g * p.rows_per_group, r_end = min(p.nrows, r_begin + p.rows_per_group);
+  int ntl = 0;
+  for (int r = r_begin; r < r_end; ++r) ntl += (get_row<MODE>(p, r).kn + KT - 1) / KT;
+
+  // ---- DMA source bookkeeping: 4 P pieces and 8 V pieces of 16 bytes per lane and stage ----
+  int p_off[4], v_key[8], v_off[8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int s = (wave * 4 + i) * 64 + lane, r = s >> 3, lc = (s & 7) ^ ((r >> 1) & 7);
+    p_off[i] = (q0 + r) * p.ldp + lc * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int s = (wave * 8 + i) * 64 + lane, key = s >> 5, lc = (s & 31) ^ ((key & 3) << 1);
+    v_key[i] = key;
+    v_off[i] = key * p.ldv + c0 + lc * 8;
+  }
+  const char* zero = reinterpret_cast<const char*>(g_gp_zero16);
+  int i_row = r_begin, i_t = 0;
+  GpRow ir = get_row<MODE>(p, min(i_row, p.nrows - 1));
+  auto issue = [&](int stage) {
+    char* Ps = smem + stage * SB;
+    char* Vs = Ps + PB;
+    const bf16* psrc = p.P + (long)ir.t * p.Lp + ir.kb + i_t * KT;
+    const bf16* vsrc = p.v + (long)ir.slot * p.v_slot_stride + (long)(ir.kb + i_t * KT) * p.ldv;
+    const int left = ir.kn - i_t * KT;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t)(psrc + p_off[i]), (lptr_t)(Ps + (wave * 4 + i) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const char* src = v_key[i] < left ? reinterpret_cast<const char*>(vsrc + v_off[i]) : zero;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Vs + (wave * 8 + i) * 1024), 16, 0, 0);
+    }
+    if (++i_t * KT >= ir.kn) {
+      i_t = 0;
+      ++i_row;
+      if (i_row < r_end) ir = get_row<MODE>(p, i_row);
+    }
+  };
+
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
+
+  // fragment addressing.  P (A operand): row 64 qh + 32 a + lq, logical chunk 2 s + kg.  V (B operand, transposed read):
+  // the 16-lane group (lane >> 4) & 1 covers 16 columns; lane 4 q' + p' of it addresses key row q', columns 4 p' .. 4 p' + 3
+  int pa_row[2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a) pa_row[a] = 64 * qh + 32 * a + lq;
+  const int tq = (lane & 15) >> 2, tp = lane & 3, tg = (lane >> 4) & 1;
+  int vb_off[4];        // byte offset inside a key row of this lane's 8 bytes, per 32-column block
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int col = 128 * ch + 32 * c + 16 * tg + 4 * tp;
+    vb_off[c] = ((((col >> 3) ^ (tq << 1)) << 4) | ((col & 7) << 1));
+  }
+
+  if (ntl > 0) issue(0);
+  if (ntl > 1) issue(1);
+  int stage = 0;
+  for (int j = 0; j < ntl; ++j) {
+    if (j + 1 < ntl) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const int nxt = stage == 0 ? 2 : stage - 1;
+    if (j + 2 < ntl) issue(nxt);
+    const char* Ps = smem + stage * SB;
+    const char* Vs = Ps + PB;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      bf16x8 af[2], bfr[4];
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+        af[a] = *reinterpret_cast<const bf16x8*>(Ps + pa_row[a] * 128 + (((2 * s + kg) ^ ((pa_row[a] >> 1) & 7)) << 4));
+      const char* vrow = Vs + (16 * s + 8 * kg + tq) * (CW * 2);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vrow + vb_off[c]));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vrow + 4 * (CW * 2) + vb_off[c]));
+        const __attribute__((ext_vector_type(8))) short b16 = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        bfr[c] = __builtin_bit_cast(bf16x8, b16);
+      }
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bfr[c], acc[a][c], 0, 0, 0);
+    }
+    stage = stage == 2 ? 0 : stage + 1;
+  }
+
+  // slab[g][q][c]: accumulator row (r & 3) + 8 (r >> 2) + 4 kg is the query, the lane is the column
+  float* slab = p.slabs + (long)g * p.Lqp * p.DV;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int q = q0 + 64 * qh + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * kg;
+      if (q < p.Lq) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) slab[(long)q * p.DV + c0 + 128 * ch + 32 * c + lq] = acc[a][c][r];
+      }
+    }
+}
+
+struct GpCombine {
+  const float* slabs; int groups; const float* lpart; int nrows; int Lq, Lqp, DV;
+  const bf16* ua; int ldua; const bf16* ub; int ldub; int usplit;
+  bf16* out; int ldo;
+  const rmem_attn_chunk* rows; float* mass; int T;
+};
+
+// out[q, c] = (sum_g slab[g][q][c]) / l[q] * U[q][c]; thread = 8 columns of one query
+__global__ __launch_bounds__(256) void k_gp_combine(GpCombine p) {
+  const int vpr = p.DV / 8;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)p.Lq * vpr) return;
+  const int q = (int)(i / vpr), c = (int)(i - (long)q * vpr) * 8;
+  float l = 0.f;
+  for (int r = 0; r < p.nrows; ++r) l += p.lpart[(long)r * p.Lqp + q];
+  float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int g = 0; g < p.groups; ++g) {
+    const float* s = p.slabs + ((long)g * p.Lqp + q) * p.DV + c;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(s), b = *reinterpret_cast<const f32x4*>(s + 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[j] += a[j]; v[4 + j] += b[j]; }
+  }
+  const float inv = 1.f / l;
+  bf16x8 o;
+  if (c < p.usplit) {
+    const bf16x8 u = *reinterpret_cast<const bf16x8*>(p.ua + (long)q * p.ldua + c);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (bf16)(v[j] * inv * (float)u[j]);
+  } else if (p.ub) {
+    const bf16x8 u = *reinterpret_cast<const bf16x8*>(p.ub + (long)q * p.ldub + (c - p.usplit));
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (bf16)(v[j] * inv * (float)u[j]);
+  } else {                                          // torch.ones_like(curr_U) half of layer 0 (transformer.py:1117-1118)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (bf16)(v[j] * inv);
+  }
+  *reinterpret_cast<bf16x8*>(p.out + (long)q * p.ldo + c) = o;
+}
+
+// mass[q][t] = sum of the row sums of frame t / total (transformer.py:1185-1192 with one head)
+__global__ __launch_bounds__(256) void k_gp_mass(GpCombine p) {
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= p.Lq) return;
+  float acc[32];
+#pragma unroll
+  for (int t = 0; t < 32; ++t) acc[t] = 0.f;
+  float l = 0.f;
+  for (int r = 0; r < p.nrows; ++r) {
+    const float v = p.lpart[(long)r * p.Lqp + q];
+    const int t = p.rows[r].t;
+    l += v;
+#pragma unroll
+    for (int tt = 0; tt < 32; ++tt) acc[tt] += tt == t ? v : 0.f;
+  }
+  const float inv = 1.f / l;
+#pragma unroll
+  for (int t = 0; t < 32; ++t)
+    if (t < p.T) p.mass[(long)q * p.T + t] = acc[t] * inv;
+}
+
+struct GpPlan { int Lqp, Lp, ldp, nrows, groups, rpg; size_t off_l, off_p, off_s, total; };
+
+GpPlan plan(int Lq, int DV, int frames, int keys_per_frame, int nrows) {
+  GpPlan g;
+  g.Lqp = (Lq + QT - 1) / QT * QT;
+  g.Lp = (keys_per_frame + KT - 1) / KT * KT;
+  g.ldp = frames * g.Lp;
+  g.nrows = nrows;
+  const int tiles = (g.Lqp / QT) * (DV / CW);
+  int groups = tiles >= 256 ? 1 : 256 / tiles;      // about one workgroup per CU
+  if (groups > nrows) groups = nrows;
+  g.rpg = (nrows + groups - 1) / groups;
+  g.groups = (nrows + g.rpg - 1) / g.rpg;
+  auto al = [](size_t x) { return (x + 255) / 256 * 256; };
+  g.off_l = al((size_t)nrows * g.Lqp * 4);
+  g.off_p = g.off_l + al((size_t)nrows * g.Lqp * 4);
+  g.off_s = g.off_p + al((size_t)g.Lqp * g.ldp * 2);
+  g.total = g.off_s + al((size_t)g.groups * g.Lqp * DV * 4);
+  return g;
+}
+
+int check_common(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, int Lq, int DV, const void* ua, int ldua,
+                 const void* ub, int ldub, int usplit, const void* out, int ldo, const void* ws, const char* who) {
+  RMEM_REQUIRE(q && k && v && ua && out && ws, "rmem_gated_attn: null argument");
+  RMEM_REQUIRE(Lq > 0 && DV >= CW && DV % CW == 0 && DV <= 2048, "rmem_gated_attn: DV must be a multiple of 256 (<= 2048)");
+  RMEM_REQUIRE(ldq >= DQ && ldk >= DQ && ldv >= DV && ldo >= DV, "rmem_gated_attn: leading dimension too small (d_att is 128)");
+  RMEM_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 8 == 0 && ldua % 8 == 0 && (!ub || ldub % 8 == 0),
+               "rmem_gated_attn: leading dimensions must be multiples of 8 elements");
+  RMEM_REQUIRE(usplit > 0 && usplit % 8 == 0 && usplit <= DV && ldua >= usplit && (!ub || ldub >= DV - usplit),
+               "rmem_gated_attn: bad gate split");
+  RMEM_REQUIRE(((uintptr_t)q % 16) == 0 && ((uintptr_t)k % 16) == 0 && ((uintptr_t)v % 16) == 0 && ((uintptr_t)ua % 16) == 0 &&
+               ((uintptr_t)ub % 16) == 0 && ((uintptr_t)out % 16) == 0 && ((uintptr_t)ws % 256) == 0,
+               "rmem_gated_attn: pointers must be 16-byte aligned (workspace 256)");
+  (void)who;
+  return 0;
+}
+
+// ---- optional launch timing of k_gp_pv (bench.py's roofline leg for the DeAOT workload) ----
+struct GpProf {
+  bool on = false;
+  float bracket_ms = 0.f;
+  hipEvent_t ev[2 * 256];
+  bool have = false;
+  double flops[256];
+  int used = 0;
+};
+GpProf g_gprof;
+__global__ void k_gp_nop() {}
+
+template <int MODE>
+void launch_all(GpParams& p, const GpPlan& g, GpCombine& c, bool timed, double flops, hipStream_t s) {
+  const dim3 sg(p.nq, p.nrows);
+  hipLaunchKernelGGL((k_gp_scores<MODE, 0>), sg, dim3(256), 0, s, p);
+  hipLaunchKernelGGL((k_gp_scores<MODE, 1>), sg, dim3(256), 0, s, p);
+  const dim3 pg(p.nq * p.ncs * p.groups);
+  constexpr int PM = MODE == 1 ? 1 : 0;
+  int slot = -1;
+  if (timed && g_gprof.on && g_gprof.used < 256) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(s, &cs);
+    if (cs == hipStreamCaptureStatusNone) slot = g_gprof.used++;
+  }
+  if (slot >= 0) {
+    (void)hipEventRecord(g_gprof.ev[2 * slot], s);
+    hipLaunchKernelGGL((k_gp_pv<PM, true>), pg, dim3(256), 0, s, p);
+    (void)hipEventRecord(g_gprof.ev[2 * slot + 1], s);
+    g_gprof.flops[slot] = flops;
+  } else {
+    hipLaunchKernelGGL((k_gp_pv<PM, false>), pg, dim3(256), 0, s, p);
+  }
+  hipLaunchKernelGGL(k_gp_combine, dim3((unsigned)(((long)c.Lq * (c.DV / 8) + 255) / 256)), dim3(256), 0, s, c);
+  if (c.mass) hipLaunchKernelGGL(k_gp_mass, dim3((c.Lq + 255) / 256), dim3(256), 0, s, c);
+  (void)g;
+}
+
+}  // namespace
+
+extern "C" int rmem_gated_profile_start(void) {
+  if (!g_gprof.have) {
+    for (int i = 0; i < 512; ++i)
+      if (hipEventCreate(&g_gprof.ev[i]) != hipSuccess) { rmem_set_error("rmem_gated_profile_start: hipEventCreate failed"); return -3; }
+    g_gprof.have = true;
+  }
+  hipStream_t cs;
+  float best = 1e9f;
+  if (hipStreamCreate(&cs) == hipSuccess) {
+    for (int i = 0; i < 32; ++i) {
+      (void)hipEventRecord(g_gprof.ev[0], cs);
+      hipLaunchKernelGGL(k_gp_nop, dim3(1), dim3(64), 0, cs);
+      (void)hipEventRecord(g_gprof.ev[1], cs);
+      (void)hipEventSynchronize(g_gprof.ev[1]);
+      float t = 0.f;
+      if (hipEventElapsedTime(&t, g_gprof.ev[0], g_gprof.ev[1]) == hipSuccess && t < best) best = t;
+    }
+    (void)hipStreamDestroy(cs);
+  }
+  g_gprof.bracket_ms = best < 1e8f ? best : 0.f;
+  g_gprof.used = 0;
+  g_gprof.on = true;
+  return 0;
+}
+
+extern "C" int rmem_gated_profile_stop(double* total_ms, double* total_flops, int* launches) {
+  g_gprof.on = false;
+  double ms = 0.0, fl = 0.0;
+  for (int i = 0; i < g_gprof.used; ++i) {
+    float t = 0.f;
+    if (hipEventSynchronize(g_gprof.ev[2 * i + 1]) != hipSuccess ||
+        hipEventElapsedTime(&t, g_gprof.ev[2 * i], g_gprof.ev[2 * i + 1]) != hipSuccess) {
+      rmem_set_error("rmem_gated_profile_stop: event query failed");
+      return -3;
+    }
+    ms += fmaxf(t - g_gprof.bracket_ms, 0.f);
+    fl += g_gprof.flops[i];
+  }
+  if (total_ms) *total_ms = ms;
+  if (total_flops) *total_flops = fl;
+  if (launches) *launches = g_gprof.used;
+  return 0;
+}
+
+extern "C" size_t rmem_gated_attn_workspace_bytes(int Lq, int DV, int frames, int keys_per_frame, int nrows) {
+  if (Lq <= 0 || DV < CW || DV % CW || frames < 1 || keys_per_frame < 1 || nrows < 1 || nrows > MAX_ROWS) return 0;
+  return plan(Lq, DV, frames, keys_per_frame, nrows).total;
+}
+
+extern "C" int rmem_gated_attn(const void* q, int ldq, const void* k_bank, long long k_slot_stride, int ldk, const void* v_bank,
+                               long long v_slot_stride, int ldv, const rmem_attn_chunk* chunks, int nchunks, int frames,
+                               int keys_per_frame, const float* pe_cur, const float* pe_mem, int Lq, int DV, const void* u_a,
+                               int ldua, const void* u_b, int ldub, int usplit, void* out, int ldo, float* attn_mass,
+                               void* workspace, void* stream) {
+  if (check_common(q, ldq, k_bank, ldk, v_bank, ldv, Lq, DV, u_a, ldua, u_b, ldub, usplit, out, ldo, workspace, "rmem_gated_attn")) return -1;
+  RMEM_REQUIRE(frames >= 1 && keys_per_frame >= 1, "rmem_gated_attn: frames and keys_per_frame must be >= 1");
+  RMEM_REQUIRE(nchunks >= 1 && nchunks <= MAX_ROWS, "rmem_gated_attn: 1 <= nchunks <= 64");
+  RMEM_REQUIRE(chunks || frames == 1, "rmem_gated_attn: more than one key frame needs a chunk table");
+  RMEM_REQUIRE(!attn_mass || (chunks && frames <= 32), "rmem_gated_attn: the mass output needs a chunk table and <= 32 frames");
+  RMEM_REQUIRE(!pe_mem || chunks, "rmem_gated_attn: pe_mem needs a chunk table");
+  RMEM_REQUIRE(k_slot_stride % 8 == 0 && v_slot_stride % 8 == 0, "rmem_gated_attn: slot strides must be multiples of 8 elements");
+  GpParams p = {};
+  p.q = (const bf16*)q; p.ldq = ldq; p.k = (const bf16*)k_bank; p.k_slot_stride = k_slot_stride; p.ldk = ldk;
+  p.v = (const bf16*)v_bank; p.v_slot_stride = v_slot_stride; p.ldv = ldv;
+  p.rows = chunks; p.lk = keys_per_frame;
+  int nrows = nchunks;
+  if (!chunks) {                 // one key frame cut into ranges that start on tile boundaries
+    p.per = ((keys_per_frame + nchunks - 1) / nchunks + KT - 1) / KT * KT;
+    nrows = (keys_per_frame + p.per - 1) / p.per;
+  }
+  p.nrows = nrows;
+  const GpPlan g = plan(Lq, DV, frames, keys_per_frame, nrows);
+  p.pe_cur = pe_cur; p.pe_mem = pe_mem; p.Lq = Lq; p.Lqp = g.Lqp; p.Lp = g.Lp; p.ldp = g.ldp;
+  RMEM_REQUIRE((long)g.Lqp * g.ldp < (1L << 31), "rmem_gated_attn: probability matrix exceeds 2^31 elements");
+  char* ws = (char*)workspace;
+  p.mpart = (float*)ws; p.lpart = (float*)(ws + g.off_l); p.P = (bf16*)(ws + g.off_p); p.slabs = (float*)(ws + g.off_s);
+  p.qscale = LOG2E / sqrtf((float)DQ);
+  p.DV = DV; p.nq = g.Lqp / QT; p.ncs = DV / CW; p.groups = g.groups; p.rows_per_group = g.rpg;
+  GpCombine c = {};
+  c.slabs = p.slabs; c.groups = g.groups; c.lpart = p.lpart; c.nrows = nrows; c.Lq = Lq; c.Lqp = g.Lqp; c.DV = DV;
+  c.ua = (const bf16*)u_a; c.ldua = ldua; c.ub = (const bf16*)u_b; c.ldub = ldub; c.usplit = usplit;
+  c.out = (bf16*)out; c.ldo = ldo; c.rows = chunks; c.mass = attn_mass; c.T = frames;
+  hipStream_t s = (hipStream_t)stream;
+  const double flops = 2.0 * (double)Lq * (double)frames * (double)keys_per_frame * (double)DV;
+  if (chunks) launch_all<1>(p, g, c, true, flops, s);
+  else launch_all<0>(p, g, c, false, flops, s);
+  return rmem_check_launch("rmem_gated_attn");
+}
+
+extern "C" int rmem_local_gated_attn(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const float* rel,
+                                     int ldrel, int H, int W, int DV, const void* u_a, int ldua, const void* u_b, int ldub,
+                                     int usplit, void* out, int ldo, void* workspace, void* stream) {
+  const int L = H * W;
+  if (check_common(q, ldq, k, ldk, v, ldv, L, DV, u_a, ldua, u_b, ldub, usplit, out, ldo, workspace, "rmem_local_gated_attn")) return -1;
+  RMEM_REQUIRE(rel && H > 0 && W > 0 && W < 32768 && ldrel >= WIN * WIN, "rmem_local_gated_attn: bad rel / H / W");
+  GpParams p = {};
+  p.q = (const bf16*)q; p.ldq = ldq; p.k = (const bf16*)k; p.ldk = ldk; p.v = (const bf16*)v; p.ldv = ldv;
+  p.lk = L;
+  const int want = 8;
+  p.per = ((L + want - 1) / want + KT - 1) / KT * KT;
+  p.nrows = (L + p.per - 1) / p.per;
+  const GpPlan g = plan(L, DV, 1, L, p.nrows);
+  p.Lq = L; p.Lqp = g.Lqp; p.Lp = g.Lp; p.ldp = g.ldp;
+  char* ws = (char*)workspace;
+  p.mpart = (float*)ws; p.lpart = (float*)(ws + g.off_l); p.P = (bf16*)(ws + g.off_p); p.slabs = (float*)(ws + g.off_s);
+  p.qscale = LOG2E / sqrtf((float)DQ);
+  p.H = H; p.W = W; p.rel = rel; p.ldrel = ldrel;
+  p.DV = DV; p.nq = g.Lqp / QT; p.ncs = DV / CW; p.groups = g.groups; p.rows_per_group = g.rpg;
+  GpCombine c = {};
+  c.slabs = p.slabs; c.groups = g.groups; c.lpart = p.lpart; c.nrows = p.nrows; c.Lq = L; c.Lqp = g.Lqp; c.DV = DV;
+  c.ua = (const bf16*)u_a; c.ldua = ldua; c.ub = (const bf16*)u_b; c.ldub = ldub; c.usplit = usplit;
+  c.out = (bf16*)out; c.ldo = ldo;
+  launch_all<2>(p, g, c, false, 0.0, (hipStream_t)stream);
+  return rmem_check_launch("rmem_local_gated_attn");
+}

@@ -43,6 +43,8 @@ struct ConvParams {
   int M, K;
   int ldo, ldr, ld2;
   int relu, out_f32, res_f32;
+  int ldx;               // input row stride of the 1x1 (GEMM) case
+  int act_begin;         // first output channel the activation applies to (multiple of 8)
   int steps_per_split;   // k-steps (of 32) per gridDim.z slice
   int vec_ok;            // all leading dimensions / pointers allow 8-wide vector access
 };
@@ -77,12 +79,17 @@ __device__ __forceinline__ void finish8(const ConvParams& p, int m, int n, float
       for (int j = 0; j < 8; ++j) v[j] += (float)r[j];
     }
   }
-  if (p.relu == 1) {
+  if (n >= p.act_begin) {
+    if (p.relu == 1) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
-  } else if (p.relu == 2) {                 // exact (erf) GELU: Swin MLP, encoders/swin/swin_transformer.py:55-57
+      for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+    } else if (p.relu == 2) {               // exact (erf) GELU: Swin MLP, encoders/swin/swin_transformer.py:55-57
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = 0.5f * v[j] * (1.f + erff(v[j] * 0.70710678118654752f));
+      for (int j = 0; j < 8; ++j) v[j] = 0.5f * v[j] * (1.f + erff(v[j] * 0.70710678118654752f));
+    } else if (p.relu == 3) {               // SiLU: layers/attention.py:89-90
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = v[j] / (1.f + expf(-v[j]));
+    }
   }
   if (p.out_f32) {
     float* y = reinterpret_cast<float*>(p.y) + (long)m * p.ldo + n;
@@ -103,8 +110,11 @@ __device__ __forceinline__ void finish1(const ConvParams& p, int m, int n, float
   if (p.res)
     v += p.res_f32 ? reinterpret_cast<const float*>(p.res)[(long)m * p.ldr + n]
                    : (float)reinterpret_cast<const bf16*>(p.res)[(long)m * p.ldr + n];
-  if (p.relu == 1) v = fmaxf(v, 0.f);
-  else if (p.relu == 2) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
+  if (n >= p.act_begin) {
+    if (p.relu == 1) v = fmaxf(v, 0.f);
+    else if (p.relu == 2) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
+    else if (p.relu == 3) v = v / (1.f + expf(-v));
+  }
   if (p.out_f32) reinterpret_cast<float*>(p.y)[(long)m * p.ldo + n] = v;
   else reinterpret_cast<bf16*>(p.y)[(long)m * p.ldo + n] = (bf16)v;
 }
@@ -145,7 +155,7 @@ __global__ __launch_bounds__(256) void k_conv_gemm(ConvParams p) {
     const int m = m0 + (tid >> 3) + i * 32;
     a_ok[i] = m < p.M;
     if (IS1X1) {
-      a_base[i] = (long)m * p.Cin;
+      a_base[i] = (long)m * p.ldx;
       a_hi0[i] = a_wi0[i] = 0;
     } else {
       const int ho = m / p.Wo, wo = m - ho * p.Wo;
@@ -322,7 +332,7 @@ __global__ __launch_bounds__(256) void k_conv_gemm_dma(ConvParams p) {
     const int m = m0 + r;
     a_ok[i] = m < p.M;
     if (IS1X1) {
-      a_base[i] = (long)m * p.Cin;
+      a_base[i] = (long)m * p.ldx;
       a_hi0[i] = a_wi0[i] = a_ci[i] = a_kw[i] = a_kh[i] = 0;
     } else {
       const int ho = m / p.Wo, wo = m - ho * p.Wo;
@@ -535,11 +545,17 @@ extern "C" int rmem_conv2d_nhwc(const rmem_conv_desc* d, const void* x, const vo
   p.M = Ho * Wo; p.K = d->KH * d->KW * d->Cin;
   p.ldo = d->ldo; p.ldr = d->ldr; p.ld2 = d->ld2;
   p.relu = d->relu; p.out_f32 = d->out_f32; p.res_f32 = d->res_f32;
+  const bool is1x1 = d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0;
+  RMEM_REQUIRE(d->relu >= 0 && d->relu <= 3, "rmem_conv2d_nhwc: relu must be 0 (none), 1 (ReLU), 2 (GELU) or 3 (SiLU)");
+  RMEM_REQUIRE(d->act_begin >= 0 && d->act_begin % 8 == 0, "rmem_conv2d_nhwc: act_begin must be a non-negative multiple of 8");
+  RMEM_REQUIRE(d->ldx == 0 || (is1x1 && d->ldx >= d->Cin && d->ldx % 8 == 0),
+               "rmem_conv2d_nhwc: ldx needs a 1x1 stride-1 problem, ldx >= Cin, ldx % 8 == 0");
+  p.ldx = d->ldx ? d->ldx : d->Cin;
+  p.act_begin = d->act_begin;
   p.steps_per_split = (p.K + 63) / 64;
   auto al = [](const void* q, int a) { return q == nullptr || ((uintptr_t)q % a) == 0; };
   p.vec_ok = p.Cout % 8 == 0 && p.ldo % 8 == 0 && al(y, 16) && al(bias, 16) &&
              (!residual || (p.ldr % 8 == 0 && al(residual, 16))) && (!y2 || (p.ld2 % 8 == 0 && al(y2, 16)));
-  const bool is1x1 = d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0;
   hipStream_t s = (hipStream_t)stream;
   const long t128 = (long)((p.M + 127) / 128) * ((p.Cout + 127) / 128);
   static const int force_tile = getenv("RMEM_GEMM_TILE") ? atoi(getenv("RMEM_GEMM_TILE")) : -1;   // kernel experiments only

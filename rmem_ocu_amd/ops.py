@@ -54,9 +54,9 @@ def _dev(*ts):
 
 
 def conv2d(x, w, bias, y, *, H, W, Cin, Cout, KH=1, KW=1, stride=1, pad=0, residual=None, y2=None, relu=False,
-           ldo=None, ldr=None, ld2=None, ws=None) -> Op:
+           ldo=None, ldr=None, ld2=None, ws=None, ldx=0, act_begin=0) -> Op:
     """y = act(conv(x, w) + bias (+ residual)); w is [Cout, KH, KW, Cin] bf16, x NHWC bf16.
-    relu: False/0 none, True/1 ReLU, 2 exact GELU."""
+    relu: False/0 none, True/1 ReLU, 2 exact GELU, 3 SiLU (channels >= act_begin); ldx: input row stride of a 1x1 problem."""
     _dev(x, w, bias, y, residual, y2)
     assert x.dtype == BF16 and w.dtype == BF16 and w.is_contiguous()
     assert w.numel() == Cout * KH * KW * Cin, (w.shape, Cout, KH, KW, Cin)
@@ -67,9 +67,9 @@ def conv2d(x, w, bias, y, *, H, W, Cin, Cout, KH=1, KW=1, stride=1, pad=0, resid
     ldo = Cout if ldo is None else ldo
     ldr = Cout if ldr is None else ldr
     ld2 = Cout if ld2 is None else ld2
-    assert x.numel() >= H * W * Cin and y.numel() >= (Ho * Wo - 1) * ldo + Cout
+    assert x.numel() >= (H * W - 1) * (ldx or Cin) + Cin and y.numel() >= (Ho * Wo - 1) * ldo + Cout
     d = ConvDesc(H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, ldo, ldr, ld2, int(relu), int(y.dtype == F32),
-                 int(residual is not None and residual.dtype == F32))
+                 int(residual is not None and residual.dtype == F32), ldx, act_begin)
     if ws is not None:   # split-K workspace: use it only if it is big enough for this problem
         _dev(ws)
         if ws.numel() * ws.element_size() < _lib.lib().rmem_conv_workspace_bytes(C.byref(d)):
@@ -78,9 +78,11 @@ def conv2d(x, w, bias, y, *, H, W, Cin, Cout, KH=1, KW=1, stride=1, pad=0, resid
     return Op(_lib.lib().rmem_conv2d_nhwc, args, 'rmem_conv2d_nhwc', (d, x, w, bias, residual, y, y2, ws))
 
 
-def linear(x, w, bias, y, *, M, K, N, residual=None, y2=None, relu=False, ldo=None, ldr=None, ld2=None, ws=None) -> Op:
-    """y[M, N] = x[M, K] @ w[N, K]^T + bias: the 1x1 case of conv2d (x rows contiguous with stride K)."""
-    return conv2d(x, w, bias, y, H=M, W=1, Cin=K, Cout=N, residual=residual, y2=y2, relu=relu, ldo=ldo, ldr=ldr, ld2=ld2, ws=ws)
+def linear(x, w, bias, y, *, M, K, N, residual=None, y2=None, relu=False, ldo=None, ldr=None, ld2=None, ws=None, ldx=0,
+           act_begin=0) -> Op:
+    """y[M, N] = x[M, K] @ w[N, K]^T + bias: the 1x1 case of conv2d (x rows of stride ldx, default K)."""
+    return conv2d(x, w, bias, y, H=M, W=1, Cin=K, Cout=N, residual=residual, y2=y2, relu=relu, ldo=ldo, ldr=ldr, ld2=ld2, ws=ws,
+                  ldx=ldx, act_begin=act_begin)
 
 
 def attn_workspace(Lq: int, heads: int, nchunks: int, device) -> torch.Tensor:
@@ -217,6 +219,50 @@ def copy_async(dst, src, nbytes: int) -> Op:
     assert dst.is_contiguous() and src.is_contiguous()
     assert nbytes <= dst.numel() * dst.element_size() and nbytes <= src.numel() * src.element_size()
     return Op(_lib.lib().rmem_copy_async, (_ptr(dst), _ptr(src), nbytes), 'rmem_copy_async', (dst, src))
+
+
+def copy2d_async(dst, dst_pitch: int, src, src_pitch: int, row_bytes: int, rows: int) -> Op:
+    """rows x row_bytes device copy between pitched buffers (pitches in bytes)."""
+    _dev(dst, src)
+    assert (rows - 1) * dst_pitch + row_bytes <= dst.numel() * dst.element_size()
+    assert (rows - 1) * src_pitch + row_bytes <= src.numel() * src.element_size()
+    return Op(_lib.lib().rmem_copy2d_async, (_ptr(dst), dst_pitch, _ptr(src), src_pitch, row_bytes, rows), 'rmem_copy2d_async', (dst, src))
+
+
+def gated_workspace(Lq: int, DV: int, frames: int, keys_per_frame: int, nchunks: int, device) -> torch.Tensor:
+    n = _lib.lib().rmem_gated_attn_workspace_bytes(Lq, DV, frames, keys_per_frame, nchunks)
+    if n == 0:
+        raise RmemError('rmem_gated_attn_workspace_bytes: bad geometry')
+    return torch.empty(n // 4 + 64, dtype=F32, device=device)
+
+
+def gated_attn(q, k_bank, v_bank, u_a, out, workspace, *, Lq, DV, ldq, ldk, ldv, ldua, ldo, k_slot_stride=0, v_slot_stride=0,
+               chunks=None, nchunks=1, frames=1, keys_per_frame, pe_cur=None, pe_mem=None, u_b=None, ldub=0, usplit=None,
+               mass=None) -> Op:
+    """DeAOT gated propagation attention (single head, d_att 128); see include/rmem.h."""
+    _dev(q, k_bank, v_bank, u_a, u_b, out, workspace, chunks, pe_cur, pe_mem, mass)
+    assert all(t.dtype == BF16 for t in (q, k_bank, v_bank, u_a, out)) and (u_b is None or u_b.dtype == BF16)
+    assert workspace.numel() * 4 >= _lib.lib().rmem_gated_attn_workspace_bytes(Lq, DV, frames, keys_per_frame, nchunks)
+    assert chunks is None or (chunks.dtype == torch.int32 and chunks.numel() >= nchunks * 8)
+    assert mass is None or (mass.dtype == F32 and mass.numel() >= Lq * frames)
+    usplit = DV if usplit is None else usplit
+    args = (_ptr(q), ldq, _ptr(k_bank), k_slot_stride, ldk, _ptr(v_bank), v_slot_stride, ldv, _ptr(chunks), nchunks, frames,
+            keys_per_frame, _ptr(pe_cur), _ptr(pe_mem), Lq, DV, _ptr(u_a), ldua, _ptr(u_b), ldub, usplit, _ptr(out), ldo,
+            _ptr(mass), _ptr(workspace))
+    return Op(_lib.lib().rmem_gated_attn, args, 'rmem_gated_attn',
+              (q, k_bank, v_bank, u_a, u_b, out, workspace, chunks, pe_cur, pe_mem, mass))
+
+
+def local_gated_attn(q, k, v, rel, u_a, out, workspace, *, H, W, DV, ldq, ldk, ldv, ldrel, ldua, ldo, u_b=None, ldub=0,
+                     usplit=None) -> Op:
+    """DeAOT 15x15 local gated propagation attention; rel = relative_emb_k(q) fp32 [H*W][ldrel]."""
+    _dev(q, k, v, rel, u_a, u_b, out, workspace)
+    assert all(t.dtype == BF16 for t in (q, k, v, u_a, out)) and rel.dtype == F32
+    assert workspace.numel() * 4 >= _lib.lib().rmem_gated_attn_workspace_bytes(H * W, DV, 1, H * W, 8)
+    usplit = DV if usplit is None else usplit
+    args = (_ptr(q), ldq, _ptr(k), ldk, _ptr(v), ldv, _ptr(rel), ldrel, H, W, DV, _ptr(u_a), ldua, _ptr(u_b), ldub, usplit,
+            _ptr(out), ldo, _ptr(workspace))
+    return Op(_lib.lib().rmem_local_gated_attn, args, 'rmem_local_gated_attn', (q, k, v, rel, u_a, u_b, out, workspace))
 
 
 class Graph:

@@ -72,6 +72,43 @@ def _pack_swin(sd, put):
         put(f'sw.norm{li}.g', sd[f'encoder.norm{li}.weight'].float()); put(f'sw.norm{li}.b', sd[f'encoder.norm{li}.bias'].float())
 
 
+def pack_deaot_self(sd, p: str):
+    """GatedPropagation with use_linear (layers/attention.py:151-173) as ONE GEMM over x = [tgt | tgt_id] (512):
+    rows [linear_QK (128) | V = [V1 (x[:256]) | V2 (x[256:])] (1024) | U likewise (1024)]; the two halves of V and U read
+    disjoint input halves, so their weight is block diagonal.  Returns (bf16 [2176, 512], fp32 [2176])."""
+    f = lambda k: sd[p + k].float()   # noqa: E731
+    z = torch.zeros(512, 256)
+    blk = lambda a, b: torch.cat([torch.cat([f(a + '.weight'), z], 1), torch.cat([z, f(b + '.weight')], 1)], 0)   # noqa: E731
+    W = torch.cat([f('.linear_QK.weight'), blk('.linear_V1', '.linear_V2'), blk('.linear_U1', '.linear_U2')], 0)
+    b = torch.cat([f('.linear_QK.bias'), f('.linear_V1.bias'), f('.linear_V2.bias'), f('.linear_U1.bias'), f('.linear_U2.bias')], 0)
+    return W.to(torch.bfloat16), b
+
+
+def _pack_deaot_gpm(sd, put, lin, norm, num_lstt):
+    """DualBranchGPM (layers/transformer.py:700-763, 1011-1082): per layer the fused [Q | V | U] GEMM (linear_QV + linear_U),
+    the ID branch linears, the relative embedding, three depth-wise kernels + projections, the fused self-attention GEMM."""
+    for i in range(num_lstt):
+        s, d = f'LSTT.layers.{i}', f'g{i}'
+        norm(d + '.ln1', s + '.norm1')
+        put(d + '.qvu.w', torch.cat([sd[s + '.linear_QV.weight'], sd[s + '.linear_U.weight']], 0).float().to(torch.bfloat16))
+        put(d + '.qvu.b', torch.cat([sd[s + '.linear_QV.bias'], sd[s + '.linear_U.bias']], 0).float())
+        lin(d + '.idv', s + '.linear_ID_V')
+        if i > 0:
+            norm(d + '.idn1', s + '.id_norm1')
+            lin(d + '.idu', s + '.linear_ID_U')
+        put(d + '.rel.w', sd[s + '.short_term_attn.relative_emb_k.weight'].float().reshape(225, 128).to(torch.bfloat16))
+        put(d + '.rel.b', sd[s + '.short_term_attn.relative_emb_k.bias'].float())
+        for nm, src in (('long', 'long_term_attn'), ('short', 'short_term_attn'), ('self', 'self_attn')):
+            put(f'{d}.{nm}_dw.w', sd[f'{s}.{src}.dw_conv.conv.weight'].float().view(-1, 25).t())
+            lin(f'{d}.{nm}_proj', f'{s}.{src}.projection')
+        norm(d + '.ln2', s + '.norm2')
+        norm(d + '.idn2', s + '.id_norm2')
+        W, b = pack_deaot_self(sd, s + '.self_attn')
+        put(d + '.self.w', W); put(d + '.self.b', b)
+    norm('dec_gn', 'LSTT.decoder_norms.0.gn')
+    norm('idnorm', 'id_norm')
+
+
 def pack_state_dict(sd: Dict[str, torch.Tensor], device, num_lstt: int = 3) -> Dict[str, torch.Tensor]:
     P: Dict[str, torch.Tensor] = {}
 
@@ -101,7 +138,10 @@ def pack_state_dict(sd: Dict[str, torch.Tensor], device, num_lstt: int = 3) -> D
     def norm(dst, src):
         put(dst + '.g', sd[src + '.weight'].float()); put(dst + '.b', sd[src + '.bias'].float())
 
-    for i in range(num_lstt):
+    deaot = 'LSTT.layers.0.linear_QV.weight' in sd
+    if deaot:
+        _pack_deaot_gpm(sd, put, lin, norm, num_lstt)
+    for i in range(0 if deaot else num_lstt):
         s, d = f'LSTT.layers.{i}', f'l{i}'
         norm(d + '.ln1', s + '.norm1')
         put(d + '.self_qk.w', torch.cat([sd[s + '.self_attn.linear_Q.weight'], sd[s + '.self_attn.linear_K.weight']], 0).float().to(torch.bfloat16))
