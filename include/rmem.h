@@ -142,6 +142,11 @@ size_t rmem_groupnorm_workspace_bytes(int groups);
 int rmem_groupnorm_nhwc(const void* x, int M, int C, int groups, const float* gamma, const float* beta,
                         float eps, int act, void* y, float* workspace, void* stream);
 
+/* Same with an fp32 input: the final GroupNorm1D(512, 2 groups) over the concatenated residual streams of the DeAOT
+ * stack (layers/transformer.py:755-758, 806-808; layers/basic.py:6-12). */
+int rmem_groupnorm_f32_nhwc(const float* x, int M, int C, int groups, const float* gamma, const float* beta,
+                            float eps, int act, void* y, float* workspace, void* stream);
+
 /* Depth-wise 5x5, pad 2, NHWC bf16; w_t is [25][C] fp32.  Replaces layers/basic.py:19-25, 33. */
 int rmem_dwconv5x5_nhwc(const void* x, const float* w_t, void* y, int H, int W, int C, void* stream);
 

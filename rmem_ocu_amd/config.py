@@ -1,7 +1,7 @@
 """Configuration object with the reference's UPPER_CASE attribute names.
 
 Only the attributes the inference path reads are kept:
-configs/models/default.py:3-26 overlaid by configs/models/r50_aotl.py:7-39 and the
+configs/models/default.py:3-26 overlaid by configs/models/r50_aotl.py:7-39 (or r50_deaotl.py / swinb_aotl.py) and the
 ``pre_vost`` stage (configs/pre_vost.py:14-18), plus the overrides tools/eval.py:108-135
 applies from the command line.
 """
@@ -11,8 +11,8 @@ from __future__ import annotations
 class EngineConfig:
     def __init__(self, exp_name: str = 'default', model: str = 'r50_aotl'):
         model = model.lower()
-        if model not in ('r50_aotl', 'swinb_aotl'):
-            raise NotImplementedError(f'model config {model!r}: built configs are r50_aotl and swinb_aotl')
+        if model not in ('r50_aotl', 'swinb_aotl', 'r50_deaotl'):
+            raise NotImplementedError(f'model config {model!r}: built configs are r50_aotl, swinb_aotl and r50_deaotl')
         self.EXP_NAME = exp_name
         self.MODEL_NAME = 'R50_AOTL_Temp_pe_Slot_4'
         self.MODEL_VOS = 'aot'
@@ -52,6 +52,15 @@ class EngineConfig:
             self.MODEL_ENCODER = 'swin_base'
             self.MODEL_ALIGN_CORNERS = False
             self.MODEL_ENCODER_DIM = [128, 256, 512, 512]
+        if model == 'r50_deaotl':
+            # configs/models/default_deaot.py:7-18 + configs/models/r50_deaotl.py:8-40
+            self.MODEL_NAME = 'R50_DeAOTL_Temp_pe_Slot_4'
+            self.MODEL_VOS = 'deaot'
+            self.MODEL_ENGINE = 'deaotengine'
+            self.MODEL_DECODER_INTERMEDIATE_LSTT = False
+            self.MODEL_SELF_HEADS = 1
+            self.MODEL_ATT_HEADS = 1
+            self.LATTER_MEM_LEN = 8
 
 
 def get_config(stage: str = 'pre_vost', exp_name: str = 'default', model: str = 'r50_aotl') -> EngineConfig:

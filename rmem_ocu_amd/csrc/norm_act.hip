@@ -132,8 +132,20 @@ __global__ __launch_bounds__(256) void k_add_bf16(const bf16* a, const bf16* b, 
 // ------------------------------------------------------------------ GroupNorm (NHWC)
 constexpr int GN_SPLITS = 32;
 
+__device__ __forceinline__ void gn_load8(const bf16* p, float (&f)[8]) {
+  const bf16x8 d = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) f[j] = (float)d[j];
+}
+__device__ __forceinline__ void gn_load8(const float* p, float (&f)[8]) {
+  const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { f[j] = a[j]; f[4 + j] = b[j]; }
+}
+
 // partial (sum, sumsq) per (group, split); deterministic two-stage reduction
-__global__ __launch_bounds__(256) void k_gn_stats(const bf16* x, int M, int C, int cpg, float* ws) {
+template <typename TI>
+__global__ __launch_bounds__(256) void k_gn_stats(const TI* x, int M, int C, int cpg, float* ws) {
   const int g = blockIdx.x, sp = blockIdx.y;
   const int vec = cpg / 8;                       // 16-byte pieces per pixel in this group
   const int rows_per = (M + GN_SPLITS - 1) / GN_SPLITS;
@@ -142,12 +154,10 @@ __global__ __launch_bounds__(256) void k_gn_stats(const bf16* x, int M, int C, i
   const long total = (long)(r1 - r0) * vec;
   for (long i = threadIdx.x; i < total; i += 256) {
     const int r = r0 + (int)(i / vec), v = (int)(i % vec);
-    const bf16x8 d = *reinterpret_cast<const bf16x8*>(x + (long)r * C + g * cpg + v * 8);
+    float d[8];
+    gn_load8(x + (long)r * C + g * cpg + v * 8, d);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float f = (float)d[j];
-      s += f; ss += f * f;
-    }
+    for (int j = 0; j < 8; ++j) { s += d[j]; ss += d[j] * d[j]; }
   }
   s = wave_sum(s); ss = wave_sum(ss);
   __shared__ float red[2][4];
@@ -161,7 +171,8 @@ __global__ __launch_bounds__(256) void k_gn_stats(const bf16* x, int M, int C, i
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
 
-__global__ __launch_bounds__(256) void k_gn_apply(const bf16* x, int M, int C, int cpg, int groups, const float* ws,
+template <typename TI>
+__global__ __launch_bounds__(256) void k_gn_apply(const TI* x, int M, int C, int cpg, int groups, const float* ws,
                                                   const float* gamma, const float* beta, float eps, int act, bf16* y) {
   __shared__ float s_mean[64], s_rstd[64];
   if (threadIdx.x < groups) {
@@ -182,12 +193,13 @@ __global__ __launch_bounds__(256) void k_gn_apply(const bf16* x, int M, int C, i
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
     const int c0 = (int)(i % vpr) * 8;
     const int g = c0 / cpg;
-    const bf16x8 d = reinterpret_cast<const bf16x8*>(x)[i];
+    float d[8];
+    gn_load8(x + i * 8, d);
     const float mean = s_mean[g], rstd = s_rstd[g];
     bf16x8 o;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      float f = ((float)d[j] - mean) * rstd * gamma[c0 + j] + beta[c0 + j];
+      float f = (d[j] - mean) * rstd * gamma[c0 + j] + beta[c0 + j];
       if (act == 1) f = fmaxf(f, 0.f);
       else if (act == 2) f = gelu_erf(f);
       o[j] = (bf16)f;
@@ -287,11 +299,26 @@ extern "C" int rmem_groupnorm_nhwc(const void* x, int M, int C, int groups, cons
   RMEM_REQUIRE(act >= 0 && act <= 2 && M > 0, "rmem_groupnorm_nhwc: bad act / M");
   const int cpg = C / groups;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_gn_stats, dim3(groups, GN_SPLITS), dim3(256), 0, s, (const bf16*)x, M, C, cpg, workspace);
+  hipLaunchKernelGGL(k_gn_stats<bf16>, dim3(groups, GN_SPLITS), dim3(256), 0, s, (const bf16*)x, M, C, cpg, workspace);
   const long total = (long)M * (C / 8);
   const int blocks = (int)min((long)2048, (total + 255) / 256);
-  hipLaunchKernelGGL(k_gn_apply, dim3(blocks), dim3(256), 0, s, (const bf16*)x, M, C, cpg, groups, workspace, gamma, beta, eps, act, (bf16*)y);
+  hipLaunchKernelGGL(k_gn_apply<bf16>, dim3(blocks), dim3(256), 0, s, (const bf16*)x, M, C, cpg, groups, workspace, gamma, beta, eps, act, (bf16*)y);
   return rmem_check_launch("rmem_groupnorm_nhwc");
+}
+
+extern "C" int rmem_groupnorm_f32_nhwc(const float* x, int M, int C, int groups, const float* gamma, const float* beta, float eps,
+                                       int act, void* y, float* workspace, void* stream) {
+  RMEM_REQUIRE(x && y && gamma && beta && workspace, "rmem_groupnorm_f32_nhwc: null argument");
+  RMEM_REQUIRE(groups >= 1 && groups <= 64 && C % groups == 0 && (C / groups) % 8 == 0,
+               "rmem_groupnorm_f32_nhwc: groups must divide C into multiples of 8 channels (<= 64 groups)");
+  RMEM_REQUIRE(act >= 0 && act <= 2 && M > 0, "rmem_groupnorm_f32_nhwc: bad act / M");
+  const int cpg = C / groups;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_gn_stats<float>, dim3(groups, GN_SPLITS), dim3(256), 0, s, x, M, C, cpg, workspace);
+  const long total = (long)M * (C / 8);
+  const int blocks = (int)min((long)2048, (total + 255) / 256);
+  hipLaunchKernelGGL(k_gn_apply<float>, dim3(blocks), dim3(256), 0, s, x, M, C, cpg, groups, workspace, gamma, beta, eps, act, (bf16*)y);
+  return rmem_check_launch("rmem_groupnorm_f32_nhwc");
 }
 
 extern "C" int rmem_dwconv5x5_nhwc(const void* x, const float* w_t, void* y, int H, int W, int C, void* stream) {

@@ -58,6 +58,8 @@ class MemoryPolicy:
 
 
 class AOTEngine:
+    policy_every_update = False      # DeAOT: scores / visit counts move on every long-term update (deaot_engine.py)
+
     def __init__(self, aot_model, gpu_id=0, long_term_mem_gap=9999, short_term_mem_skip=1):
         self.cfg = aot_model.cfg
         self.align_corners = aot_model.cfg.MODEL_ALIGN_CORNERS
@@ -131,8 +133,12 @@ class AOTEngine:
         n = self.cfg.FORMER_MEM_LEN + self.cfg.LATTER_MEM_LEN
         slots = n + 1 if n < 64 else 16            # +1: the bank holds N+1 entries between append and eviction
         if self.rt is None or (self.rt.H, self.rt.W) != (H, W):
-            self.rt = ClipRuntime(self.AOT.packed(), (H, W), slots, self.device, self.cfg.MODEL_LSTT_NUM,
-                                  self.align_corners, self.max_obj_num + 1)
+            P = self.AOT.packed()
+            if 'g0.qvu.w' in P:
+                from ...runtime_deaot import DeAOTRuntime as Runtime
+            else:
+                Runtime = ClipRuntime
+            self.rt = Runtime(P, (H, W), slots, self.device, self.cfg.MODEL_LSTT_NUM, self.align_corners, self.max_obj_num + 1)
             self.img_in = torch.empty(3, H, W, dtype=F32, device=self.device)
             self.label_in = torch.empty(H, W, dtype=F32, device=self.device)
             self._graphs = {}
@@ -297,7 +303,8 @@ class AOTEngine:
         rt.slots.append(slot)
         self._indexes.append(self.frame_step)
         n_keep = self.cfg.FORMER_MEM_LEN + self.cfg.LATTER_MEM_LEN
-        if len(rt.slots) > n_keep:
+        overflow = len(rt.slots) > n_keep
+        if overflow or self.policy_every_update:
             Tp = self._T_at_propagate
             keep = self.obj_nums[0] if self.obj_nums else self.max_obj_num
             ops.run([ops.evict_scores(rt.logits, rt.mass, rt.scores, ldl=16, nc=rt.nc, keep=keep, Hi=rt.H4, Wi=rt.W4,
@@ -305,8 +312,8 @@ class AOTEngine:
                      ops.copy_async(rt.scores_host, rt.scores, 4 * Tp)], s)
             ev = torch.cuda.Event()
             ev.record(self.stream)
-            self._pending_evict = (Tp, ev)
-        else:
+            self._pending_evict = (Tp, ev, overflow)
+        if not overflow:
             rt.upload_chunks(s)
 
     def _resolve_pending(self):
@@ -314,11 +321,13 @@ class AOTEngine:
         (layers/transformer.py:353-411), drop the entry from the slot table and upload the new chunk table."""
         if self._pending_evict is None:
             return
-        Tp, ev = self._pending_evict
+        Tp, ev, overflow = self._pending_evict
         self._pending_evict = None
         ev.synchronize()                      # the one host wait of the policy (the reference syncs here too, transformer.py:353)
         rt = self.rt
         drop = self.policy.choose(rt.scores_host[:Tp].clone(), self._indexes)
+        if not overflow:                      # DeAOT: the scores moved, nothing is dropped yet
+            return
         self.drop_trace.append(drop)
         rt.free.append(rt.slots.pop(drop))
         del self._indexes[drop]
@@ -326,6 +335,8 @@ class AOTEngine:
 
 
 class AOTInferEngine:
+    ENGINE = AOTEngine
+
     def __init__(self, aot_model, gpu_id=0, long_term_mem_gap=9999, short_term_mem_skip=1, max_aot_obj_num=None):
         self.cfg = aot_model.cfg
         self.AOT = aot_model
@@ -389,7 +400,7 @@ class AOTInferEngine:
                 eng = self._pool.pop(0)           # reuse device buffers of an earlier clip
                 eng.long_term_mem_gap = self.long_term_mem_gap
             else:
-                eng = AOTEngine(self.AOT, self.gpu_id, self.long_term_mem_gap, self.short_term_mem_skip)
+                eng = self.ENGINE(self.AOT, self.gpu_id, self.long_term_mem_gap, self.short_term_mem_skip)
             eng.use_graphs = self.use_graphs
             eng.sync_caller = not getattr(self, '_async', False)
             self.aot_engines.append(eng)

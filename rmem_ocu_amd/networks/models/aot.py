@@ -48,11 +48,13 @@ def _attach(root: nn.Module, key: str, value: torch.Tensor):
 
 
 class AOT(nn.Module):
+    KIND = 'aot'
+
     def __init__(self, cfg, encoder='resnet50', decoder='fpn'):
         super().__init__()
         if encoder not in ('resnet50', 'swin_base') or decoder != 'fpn':
             raise NotImplementedError('built encoders: resnet50 (R50-AOTL) and swin_base (SwinB-AOTL); decoder: fpn')
-        if cfg.MODEL_LINEAR_Q:
+        if self.KIND == 'aot' and cfg.MODEL_LINEAR_Q:
             raise NotImplementedError('MODEL_LINEAR_Q=True: the reference eval path itself crashes there '
                                       '(layers/transformer.py:650-665); use the pre_vost setting False')
         self.cfg = cfg
@@ -60,7 +62,8 @@ class AOT(nn.Module):
         self.epsilon = cfg.MODEL_EPSILON
         self.use_temporal_pe = cfg.USE_TEMPORAL_POSITIONAL_EMBEDDING
         # same construction-time randomness contract as the reference: fresh weights unless loaded
-        for k, v in synth_state_dict(0, cfg.MODEL_LSTT_NUM, cfg.MODEL_ENCODER_EMBEDDING_DIM, cfg.MODEL_MAX_OBJ_NUM, encoder).items():
+        for k, v in synth_state_dict(0, cfg.MODEL_LSTT_NUM, cfg.MODEL_ENCODER_EMBEDDING_DIM, cfg.MODEL_MAX_OBJ_NUM, encoder,
+                                     model=self.KIND).items():
             _attach(self, k, v)
         self._packed: Optional[Dict[str, torch.Tensor]] = None
         self._packed_device = None

@@ -157,8 +157,10 @@ def groupnorm_workspace(groups: int, device) -> torch.Tensor:
 
 def groupnorm(x, gamma, beta, y, ws, *, M, C, groups, act=0, eps=1e-5) -> Op:
     _dev(x, gamma, beta, y, ws)
-    assert x.dtype == BF16 and y.dtype == BF16 and gamma.dtype == F32 and gamma.numel() == C
+    assert x.dtype in (BF16, F32) and y.dtype == BF16 and gamma.dtype == F32 and gamma.numel() == C
     args = (_ptr(x), M, C, groups, _ptr(gamma), _ptr(beta), eps, act, _ptr(y), _ptr(ws))
+    if x.dtype == F32:
+        return Op(_lib.lib().rmem_groupnorm_f32_nhwc, args, 'rmem_groupnorm_f32_nhwc', (x, gamma, beta, y, ws))
     return Op(_lib.lib().rmem_groupnorm_nhwc, args, 'rmem_groupnorm_nhwc', (x, gamma, beta, y, ws))
 
 

@@ -77,7 +77,7 @@ def pack_deaot_self(sd, p: str):
     rows [linear_QK (128) | V = [V1 (x[:256]) | V2 (x[256:])] (1024) | U likewise (1024)]; the two halves of V and U read
     disjoint input halves, so their weight is block diagonal.  Returns (bf16 [2176, 512], fp32 [2176])."""
     f = lambda k: sd[p + k].float()   # noqa: E731
-    z = torch.zeros(512, 256)
+    z = torch.zeros(512, 256, device=sd[p + '.linear_QK.weight'].device)
     blk = lambda a, b: torch.cat([torch.cat([f(a + '.weight'), z], 1), torch.cat([z, f(b + '.weight')], 1)], 0)   # noqa: E731
     W = torch.cat([f('.linear_QK.weight'), blk('.linear_V1', '.linear_V2'), blk('.linear_U1', '.linear_U2')], 0)
     b = torch.cat([f('.linear_QK.bias'), f('.linear_V1.bias'), f('.linear_V2.bias'), f('.linear_U1.bias'), f('.linear_U2.bias')], 0)

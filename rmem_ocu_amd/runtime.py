@@ -67,6 +67,9 @@ def _out(n, k, s, p):
 
 
 class ClipRuntime:
+    max_chunks = MAX_CHUNKS
+    bank_kw, bank_vw = D_MODEL, D_MODEL      # row widths of the bank's K and V entries
+
     def __init__(self, P: Dict[str, torch.Tensor], in_hw: Tuple[int, int], bank_slots: int, device,
                  num_lstt: int = 3, align_corners: bool = True, num_classes: int = 11):
         self.P, self.dev, self.NL = P, device, num_lstt
@@ -113,7 +116,30 @@ class ClipRuntime:
             self.mid_a = e(M4, 128)                     # bottleneck conv1 out (<= M4*64, M4*128 for layer2.0, ...)
             self.mid_b = e(M4, 64)                      # bottleneck conv2 out
             self.ds = e(M4, 256)                        # downsample branch
-        # ---- LSTT buffers ----
+        self._alloc_lstt(L, num_lstt)
+        self.onehot = e(H * W, 16)
+        self.gn_ws = ops.groupnorm_workspace(32, device)
+        self.conv_ws = torch.empty(16 * L * D_MODEL, dtype=F32, device=device)      # split-K slabs (<= 16 slices of [HW, 256])
+        self.mass = torch.zeros(L, self.max_chunks, dtype=F32, device=device)
+        self.scores = torch.zeros(32 + 64 * 32, dtype=F32, device=device)     # T scores + reduction scratch
+        # ---- decoder buffers ----
+        self.d16a, self.d16b = e(L, 256), e(L, 256)
+        self.d8a, self.d8b = e(M8, 256), e(M8, 256)
+        self.d4a, self.d4b = e(M4, 128), e(M4, 128)
+        self.logits = torch.zeros(M4, 16, dtype=F32, device=device)
+        # ---- memory bank ----
+        self.chunks = torch.zeros(self.max_chunks, 8, dtype=torch.int32, device=device)
+        self.chunks_host = torch.zeros(8, self.max_chunks, 8, dtype=torch.int32).pin_memory()
+        self._chunk_stage = 0
+        self.scores_host = torch.zeros(MAX_CHUNKS, dtype=F32).pin_memory()
+        self.bank_generation = 0             # bumped when the bank is re-allocated: launch lists / graphs built on it are stale
+        self._alloc_bank(bank_slots)
+        self._prog: Dict[str, list] = {}
+
+    def _alloc_lstt(self, L: int, num_lstt: int):
+        """Activation buffers of the propagation stack (AOT: 3 LSTT blocks)."""
+        device = self.dev
+        e = lambda *shape, dt=BF16: torch.empty(*shape, dtype=dt, device=device)  # noqa: E731
         self.x = e(L, D_MODEL, dt=F32)              # residual stream
         self.dec_in = e(L, 4 * D_MODEL)             # cat(enc256, 3 x normed LSTT out), decoders/fpn.py:38-39
         self.t1b, self.t1p = e(L, D_MODEL), e(L, D_MODEL)
@@ -129,37 +155,24 @@ class ClipRuntime:
         self.short_K = [e(L, D_MODEL) for _ in range(num_lstt)]
         self.short_V = [e(L, D_MODEL) for _ in range(num_lstt)]
         self.id_emb = e(L, D_MODEL)
-        self.onehot = e(H * W, 16)
         self.pos = sine_pos_emb(self.H16, self.W16).to(device)
         # pos @ [Wq; Wk]^T per layer (fp32, V columns zero): the residual operand of the fused self-attention QKV GEMM
         self.pos_qk = [torch.zeros(L, 3 * D_MODEL, dtype=F32, device=device) for _ in range(num_lstt)]
         self._pos_ready = False
         self.attn_ws = ops.attn_workspace(L, HEADS, MAX_CHUNKS, device)
-        self.gn_ws = ops.groupnorm_workspace(32, device)
-        self.conv_ws = torch.empty(16 * L * D_MODEL, dtype=F32, device=device)      # split-K slabs (<= 16 slices of [HW, 256])
-        self.mass = torch.zeros(L, MAX_CHUNKS, dtype=F32, device=device)
-        self.scores = torch.zeros(32 + 64 * 32, dtype=F32, device=device)     # T scores + reduction scratch
-        # ---- decoder buffers ----
-        self.d16a, self.d16b = e(L, 256), e(L, 256)
-        self.d8a, self.d8b = e(M8, 256), e(M8, 256)
-        self.d4a, self.d4b = e(M4, 128), e(M4, 128)
-        self.logits = torch.zeros(M4, 16, dtype=F32, device=device)
-        # ---- memory bank ----
-        self.chunks = torch.zeros(MAX_CHUNKS, 8, dtype=torch.int32, device=device)
-        self.chunks_host = torch.zeros(8, MAX_CHUNKS, 8, dtype=torch.int32).pin_memory()
-        self._chunk_stage = 0
-        self.scores_host = torch.zeros(MAX_CHUNKS, dtype=F32).pin_memory()
-        self.bank_generation = 0             # bumped when the bank is re-allocated: launch lists / graphs built on it are stale
-        self._alloc_bank(bank_slots)
-        self._prog: Dict[str, list] = {}
+        self.dec_cin = 4 * D_MODEL
 
     # ------------------------------------------------------------------ bank
     def _alloc_bank(self, slots: int):
         self.S = slots
-        self.bank_K = [torch.empty(slots, self.L, D_MODEL, dtype=BF16, device=self.dev) for _ in range(self.NL)]
-        self.bank_V = [torch.empty(slots, self.L, D_MODEL, dtype=BF16, device=self.dev) for _ in range(self.NL)]
+        self.bank_K = [torch.empty(slots, self.L, self.bank_kw, dtype=BF16, device=self.dev) for _ in range(self.NL)]
+        self.bank_V = [torch.empty(slots, self.L, self.bank_vw, dtype=BF16, device=self.dev) for _ in range(self.NL)]
         self.slots: List[int] = []           # logical order t -> physical slot
         self.free: List[int] = list(range(slots))
+        self._on_bank_resized()
+
+    def _on_bank_resized(self):
+        pass
 
     def reset_bank(self):
         self.slots = []
@@ -169,13 +182,14 @@ class ClipRuntime:
         """Unbounded-memory mode (latter_mem_len = 9999, tools/eval.py:92): double the ring."""
         old_K, old_V, old_S = self.bank_K, self.bank_V, self.S
         new_S = old_S * 2
-        self.bank_K = [torch.empty(new_S, self.L, D_MODEL, dtype=BF16, device=self.dev) for _ in range(self.NL)]
-        self.bank_V = [torch.empty(new_S, self.L, D_MODEL, dtype=BF16, device=self.dev) for _ in range(self.NL)]
+        self.bank_K = [torch.empty(new_S, self.L, self.bank_kw, dtype=BF16, device=self.dev) for _ in range(self.NL)]
+        self.bank_V = [torch.empty(new_S, self.L, self.bank_vw, dtype=BF16, device=self.dev) for _ in range(self.NL)]
         for i in range(self.NL):
             self.bank_K[i][:old_S].copy_(old_K[i])
             self.bank_V[i][:old_S].copy_(old_V[i])
         self.free += list(range(old_S, new_S))
         self.S = new_S
+        self._on_bank_resized()
         self.bank_generation += 1
         self._prog = {k: v for k, v in self._prog.items() if not k.startswith(('lstt', 'update'))}
 
@@ -191,23 +205,26 @@ class ClipRuntime:
         splits = max(1, min(8 // T, MAX_CHUNKS // T))
         return splits, T * splits
 
+    def _keys_per_chunk(self, splits: int) -> int:
+        return (self.L + splits - 1) // splits
+
     def upload_chunks(self, stream: int):
         """Write the chunk table for the current slot order (call after every bank change)."""
         T = len(self.slots)
         splits, n = self.chunk_plan(T)
         pes = temporal_slots(T)
-        per = (self.L + splits - 1) // splits
+        per = self._keys_per_chunk(splits)
         rows = []
         for t, s in enumerate(self.slots):
-            for j in range(splits):
-                kb = j * per
+            for kb in range(0, self.L, per):
                 rows.append((s, kb, min(per, self.L - kb), pes[t], t))
+        assert len(rows) == n
         # a fresh pinned staging row per upload: an earlier async upload may still be reading the previous one
         self._chunk_stage = (self._chunk_stage + 1) % self.chunks_host.shape[0]
         host = self.chunks_host[self._chunk_stage]
         host.zero_()
         host[:n, :5] = torch.tensor(rows, dtype=torch.int32)
-        ops.copy_async(self.chunks, host, MAX_CHUNKS * 8 * 4)(stream)
+        ops.copy_async(self.chunks, host, self.max_chunks * 8 * 4)(stream)
 
     # ------------------------------------------------------------------ programs
     def _conv(self, *a, **kw):
@@ -249,8 +266,7 @@ class ClipRuntime:
                 h, w = (h + 1) // 2, (w + 1) // 2
                 o.append(ops.linear(mg, P[f'sw{li}.merge.w'], None, x, M=h * w, K=4 * C, N=2 * C, ws=self.conv_ws))
                 C *= 2
-        o.append(self._conv(self.enc3, P['proj.w'], P['proj.b'], self.x, H=self.L, W=1, Cin=512, Cout=D_MODEL,
-                            y2=self.dec_in, ld2=4 * D_MODEL))
+        o.append(self._proj_op(512))
         return o
 
     def prog_encode(self, img: torch.Tensor) -> list:
@@ -290,10 +306,14 @@ class ClipRuntime:
                 x, (h, w), cin = y, (ho, wo), planes * 4
             setattr(self, f'enc{li}', x)
         # encoder_projector: fp32 residual stream + bf16 copy into the decoder's concat buffer
-        o.append(self._conv(self.enc3, P['proj.w'], P['proj.b'], self.x, H=self.L, W=1, Cin=1024, Cout=D_MODEL,
-                            y2=self.dec_in, ld2=4 * D_MODEL))
+        o.append(self._proj_op(1024))
         self._prog[key] = o
         return o
+
+    def _proj_op(self, cin: int):
+        """encoder_projector (models/aot.py:25-29): fp32 residual stream + bf16 copy into the decoder's concat buffer."""
+        return self._conv(self.enc3, self.P['proj.w'], self.P['proj.b'], self.x, H=self.L, W=1, Cin=cin, Cout=D_MODEL,
+                          y2=self.dec_in, ld2=4 * D_MODEL)
 
     def _attn(self, q, ldq, k, v, ldkv, out, **kw):
         return ops.mem_read_attn(q, k, v, out, self.attn_ws, Lq=self.L, heads=HEADS, ldq=ldq, ldkv=ldkv, ldo=D_MODEL, **kw)
@@ -370,7 +390,7 @@ class ClipRuntime:
         P, o, L = self.P, [], self.L
         M8, M4 = self.H8 * self.W8, self.H4 * self.W4
         gn = lambda x, name, y, M, C: ops.groupnorm(x, P[name + '.gn.g'], P[name + '.gn.b'], y, self.gn_ws, M=M, C=C, groups=8, act=1)  # noqa: E731
-        o.append(self._conv(self.dec_in, P['dec.conv_in.w'], P['dec.conv_in.b'], self.d16a, H=L, W=1, Cin=1024, Cout=256))
+        o.append(self._conv(self.dec_in, P['dec.conv_in.w'], P['dec.conv_in.b'], self.d16a, H=L, W=1, Cin=self.dec_cin, Cout=256))
         o.append(gn(self.d16a, 'dec.conv_in', self.d16b, L, 256))
         c4, c8, c16 = self.enc_ch
         o.append(self._conv(self.enc3, P['dec.adapter_16x.w'], P['dec.adapter_16x.b'], self.d16a, H=L, W=1, Cin=c16, Cout=256,

@@ -1,0 +1,72 @@
+"""End-to-end GPU parity of the DeAOT (R50-DeAOTL) engine against the golden clips the reference produced
+(tests/golden/make_golden.py deaot) -- through the drop-in Python API, on the same seeded inputs."""
+import numpy as np
+import pytest
+import torch
+
+from test_hip_engine import _iou, _run, _trace_matrix
+
+pytestmark = pytest.mark.gpu
+
+
+def test_deaot_small_clip_teacher_forced():
+    """48 frames, bank 1 + 2, gap 2: logits within bf16 tolerance, identical eviction trace (the policy's scores and
+    visit counts move on every long-term update here, layers/transformer.py:880-968)."""
+    g, labels, samples, trace = _run('deaot_clip_small.npz', True)
+    ref = g['logit_samples']
+    err = np.abs(samples - ref).max()
+    print('deaot teacher-forced: max |dlogit| =', err, ' logit std =', ref.std(), ' label agreement =', (labels == g['labels']).mean())
+    assert err < 0.08 * ref.std() + 0.05, err
+    assert (_trace_matrix(trace, g['indexes']) == g['indexes']).all()
+    assert (labels == g['labels']).mean() > 0.97
+
+
+def test_deaot_small_clip_free_running():
+    g, labels, samples, trace = _run('deaot_clip_small.npz', False)
+    agree = (labels == g['labels']).mean(axis=(1, 2))
+    ious = [_iou(a, b) for a, b in zip(g['labels'], labels)]
+    print('deaot free-running: label agreement first/last/mean', agree[0], agree[-1], agree.mean(), ' mean IoU', np.mean(ious))
+    assert agree[0] > 0.97
+
+
+def test_deaot_graph_replay_bitwise():
+    _, l0, s0, t0 = _run('deaot_clip_small.npz', True, use_graphs=False)
+    _, l1, s1, t1 = _run('deaot_clip_small.npz', True, use_graphs=True)
+    assert t0 == t1
+    assert np.array_equal(s0, s1) and np.array_equal(l0, l1)
+
+
+def test_deaot_full_clip_cfg2_geometry():
+    """481x849 network size (31x54 tokens: window bands, several query tiles), bank 1 + 8 as shipped."""
+    g, labels, samples, trace = _run('deaot_clip_full.npz', True, use_graphs=True)
+    ref = g['logit_samples']
+    err = np.abs(samples - ref).max()
+    print('deaot full clip: max |dlogit| =', err, ' logit std =', ref.std(), ' agreement =', (labels == g['labels']).mean())
+    assert err < 0.08 * ref.std() + 0.05
+    assert (_trace_matrix(trace, g['indexes']) == g['indexes']).all()
+    assert (labels == g['labels']).mean() > 0.97
+
+
+def test_deaot_first_frames_vs_oracle():
+    """Reference frame + two propagated frames against the CPU oracle on the full logit map (not only sampled pixels)."""
+    from oracle.deaot_cpu import OracleDeAOTEngine
+    from rmem_ocu_amd.synth import make_clip
+    from rmem_ocu_amd.weights import synth_state_dict
+    from test_hip_engine import _engine
+    frames, mask = make_clip(5, 4, 161, 193, 3)
+    ora = OracleDeAOTEngine(synth_state_dict(0, model='deaot'), 1, 2, 1)
+    eng = _engine(1, 2, 1, model_name='r50_deaotl')
+    dev = torch.device('cuda', 0)
+    ora.add_reference_frame(frames[0:1], mask, 0)
+    eng.add_reference_frame(frames[0:1].to(dev), mask.to(dev), obj_nums=[3], frame_step=0)
+    for i in range(1, 4):
+        lo = ora.match_propogate_one_frame(frames[i:i + 1], (160, 192))
+        lg = eng.match_propogate_one_frame(frames[i:i + 1].to(dev), output_size=(160, 192)).cpu()
+        err = (lg - lo).abs().max().item()
+        print(f'frame {i}: max |dlogit| = {err:.4f}, std = {lo.std().item():.3f}')
+        assert err < 0.08 * lo.std().item() + 0.05
+        label = torch.argmax(lo, dim=1, keepdim=True).float()
+        m = torch.nn.functional.interpolate(label, size=(161, 193), mode='nearest')
+        ora.update_memory(m)
+        eng.update_memory(m.to(dev))
+    assert list(eng.long_memories_indexes) == list(ora.long_memories_indexes)

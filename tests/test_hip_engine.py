@@ -32,13 +32,13 @@ def _load(name):
     return g, frames, mask, (former, latter, n, h, w, oh, ow, gap, objs)
 
 
-def _engine(former, latter, gap, fitted=False):
+def _engine(former, latter, gap, fitted=False, model_name='r50_aotl'):
     from rmem_ocu_amd import build_engine, build_vos_model, get_config
     from rmem_ocu_amd.weights import fitted_state_dict, synth_state_dict
-    cfg = get_config('pre_vost', 'test', 'r50_aotl')
+    cfg = get_config('pre_vost', 'test', model_name)
     cfg.FORMER_MEM_LEN, cfg.LATTER_MEM_LEN = former, latter
     model = build_vos_model(cfg.MODEL_VOS, cfg).cuda(0)
-    model.load_state_dict(fitted_state_dict(0) if fitted else synth_state_dict(0))
+    model.load_state_dict(fitted_state_dict(0) if fitted else synth_state_dict(0, model='deaot' if model_name == 'r50_deaotl' else 'aot'))
     eng = build_engine(cfg.MODEL_ENGINE, phase='eval', aot_model=model, gpu_id=0, long_term_mem_gap=gap)
     eng.eval()
     return eng
@@ -47,7 +47,7 @@ def _engine(former, latter, gap, fitted=False):
 def _run(name, teacher_forced, use_graphs=False):
     g, frames, mask, (former, latter, n, h, w, oh, ow, gap, objs) = _load(name)
     inject_at = int(g['inject_at']) if 'inject_at' in g.files else -1
-    eng = _engine(former, latter, gap, fitted='fitted' in name)
+    eng = _engine(former, latter, gap, fitted='fitted' in name, model_name='r50_deaotl' if 'deaot' in name else 'r50_aotl')
     eng.use_graphs = use_graphs
     dev = torch.device('cuda', 0)
     frames_d = frames.to(dev)
