@@ -47,6 +47,8 @@ PEAK_BF16_TFLOPS = 2500.0
 WORKLOADS = {
     'davis17_480p_r50_N8': dict(model='r50_aotl', video=(480, 854), clip=80, objs=3, former=1, latter=7, net=None),
     # cfg 5 geometry: 720p, Swin-B, bank N = 12 (1 + 11), align_corners False -> network size = video size (multiple of 16)
+    # the model the reference's shipped eval_vost.sh runs: R50-DeAOTL, bank 1 + 8 (configs/models/r50_deaotl.py:8-9), cfg-2 geometry
+    'davis17_480p_r50deaot_N9': dict(model='r50_deaotl', video=(480, 854), clip=80, objs=3, former=1, latter=8, net=None),
     'lvos_720p_swinb_N12': dict(model='swinb_aotl', video=(720, 1280), clip=150, objs=2, former=1, latter=11, net=(720, 1280)),
 }
 
@@ -130,7 +132,8 @@ def main():
     cfg = get_config('pre_vost', 'bench', wl['model'])
     cfg.FORMER_MEM_LEN, cfg.LATTER_MEM_LEN = wl['former'], wl['latter']
     model = build_vos_model(cfg.MODEL_VOS, cfg).cuda(local_rank)
-    model.load_state_dict(synth_state_dict(0, encoder=cfg.MODEL_ENCODER))
+    deaot = cfg.MODEL_VOS == 'deaot'
+    model.load_state_dict(synth_state_dict(0, encoder=cfg.MODEL_ENCODER, model='deaot' if deaot else 'aot'))
     net_hw = wl['net'] or network_size(*VIDEO_HW)
 
     # two distinct synthetic clips per rank, reused round-robin by the clip slots
@@ -189,6 +192,8 @@ def main():
 
     L = _lib.lib()
     _lib.check(L.rmem_profile_start(4 * (args.steps // max(1, args.sample_every) + 4)), 'rmem_profile_start')
+    if deaot:
+        _lib.check(L.rmem_gated_profile_start(), 'rmem_gated_profile_start')
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -201,6 +206,8 @@ def main():
     elapsed = time.perf_counter() - t0
     ms, fl, nl = ctypes.c_double(), ctypes.c_double(), ctypes.c_int()
     _lib.check(L.rmem_profile_stop(ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(nl)), 'rmem_profile_stop')
+    if deaot:       # the dominant kernel of this workload is the value-side GEMM of the long-term gated attention
+        _lib.check(L.rmem_gated_profile_stop(ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(nl)), 'rmem_gated_profile_stop')
 
     checksum = float(sum(int(s.labels.sum().item()) for s in slots))
     from rmem_ocu_amd.clip_runner import gather_stats
@@ -221,7 +228,7 @@ def main():
                        'memory_bank': f"{wl['former']}+{wl['latter']}", 'gap': max(int(round(CLIP_LEN / 30)), 5), 'clips_in_flight_per_gpu': C,
                        'parallelism': f'clip-parallel x{world}', 'weights': 'synthetic (no checkpoint offline)',
                        'hipgraphs': not args.no_graphs, 'host_enqueue_ms_per_step': round(1e3 * host_enqueue / args.steps, 4)},
-            'roofline': {'bound': 'mfma', 'kernel': 'k_attn_partial<true, true>', 'achieved': None if achieved is None else round(achieved, 2),
+            'roofline': {'bound': 'mfma', 'kernel': 'k_gp_pv<1, true>' if deaot else 'k_attn_partial<true, true>', 'achieved': None if achieved is None else round(achieved, 2),
                          'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': None if achieved is None else round(achieved / PEAK_BF16_TFLOPS, 4),
                          'traffic': pmc_traffic() if args.workload == 'davis17_480p_r50_N8' else None, 'launches_timed': nl.value,
                          'avg_launch_us': None if not nl.value else round(1e3 * ms.value / nl.value, 2)},

@@ -281,10 +281,55 @@ __global__ __launch_bounds__(256) void k_gp_scores(GpParams p) {
   }
 }
 
+// ---- P.V fragment plumbing (inline-asm LDS reads, counted waits) ----
+struct PvFrags { bf16x8 a[2]; s16x4 lo[4], hi[4]; };
+constexpr int PV_PB = QT * KT * 2;            // bytes of the P tile in a stage (the V tile follows)
+
+__device__ __forceinline__ bf16x8 lds_b128(unsigned addr) {
+  bf16x8 v;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
+  return v;
+}
+template <int OFF>
+__device__ __forceinline__ s16x4 lds_tr16(unsigned addr) {
+  s16x4 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+// the 10 reads of key-step S (16 keys) of the stage at LDS address sb: 2 P fragments, 4 x (low, high) V fragments
+template <int S>
+__device__ __forceinline__ void pv_load(unsigned sb, const int (&pa_off)[2][4], const int (&vbase)[4], PvFrags& f) {
+  f.a[0] = lds_b128(sb + pa_off[0][S]);
+  f.a[1] = lds_b128(sb + pa_off[1][S]);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    f.lo[c] = lds_tr16<PV_PB + S * 16 * CW * 2>(sb + vbase[c]);
+    f.hi[c] = lds_tr16<PV_PB + S * 16 * CW * 2 + 4 * CW * 2>(sb + vbase[c]);
+  }
+}
+// wait until at most N LDS reads are outstanding; the fragments pass through so their consumers stay behind the wait
+template <int N>
+__device__ __forceinline__ void pv_wait(PvFrags& f) {
+  asm volatile("s_waitcnt lgkmcnt(%10)"
+               : "+v"(f.a[0]), "+v"(f.a[1]), "+v"(f.lo[0]), "+v"(f.hi[0]), "+v"(f.lo[1]), "+v"(f.hi[1]), "+v"(f.lo[2]), "+v"(f.hi[2]),
+                 "+v"(f.lo[3]), "+v"(f.hi[3])
+               : "n"(N));
+}
+__device__ __forceinline__ void pv_mma(const PvFrags& f, f32x16 (&acc)[2][4]) {
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const __attribute__((ext_vector_type(8))) short b16 = {f.lo[c][0], f.lo[c][1], f.lo[c][2], f.lo[c][3],
+                                                           f.hi[c][0], f.hi[c][1], f.hi[c][2], f.hi[c][3]};
+    const bf16x8 b = __builtin_bit_cast(bf16x8, b16);
+    acc[0][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[0], b, acc[0][c], 0, 0, 0);
+    acc[1][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[1], b, acc[1][c], 0, 0, 0);
+  }
+}
+
 // O = P V for one (query tile of 128, value slice of 256, key group).  Tiles of 64 keys stream through a 3-deep LDS ring
 // by LDS-DMA: P tile [128 q][64 keys] (16-byte chunk c of row r at slot c ^ ((r >> 1) & 7)), V tile [64 keys][256 c]
-// (chunk c of key row k at slot c ^ ((k & 3) << 1), which spreads the four key rows of a transposed read over four
-// 32-byte bank groups).  The swizzles are applied to the per-lane SOURCE address, the LDS side of a DMA is linear.
+// (chunk c of key row k at slot c ^ ((k & 3) << 2): the 32 lanes of a transposed-read half -- 4 key rows x 2 column groups
+// x 4 pieces of 8 bytes -- then cover all 64 banks once).  The swizzles are applied to the per-lane SOURCE address, the LDS side of a DMA is linear.
 // Waves = (query half qh) x (column half ch), 64 x 128 outputs each = 8 accumulator tiles of 32 x 32.
 template <int MODE, bool TIMED>
 __global__ __launch_bounds__(256) void k_gp_pv(GpParams p) {
@@ -307,9 +352,24 @@ __global__ __launch_bounds__(256) void k_gp_pv(GpParams p) {
     g = rest / p.nq;
   }
   const int q0 = qt * QT, c0 = cs * CW;
-  const int r_begin = g * p.rows_per_group, r_end = min(p.nrows, r_begin + p.rows_per_group);
-  int ntl = 0;
-  for (int r = r_begin; r < r_end; ++r) ntl += (get_row<MODE>(p, r).kn + KT - 1) / KT;
+  // table rows in LDS (scalar-like reads that do not touch vmcnt: the DMA pipeline below counts on vmcnt); the key tiles of
+  // all rows form one stream that is cut into `groups` equal ranges
+  __shared__ int rowtab[MAX_ROWS][4];       // slot, key_begin, key_count, P column of key 0
+  __shared__ int tile_total;
+  if (tid < p.nrows) {
+    const GpRow r = get_row<MODE>(p, tid);
+    rowtab[tid][0] = r.slot; rowtab[tid][1] = r.kb; rowtab[tid][2] = r.kn; rowtab[tid][3] = r.t * p.Lp + r.kb;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int n = 0;
+    for (int r = 0; r < p.nrows; ++r) n += (rowtab[r][2] + KT - 1) / KT;
+    tile_total = n;
+  }
+  __syncthreads();
+  const int tpg = (tile_total + p.groups - 1) / p.groups;
+  const int tile_begin = g * tpg;
+  const int ntl = max(0, min(tile_total, tile_begin + tpg) - tile_begin);
 
   // ---- DMA source bookkeeping: 4 P pieces and 8 V pieces of 16 bytes per lane and stage ----
   int p_off[4], v_key[8], v_off[8];
@@ -320,19 +380,21 @@ __global__ __launch_bounds__(256) void k_gp_pv(GpParams p) {
   }
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
-    const int s = (wave * 8 + i) * 64 + lane, key = s >> 5, lc = (s & 31) ^ ((key & 3) << 1);
+    const int s = (wave * 8 + i) * 64 + lane, key = s >> 5, lc = (s & 31) ^ ((key & 3) << 2);
     v_key[i] = key;
     v_off[i] = key * p.ldv + c0 + lc * 8;
   }
   const char* zero = reinterpret_cast<const char*>(g_gp_zero16);
-  int i_row = r_begin, i_t = 0;
-  GpRow ir = get_row<MODE>(p, min(i_row, p.nrows - 1));
+  // issue cursor: (row, tile inside the row) of the next tile to fetch
+  int i_row = 0, i_t = tile_begin;
+  while (i_row < p.nrows - 1 && i_t >= (rowtab[i_row][2] + KT - 1) / KT) { i_t -= (rowtab[i_row][2] + KT - 1) / KT; ++i_row; }
+  int ir_slot = rowtab[i_row][0], ir_kb = rowtab[i_row][1], ir_kn = rowtab[i_row][2], ir_pc = rowtab[i_row][3];
   auto issue = [&](int stage) {
     char* Ps = smem + stage * SB;
     char* Vs = Ps + PB;
-    const bf16* psrc = p.P + (long)ir.t * p.Lp + ir.kb + i_t * KT;
-    const bf16* vsrc = p.v + (long)ir.slot * p.v_slot_stride + (long)(ir.kb + i_t * KT) * p.ldv;
-    const int left = ir.kn - i_t * KT;
+    const bf16* psrc = p.P + ir_pc + i_t * KT;
+    const bf16* vsrc = p.v + (long)ir_slot * p.v_slot_stride + (long)(ir_kb + i_t * KT) * p.ldv;
+    const int left = ir_kn - i_t * KT;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
       __builtin_amdgcn_global_load_lds((gptr_t)(psrc + p_off[i]), (lptr_t)(Ps + (wave * 4 + i) * 1024), 16, 0, 0);
@@ -341,10 +403,10 @@ __global__ __launch_bounds__(256) void k_gp_pv(GpParams p) {
       const char* src = v_key[i] < left ? reinterpret_cast<const char*>(vsrc + v_off[i]) : zero;
       __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Vs + (wave * 8 + i) * 1024), 16, 0, 0);
     }
-    if (++i_t * KT >= ir.kn) {
+    if (++i_t * KT >= ir_kn) {
       i_t = 0;
-      ++i_row;
-      if (i_row < r_end) ir = get_row<MODE>(p, i_row);
+      i_row = min(i_row + 1, p.nrows - 1);
+      ir_slot = rowtab[i_row][0]; ir_kb = rowtab[i_row][1]; ir_kn = rowtab[i_row][2]; ir_pc = rowtab[i_row][3];
     }
   };
 
@@ -357,16 +419,23 @@ __global__ __launch_bounds__(256) void k_gp_pv(GpParams p) {
       for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
 
   // fragment addressing.  P (A operand): row 64 qh + 32 a + lq, logical chunk 2 s + kg.  V (B operand, transposed read):
-  // the 16-lane group (lane >> 4) & 1 covers 16 columns; lane 4 q' + p' of it addresses key row q', columns 4 p' .. 4 p' + 3
-  int pa_row[2];
+  // the 16-lane group (lane >> 4) & 1 covers 16 columns; lane 4 q' + p' of it addresses key row q', columns 4 p' .. 4 p' + 3.
+  // The LDS reads are inline asm: the compiler orders a builtin transposed read behind ALL outstanding LDS-DMA
+  // (s_waitcnt vmcnt(0)), which would serialise the ring; with asm reads the waits are the counted ones below.
+  const unsigned smem_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  int pa_off[2][4];
 #pragma unroll
-  for (int a = 0; a < 2; ++a) pa_row[a] = 64 * qh + 32 * a + lq;
+  for (int a = 0; a < 2; ++a) {
+    const int row = 64 * qh + 32 * a + lq;
+#pragma unroll
+    for (int st = 0; st < 4; ++st) pa_off[a][st] = row * 128 + (((2 * st + kg) ^ ((row >> 1) & 7)) << 4);
+  }
   const int tq = (lane & 15) >> 2, tp = lane & 3, tg = (lane >> 4) & 1;
-  int vb_off[4];        // byte offset inside a key row of this lane's 8 bytes, per 32-column block
+  int vbase[4];         // byte offset of this lane's 8 bytes for key-step 0, low half, per 32-column block
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
     const int col = 128 * ch + 32 * c + 16 * tg + 4 * tp;
-    vb_off[c] = ((((col >> 3) ^ (tq << 1)) << 4) | ((col & 7) << 1));
+    vbase[c] = (8 * kg + tq) * (CW * 2) + ((((col >> 3) ^ (tq << 2)) << 4) | ((col & 7) << 1));
   }
 
   if (ntl > 0) issue(0);
@@ -378,27 +447,16 @@ __global__ __launch_bounds__(256) void k_gp_pv(GpParams p) {
     __builtin_amdgcn_s_barrier();
     const int nxt = stage == 0 ? 2 : stage - 1;
     if (j + 2 < ntl) issue(nxt);
-    const char* Ps = smem + stage * SB;
-    const char* Vs = Ps + PB;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      bf16x8 af[2], bfr[4];
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
-        af[a] = *reinterpret_cast<const bf16x8*>(Ps + pa_row[a] * 128 + (((2 * s + kg) ^ ((pa_row[a] >> 1) & 7)) << 4));
-      const char* vrow = Vs + (16 * s + 8 * kg + tq) * (CW * 2);
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vrow + vb_off[c]));
-        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vrow + 4 * (CW * 2) + vb_off[c]));
-        const __attribute__((ext_vector_type(8))) short b16 = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        bfr[c] = __builtin_bit_cast(bf16x8, b16);
-      }
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bfr[c], acc[a][c], 0, 0, 0);
-    }
+    const unsigned sb = smem_base + stage * SB;
+    PvFrags fa, fb;
+    pv_load<0>(sb, pa_off, vbase, fa);
+    pv_load<1>(sb, pa_off, vbase, fb);
+    pv_wait<10>(fa); pv_mma(fa, acc);
+    pv_load<2>(sb, pa_off, vbase, fa);
+    pv_wait<10>(fb); pv_mma(fb, acc);
+    pv_load<3>(sb, pa_off, vbase, fb);
+    pv_wait<10>(fa); pv_mma(fa, acc);
+    pv_wait<0>(fb); pv_mma(fb, acc);
     stage = stage == 2 ? 0 : stage + 1;
   }
 
@@ -485,10 +543,12 @@ GpPlan plan(int Lq, int DV, int frames, int keys_per_frame, int nrows) {
   g.ldp = frames * g.Lp;
   g.nrows = nrows;
   const int tiles = (g.Lqp / QT) * (DV / CW);
-  int groups = tiles >= 256 ? 1 : 256 / tiles;      // about one workgroup per CU
-  if (groups > nrows) groups = nrows;
-  g.rpg = (nrows + groups - 1) / groups;
-  g.groups = (nrows + g.rpg - 1) / g.rpg;
+  int groups = tiles >= 256 ? 1 : 256 / tiles;      // about one workgroup per CU; the key-tile stream is cut evenly
+  const int max_tiles = frames * (g.Lp / KT);
+  if (groups > 8) groups = 8;
+  if (groups > max_tiles) groups = max_tiles;
+  g.rpg = 0;
+  g.groups = groups;
   auto al = [](size_t x) { return (x + 255) / 256 * 256; };
   g.off_l = al((size_t)nrows * g.Lqp * 4);
   g.off_p = g.off_l + al((size_t)nrows * g.Lqp * 4);
