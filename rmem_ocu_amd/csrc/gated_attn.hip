@@ -20,6 +20,7 @@
 #include "common.h"
 #include "../../include/rmem.h"
 #include <math.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -54,6 +55,7 @@ struct GpParams {
   int H, W; const float* rel; int ldrel;      // local-window mode
   int DV, nq, ncs, groups, rows_per_group;
   float* slabs;
+  int debug;               // kernel experiments only (RMEM_GP_DEBUG): 1 = no MFMA, 2 = no refills after the first stages
 };
 
 // MODE 0: one key frame split into nrows ranges of `per` keys; 1: chunk table over the memory bank; 2: as 0 with the 15x15
@@ -90,8 +92,8 @@ template <int MODE, int PASS>
 __global__ __launch_bounds__(256) void k_gp_scores(GpParams p) {
   __shared__ __attribute__((aligned(16))) bf16 Ks[2][KT * DQ];
   __shared__ float red[2][QT];
-  __shared__ float biasq[QT];
   __shared__ float mq[QT];
+  __shared__ __attribute__((aligned(16))) bf16 Pst[PASS == 1 ? 4 : 1][32 * 32];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int qh = wave >> 1, kh = wave & 1, lq = lane & 31, kg = lane >> 5;
@@ -117,32 +119,41 @@ __global__ __launch_bounds__(256) void k_gp_scores(GpParams p) {
     }
   }
 
-  // ---- per-query constants in LDS: temporal-PE logit bias of this table row, final row maximum (PASS 1) ----
-  {
-    const int ql = tid & (QT - 1), hf = tid >> 7;
-    const int qrow = min(q0 + ql, p.Lq - 1);
-    float part = 0.f;
-    if (has_mem) {
-      const bf16* qp = p.q + (long)qrow * p.ldq + 64 * hf;
-      const float* pm = p.pe_mem + row.pe_slot * DQ + 64 * hf;
-      const float* pc = p.pe_cur ? p.pe_cur + 64 * hf : nullptr;
-      for (int d = 0; d < 64; ++d) {
-        const bf16 qs = (bf16)(((float)qp[d] + (pc ? pc[d] : 0.f)) * p.qscale);
-        part += (float)qs * pm[d];
+  // ---- temporal-PE logit bias of this table row, per query: Qs . pe_mem[slot] through the matrix pipe.  The B operand is
+  // the embedding broadcast over all 32 columns (split into bf16 high + low parts: ~2^-17 relative), so every lane ends up
+  // with the bias of exactly the 2 x 16 query rows its score accumulators hold ----
+  f32x16 bacc[2];
+#pragma unroll
+  for (int b = 0; b < 2; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bacc[b][r] = 0.f;
+  if (has_mem) {
+    const float* pm = p.pe_mem + row.pe_slot * DQ + 8 * kg;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const f32x4 e0 = *reinterpret_cast<const f32x4*>(pm + 16 * s), e1 = *reinterpret_cast<const f32x4*>(pm + 16 * s + 4);
+      bf16x8 hi8, lo8;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float e = j < 4 ? e0[j & 3] : e1[j & 3];
+        hi8[j] = (bf16)e;
+        lo8[j] = (bf16)(e - (float)hi8[j]);
+      }
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        bacc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[b][s], hi8, bacc[b], 0, 0, 0);
+        bacc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[b][s], lo8, bacc[b], 0, 0, 0);
       }
     }
-    red[hf][ql] = part;
+  }
+  if (PASS == 1) {      // final row maximum over all table rows, via LDS
+    const int ql = tid & (QT - 1), hf = tid >> 7;
+    float m = NEG_BIG;
+    for (int r = hf; r < p.nrows; r += 2) m = fmaxf(m, p.mpart[(long)r * p.Lqp + q0 + ql]);
+    red[hf][ql] = m;
     __syncthreads();
-    if (tid < QT) biasq[tid] = red[0][tid] + red[1][tid];
+    if (tid < QT) mq[tid] = fmaxf(red[0][tid], red[1][tid]);
     __syncthreads();
-    if (PASS == 1) {
-      float m = NEG_BIG;
-      for (int r = hf; r < p.nrows; r += 2) m = fmaxf(m, p.mpart[(long)r * p.Lqp + q0 + ql]);
-      red[hf][ql] = m;
-      __syncthreads();
-      if (tid < QT) mq[tid] = fmaxf(red[0][tid], red[1][tid]);
-      __syncthreads();
-    }
   }
   // this lane's 2 x 16 query rows: ql(b, r) = 64 qh + 32 b + (r & 3) + 8 (r >> 2) + 4 kg
   float off[2][16];      // PASS 0: bias; PASS 1: bias - row maximum
@@ -152,7 +163,7 @@ __global__ __launch_bounds__(256) void k_gp_scores(GpParams p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int ql = 64 * qh + 32 * b + (r & 3) + 8 * (r >> 2) + 4 * kg;
-      off[b][r] = PASS == 1 ? biasq[ql] - mq[ql] : biasq[ql];
+      off[b][r] = PASS == 1 ? bacc[b][r] - mq[ql] : bacc[b][r];
       if (MODE == 2) {
         const int qg = min(q0 + ql, p.Lq - 1);
         const int qy = qg / p.W;
@@ -171,21 +182,20 @@ __global__ __launch_bounds__(256) void k_gp_scores(GpParams p) {
     if (key_hi <= row.kb || key_lo >= row.kb + row.kn) { t_lo = 0; t_hi = 0; }
     if (t_hi < t_lo) t_hi = t_lo;
   }
+  if (p.debug & 4) t_hi = t_lo;
   bf16* Pq = p.P + (long)row.t * p.Lp + row.kb;       // + q * ldp + key index inside the row
-  if (MODE == 2 && PASS == 1) {                       // tiles outside the window band: probability zero
-    const bf16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int t = 0; t < ntiles; ++t) {
-      if (t >= t_lo && t < t_hi) continue;
-      for (int i = tid; i < QT * 8; i += 256)
-        *reinterpret_cast<bf16x8*>(Pq + (long)(q0 + (i >> 3)) * p.ldp + t * KT + (i & 7) * 8) = z8;
-    }
-  }
-
-  float mx[2][16], ls[2][16];
+  float mx[2][16];       // PASS 0: running maxima of this lane's rows
+  float ls4[4] = {0.f, 0.f, 0.f, 0.f};   // PASS 1: row-sum pieces of rows 16 i + (lane >> 2), keys 8 (lane & 3) .. + 7 of every tile
 #pragma unroll
   for (int b = 0; b < 2; ++b)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { mx[b][r] = NEG_BIG; ls[b][r] = 0.f; }
+    for (int r = 0; r < 16; ++r) mx[b][r] = NEG_BIG;
+  // bias (- row maximum) as the accumulators' initial value: no per-score add
+  f32x16 cinit[2];
+#pragma unroll
+  for (int b = 0; b < 2; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cinit[b][r] = off[b][r];
 
   // staging: thread -> 4 x (key, 16-byte chunk) of the 64 x 256 B tile
   bf16x8 rk[4];
@@ -212,19 +222,16 @@ __global__ __launch_bounds__(256) void k_gp_scores(GpParams p) {
   }
   __syncthreads();
   const int kl = 32 * kh + lq;                        // this lane's key inside a tile
+  bf16* pst = &Pst[wave][0];                          // this wave's [64 q][32 keys] transposition pad
   for (int t = t_lo; t < t_hi; ++t) {
     const int cur = (t - t_lo) & 1;
     if (t + 1 < t_hi) load_tile(t + 1);
     f32x16 acc[2];
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
-#pragma unroll
     for (int s = 0; s < 8; ++s) {
       const bf16x8 kf = *reinterpret_cast<const bf16x8*>(&Ks[cur][kl * DQ + (((2 * s + kg) ^ (kl & 15)) << 3)]);
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[0][s], kf, acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[1][s], kf, acc[1], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[0][s], kf, s == 0 ? cinit[0] : acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[1][s], kf, s == 0 ? cinit[1] : acc[1], 0, 0, 0);
     }
     const int kidx = t * KT + kl;
     const bool kvalid = kidx < row.kn;
@@ -234,41 +241,87 @@ __global__ __launch_bounds__(256) void k_gp_scores(GpParams p) {
       ky = kgl / p.W;
       kx = kgl - ky * p.W;
     }
+    // window mode: all 32 relative-embedding gathers of the tile are issued before any of this tile's P stores (loads and
+    // stores share vmcnt, so a gather issued after a store would wait for that store to drain); the index is clamped into
+    // the row so the loads are unconditional
+    float rl[2][16];
+    unsigned okm = 0;
+    if (MODE == 2) {
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int dy = ky - (qyx[b][r] >> 16) + WIN_R, dx = kx - (qyx[b][r] & 0xffff) + WIN_R;
+          const bool in = (unsigned)dy < (unsigned)WIN && (unsigned)dx < (unsigned)WIN;
+          okm |= (unsigned)in << (16 * b + r);
+          const int rr = 32 * b + (r & 3) + 8 * (r >> 2) + 4 * kg;
+          rl[b][r] = p.rel[(long)min(q0 + 64 * qh + rr, p.Lq - 1) * p.ldrel + (in ? dy * WIN + dx : 0)];
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         bool ok = kvalid;
-        float sv = acc[b][r] + off[b][r];
+        float sv = acc[b][r];
+        const int r32 = (r & 3) + 8 * (r >> 2) + 4 * kg;             // query row inside the 32-row block b
         if (MODE == 2) {
-          const int dy = ky - (qyx[b][r] >> 16) + WIN_R, dx = kx - (qyx[b][r] & 0xffff) + WIN_R;
-          ok = ok && (unsigned)dy < (unsigned)WIN && (unsigned)dx < (unsigned)WIN;
-          if (ok) {
-            const int ql = 64 * qh + 32 * b + (r & 3) + 8 * (r >> 2) + 4 * kg;
-            sv += p.rel[(long)min(q0 + ql, p.Lq - 1) * p.ldrel + dy * WIN + dx] * LOG2E;
-          }
+          ok = ok && ((okm >> (16 * b + r)) & 1u);
+          sv += rl[b][r] * LOG2E;
         }
-        if (PASS == 0) {
-          mx[b][r] = fmaxf(mx[b][r], ok ? sv : NEG_BIG);
-        } else {
-          const bf16 pb = (bf16)(ok ? __builtin_amdgcn_exp2f(sv) : 0.f);
-          ls[b][r] += (float)pb;
-          const int ql = 64 * qh + 32 * b + (r & 3) + 8 * (r >> 2) + 4 * kg;
-          Pq[(long)(q0 + ql) * p.ldp + kidx] = pb;
+        if (PASS == 0) mx[b][r] = fmaxf(mx[b][r], ok ? sv : NEG_BIG);
+        else pst[r32 * 32 + lq] = (bf16)(ok ? __builtin_amdgcn_exp2f(sv) : 0.f);
+      }
+      if (PASS == 1) {
+        // the wave's 32 x 32 block leaves as 16-byte pieces: lane -> (row 16 i + (lane >> 2), keys 8 (lane & 3) .. + 7).
+        // LDS operations of one wave execute in order, so the reads see the stores above (and the next block's stores come
+        // after these reads) without a barrier
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int r32 = 16 * i + (lane >> 2);
+          const bf16x8 v = *reinterpret_cast<const bf16x8*>(&pst[r32 * 32 + (lane & 3) * 8]);
+          *reinterpret_cast<bf16x8*>(Pq + (long)(q0 + 64 * qh + 32 * b + r32) * p.ldp + t * KT + 32 * kh + (lane & 3) * 8) = v;
+          float sum = 0.f;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) sum += (float)v[j];
+          ls4[2 * b + i] += sum;
         }
       }
+    }
     if (t + 1 < t_hi) store_tile(cur ^ 1);
     __syncthreads();
   }
 
   // ---- reduce over the keys (lanes) and over the two key halves (waves) ----
+  if (PASS == 0) {
+    // 128 rows x 64 key lanes of partial maxima through LDS (the K ring is free now): 32 dependent shuffle chains per lane
+    // cost more than the whole tile loop of a short row
+    float* scr = reinterpret_cast<float*>(&Ks[0][0]);            // [128 rows][64]: column 32 kh + lq
 #pragma unroll
-  for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < 2; ++b)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float v = PASS == 0 ? half_max(mx[b][r]) : half_sum(ls[b][r]);
-      if (lq == 0) red[kh][64 * qh + 32 * b + (r & 3) + 8 * (r >> 2) + 4 * kg] = v;
+      for (int r = 0; r < 16; ++r) scr[(64 * qh + 32 * b + (r & 3) + 8 * (r >> 2) + 4 * kg) * 64 + 32 * kh + lq] = mx[b][r];
+    __syncthreads();
+    {
+      const int rrow = tid >> 1, hf = tid & 1;
+      float m = NEG_BIG;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(&scr[rrow * 64 + 32 * hf + 4 * j]);
+        m = fmaxf(fmaxf(fmaxf(m, v[0]), fmaxf(v[1], v[2])), v[3]);
+      }
+      m = fmaxf(m, __shfl_xor(m, 1, 64));
+      if (hf == 0) { red[0][rrow] = m; red[1][rrow] = NEG_BIG; }
     }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float v = ls4[i];
+      v += __shfl_xor(v, 1, 64);
+      v += __shfl_xor(v, 2, 64);
+      if ((lane & 3) == 0) red[kh][64 * qh + 16 * i + (lane >> 2)] = v;
+    }
+  }
   __syncthreads();
   if (tid < QT) {
     float* dst = (PASS == 0 ? p.mpart : p.lpart) + (long)blockIdx.y * p.Lqp + q0 + tid;
@@ -367,9 +420,17 @@ __global__ __launch_bounds__(256) void k_gp_pv(GpParams p) {
     tile_total = n;
   }
   __syncthreads();
-  const int tpg = (tile_total + p.groups - 1) / p.groups;
-  const int tile_begin = g * tpg;
-  const int ntl = max(0, min(tile_total, tile_begin + tpg) - tile_begin);
+  // window mode: only the key tiles that can intersect a 15x15 window of this query tile (the same band k_gp_scores<2, .>
+  // visits; the probabilities outside it are never written)
+  int band_lo = 0, band_hi = tile_total;
+  if (p.W > 0) {
+    const int y0 = q0 / p.W, y1 = min(q0 + QT - 1, p.Lq - 1) / p.W;
+    band_lo = max(0, (y0 - WIN_R) * p.W) / KT;
+    band_hi = min(tile_total, (min(p.lk, (y1 + WIN_R + 1) * p.W) + KT - 1) / KT);
+  }
+  const int tpg = (band_hi - band_lo + p.groups - 1) / p.groups;
+  const int tile_begin = band_lo + g * tpg;
+  const int ntl = max(0, min(band_hi, tile_begin + tpg) - tile_begin);
 
   // ---- DMA source bookkeeping: 4 P pieces and 8 V pieces of 16 bytes per lane and stage ----
   int p_off[4], v_key[8], v_off[8];
@@ -446,17 +507,18 @@ __global__ __launch_bounds__(256) void k_gp_pv(GpParams p) {
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     const int nxt = stage == 0 ? 2 : stage - 1;
-    if (j + 2 < ntl) issue(nxt);
+    if (j + 2 < ntl && !(p.debug & 2)) issue(nxt);
     const unsigned sb = smem_base + stage * SB;
     PvFrags fa, fb;
     pv_load<0>(sb, pa_off, vbase, fa);
     pv_load<1>(sb, pa_off, vbase, fb);
-    pv_wait<10>(fa); pv_mma(fa, acc);
+    const bool mm = !(p.debug & 1);
+    pv_wait<10>(fa); if (mm) pv_mma(fa, acc);
     pv_load<2>(sb, pa_off, vbase, fa);
-    pv_wait<10>(fb); pv_mma(fb, acc);
+    pv_wait<10>(fb); if (mm) pv_mma(fb, acc);
     pv_load<3>(sb, pa_off, vbase, fb);
-    pv_wait<10>(fa); pv_mma(fa, acc);
-    pv_wait<0>(fb); pv_mma(fb, acc);
+    pv_wait<10>(fa); if (mm) pv_mma(fa, acc);
+    pv_wait<0>(fb); if (mm) pv_mma(fb, acc);
     stage = stage == 2 ? 0 : stage + 1;
   }
 
@@ -513,25 +575,17 @@ __global__ __launch_bounds__(256) void k_gp_combine(GpCombine p) {
   *reinterpret_cast<bf16x8*>(p.out + (long)q * p.ldo + c) = o;
 }
 
-// mass[q][t] = sum of the row sums of frame t / total (transformer.py:1185-1192 with one head)
+// mass[q][t] = sum of the row sums of frame t / total (transformer.py:1185-1192 with one head); grid = (query blocks, T)
 __global__ __launch_bounds__(256) void k_gp_mass(GpCombine p) {
-  const int q = blockIdx.x * 256 + threadIdx.x;
+  const int q = blockIdx.x * 256 + threadIdx.x, t = blockIdx.y;
   if (q >= p.Lq) return;
-  float acc[32];
-#pragma unroll
-  for (int t = 0; t < 32; ++t) acc[t] = 0.f;
-  float l = 0.f;
+  float l = 0.f, lt = 0.f;
   for (int r = 0; r < p.nrows; ++r) {
     const float v = p.lpart[(long)r * p.Lqp + q];
-    const int t = p.rows[r].t;
     l += v;
-#pragma unroll
-    for (int tt = 0; tt < 32; ++tt) acc[tt] += tt == t ? v : 0.f;
+    lt += p.rows[r].t == t ? v : 0.f;
   }
-  const float inv = 1.f / l;
-#pragma unroll
-  for (int t = 0; t < 32; ++t)
-    if (t < p.T) p.mass[(long)q * p.T + t] = acc[t] * inv;
+  p.mass[(long)q * p.T + t] = lt / l;
 }
 
 struct GpPlan { int Lqp, Lp, ldp, nrows, groups, rpg; size_t off_l, off_p, off_s, total; };
@@ -607,7 +661,7 @@ void launch_all(GpParams& p, const GpPlan& g, GpCombine& c, bool timed, double f
     hipLaunchKernelGGL((k_gp_pv<PM, false>), pg, dim3(256), 0, s, p);
   }
   hipLaunchKernelGGL(k_gp_combine, dim3((unsigned)(((long)c.Lq * (c.DV / 8) + 255) / 256)), dim3(256), 0, s, c);
-  if (c.mass) hipLaunchKernelGGL(k_gp_mass, dim3((c.Lq + 255) / 256), dim3(256), 0, s, c);
+  if (c.mass) hipLaunchKernelGGL(k_gp_mass, dim3((c.Lq + 255) / 256, c.T), dim3(256), 0, s, c);
   (void)g;
 }
 
@@ -691,6 +745,7 @@ extern "C" int rmem_gated_attn(const void* q, int ldq, const void* k_bank, long 
   p.mpart = (float*)ws; p.lpart = (float*)(ws + g.off_l); p.P = (bf16*)(ws + g.off_p); p.slabs = (float*)(ws + g.off_s);
   p.qscale = LOG2E / sqrtf((float)DQ);
   p.DV = DV; p.nq = g.Lqp / QT; p.ncs = DV / CW; p.groups = g.groups; p.rows_per_group = g.rpg;
+  { static const int dbg = getenv("RMEM_GP_DEBUG") ? atoi(getenv("RMEM_GP_DEBUG")) : 0; p.debug = dbg; }
   GpCombine c = {};
   c.slabs = p.slabs; c.groups = g.groups; c.lpart = p.lpart; c.nrows = nrows; c.Lq = Lq; c.Lqp = g.Lqp; c.DV = DV;
   c.ua = (const bf16*)u_a; c.ldua = ldua; c.ub = (const bf16*)u_b; c.ldub = ldub; c.usplit = usplit;
@@ -721,6 +776,7 @@ extern "C" int rmem_local_gated_attn(const void* q, int ldq, const void* k, int 
   p.qscale = LOG2E / sqrtf((float)DQ);
   p.H = H; p.W = W; p.rel = rel; p.ldrel = ldrel;
   p.DV = DV; p.nq = g.Lqp / QT; p.ncs = DV / CW; p.groups = g.groups; p.rows_per_group = g.rpg;
+  { static const int dbg = getenv("RMEM_GP_DEBUG") ? atoi(getenv("RMEM_GP_DEBUG")) : 0; p.debug = dbg; }
   GpCombine c = {};
   c.slabs = p.slabs; c.groups = g.groups; c.lpart = p.lpart; c.nrows = p.nrows; c.Lq = L; c.Lqp = g.Lqp; c.DV = DV;
   c.ua = (const bf16*)u_a; c.ldua = ldua; c.ub = (const bf16*)u_b; c.ldub = ldub; c.usplit = usplit;
