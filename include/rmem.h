@@ -50,6 +50,8 @@ typedef struct rmem_conv_desc {
   int res_f32;        /* 1: residual is fp32, 0: bf16 */
   int ldx;            /* 1x1 stride-1 problems only: input row stride in elements (0 = Cin); lets a GEMM read a column
                          range of a wider activation buffer (the torch.split / torch.cat of transformer.py:1104-1124) */
+  int batch;          /* images in x / y (0 or 1 = one): x is [batch][H][W][Cin], y [batch][Ho][Wo] rows of ldo; several
+                         clips' frames go through the encoder as one launch per layer */
   int act_begin;      /* the activation applies to output channels >= act_begin (multiple of 8; 0 = all): one GEMM for
                          linear_QV, whose Q half is raw and whose V half goes through SiLU (transformer.py:1104-1110) */
 } rmem_conv_desc;

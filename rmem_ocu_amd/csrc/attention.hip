@@ -48,6 +48,7 @@ struct AttnParams {
   int Lq, heads, C, nq;
   float* opart; float* ml;
   float qscale;
+  bf16* direct_out; int ldo;      // one chunk only: normalised bf16 output straight from this kernel (no combine launch)
 };
 
 __device__ __forceinline__ int kswz(int row, int chunk) { return row * D + ((chunk ^ ((row >> 2) & 3)) << 3); }
@@ -231,6 +232,17 @@ __global__ __launch_bounds__(256) void k_attn_partial(AttnParams p) {
   }
 
   const int qg = qt * 128 + wave * 32 + lq;
+  if (p.direct_out) {
+    if (qg < p.Lq) {
+      const float inv = 1.f / lacc[0];
+      bf16* o = p.direct_out + (long)qg * p.ldo + head * D + 4 * lh;
+#pragma unroll
+      for (int g = 0; g < 4; ++g)    // C/D rows (r&3) + 8(r>>2) + 4h -> d = 8g + 4h + (0..3)
+        *reinterpret_cast<bf16x4*>(o + 8 * g) = bf16x4{(bf16)(oacc[4 * g] * inv), (bf16)(oacc[4 * g + 1] * inv),
+                                                       (bf16)(oacc[4 * g + 2] * inv), (bf16)(oacc[4 * g + 3] * inv)};
+    }
+    return;
+  }
   if (qg < p.Lq) {
     // partial O layout [chunk][head][G = d / 4][q] x float4: a half-wave stores 512 contiguous bytes per instruction
     const long ch = (long)c * p.heads + head;
@@ -407,6 +419,9 @@ extern "C" int rmem_mem_read_attn(const void* q, int ldq, const void* k_bank, co
   p.opart = (float*)workspace; p.ml = p.opart + (size_t)nchunks * heads * Lq * D;
   p.qscale = 1.4426950408889634f / sqrtf((float)D);
   p.nq = (Lq + 127) / 128;
+  const bool direct = !chunks && nchunks == 1;          // a single key range: no partials to merge
+  p.direct_out = direct ? (bf16*)out : nullptr;
+  p.ldo = ldo;
   dim3 grid(p.nq * heads * nchunks);
   if (chunks) {
     // time this launch if asked to (never while the stream is being captured into a graph)
@@ -430,6 +445,7 @@ extern "C" int rmem_mem_read_attn(const void* q, int ldq, const void* k_bank, co
   } else {
     hipLaunchKernelGGL((k_attn_partial<false, false>), grid, dim3(256), 0, s, p);
   }
+  if (direct) return rmem_check_launch("rmem_mem_read_attn");
   CombineParams cp;
   cp.opart = p.opart; cp.ml = p.ml; cp.chunks = chunks; cp.nchunks = nchunks; cp.Lq = Lq; cp.heads = heads;
   cp.out = (bf16*)out; cp.ldo = ldo; cp.mass = attn_mass; cp.T = T;

@@ -40,7 +40,7 @@ struct ConvParams {
   bf16* y2;
   float* slabs;          // split-K partials [splits][M][Cout] (fp32) or null
   int H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad;
-  int M, K;
+  int M, K, HoWo;
   int ldo, ldr, ld2;
   int relu, out_f32, res_f32;
   int ldx;               // input row stride of the 1x1 (GEMM) case
@@ -158,10 +158,11 @@ __global__ __launch_bounds__(256) void k_conv_gemm(ConvParams p) {
       a_base[i] = (long)m * p.ldx;
       a_hi0[i] = a_wi0[i] = 0;
     } else {
-      const int ho = m / p.Wo, wo = m - ho * p.Wo;
+      const int img = m / p.HoWo, rem = m - img * p.HoWo;      // batch of images: rows are [image][ho][wo]
+      const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
       a_hi0[i] = ho * p.stride - p.pad;
       a_wi0[i] = wo * p.stride - p.pad;
-      a_base[i] = 0;
+      a_base[i] = (long)img * p.H * p.W * p.Cin;
     }
   }
   if (IS1X1) {
@@ -189,7 +190,7 @@ __global__ __launch_bounds__(256) void k_conv_gemm(ConvParams p) {
       } else {
         const int hi = a_hi0[i] + a_kh, wi = a_wi0[i] + a_kw;
         if (a_ok[i] && a_kh < p.KH && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W)
-          v = *reinterpret_cast<const bf16x8*>(p.x + ((long)hi * p.W + wi) * p.Cin + a_ci);
+          v = *reinterpret_cast<const bf16x8*>(p.x + a_base[i] + ((long)hi * p.W + wi) * p.Cin + a_ci);
       }
       xa[i] = v;
     }
@@ -335,10 +336,11 @@ __global__ __launch_bounds__(256) void k_conv_gemm_dma(ConvParams p) {
       a_base[i] = (long)m * p.ldx;
       a_hi0[i] = a_wi0[i] = a_ci[i] = a_kw[i] = a_kh[i] = 0;
     } else {
-      const int ho = m / p.Wo, wo = m - ho * p.Wo;
+      const int img = m / p.HoWo, rem = m - img * p.HoWo;
+      const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
       a_hi0[i] = ho * p.stride - p.pad;
       a_wi0[i] = wo * p.stride - p.pad;
-      a_base[i] = 0;
+      a_base[i] = (long)img * p.H * p.W * p.Cin;
       const int kidx = kt0 * BK + a_c[i] * 8;
       const int kk = kidx / p.Cin;
       a_ci[i] = kidx - kk * p.Cin;
@@ -363,7 +365,7 @@ __global__ __launch_bounds__(256) void k_conv_gemm_dma(ConvParams p) {
       } else {
         const int hi = a_hi0[i] + a_kh[i], wi = a_wi0[i] + a_kw[i];
         if (a_ok[i] && a_kh[i] < p.KH && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W)
-          src = reinterpret_cast<const char*>(p.x + ((long)hi * p.W + wi) * p.Cin + a_ci[i]);
+          src = reinterpret_cast<const char*>(p.x + a_base[i] + ((long)hi * p.W + wi) * p.Cin + a_ci[i]);
         a_ci[i] += BK;
         while (a_ci[i] >= p.Cin) {
           a_ci[i] -= p.Cin;
@@ -519,7 +521,7 @@ bool use_small_tiles(int M, int Cout) {
 
 extern "C" size_t rmem_conv_workspace_bytes(const rmem_conv_desc* d) {
   if (!d) return 0;
-  const int M = d->Ho * d->Wo, K = d->KH * d->KW * d->Cin;
+  const int M = (d->batch > 0 ? d->batch : 1) * d->Ho * d->Wo, K = d->KH * d->KW * d->Cin;
   if (!use_small_tiles(M, d->Cout)) return 0;
   const int s = plan_splits(M, d->Cout, K);
   return s > 1 ? (size_t)s * M * d->Cout * sizeof(float) : 0;
@@ -542,7 +544,8 @@ extern "C" int rmem_conv2d_nhwc(const rmem_conv_desc* d, const void* x, const vo
   p.slabs = nullptr;
   p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Ho = Ho; p.Wo = Wo; p.Cout = d->Cout;
   p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad;
-  p.M = Ho * Wo; p.K = d->KH * d->KW * d->Cin;
+  const int nb = d->batch > 0 ? d->batch : 1;
+  p.HoWo = Ho * Wo; p.M = nb * Ho * Wo; p.K = d->KH * d->KW * d->Cin;
   p.ldo = d->ldo; p.ldr = d->ldr; p.ld2 = d->ld2;
   p.relu = d->relu; p.out_f32 = d->out_f32; p.res_f32 = d->res_f32;
   const bool is1x1 = d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0;

@@ -54,7 +54,7 @@ def _dev(*ts):
 
 
 def conv2d(x, w, bias, y, *, H, W, Cin, Cout, KH=1, KW=1, stride=1, pad=0, residual=None, y2=None, relu=False,
-           ldo=None, ldr=None, ld2=None, ws=None, ldx=0, act_begin=0) -> Op:
+           ldo=None, ldr=None, ld2=None, ws=None, ldx=0, act_begin=0, batch=1) -> Op:
     """y = act(conv(x, w) + bias (+ residual)); w is [Cout, KH, KW, Cin] bf16, x NHWC bf16.
     relu: False/0 none, True/1 ReLU, 2 exact GELU, 3 SiLU (channels >= act_begin); ldx: input row stride of a 1x1 problem."""
     _dev(x, w, bias, y, residual, y2)
@@ -67,9 +67,10 @@ def conv2d(x, w, bias, y, *, H, W, Cin, Cout, KH=1, KW=1, stride=1, pad=0, resid
     ldo = Cout if ldo is None else ldo
     ldr = Cout if ldr is None else ldr
     ld2 = Cout if ld2 is None else ld2
-    assert x.numel() >= (H * W - 1) * (ldx or Cin) + Cin and y.numel() >= (Ho * Wo - 1) * ldo + Cout
+    assert x.numel() >= (batch * H * W - 1) * (ldx or Cin) + Cin and y.numel() >= (batch * Ho * Wo - 1) * ldo + Cout
+    assert batch == 1 or not ldx
     d = ConvDesc(H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, ldo, ldr, ld2, int(relu), int(y.dtype == F32),
-                 int(residual is not None and residual.dtype == F32), ldx, act_begin)
+                 int(residual is not None and residual.dtype == F32), ldx, batch, act_begin)
     if ws is not None:   # split-K workspace: use it only if it is big enough for this problem
         _dev(ws)
         if ws.numel() * ws.element_size() < _lib.lib().rmem_conv_workspace_bytes(C.byref(d)):

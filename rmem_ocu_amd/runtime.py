@@ -29,6 +29,9 @@ from .pack import R50_BLOCKS, R50_STRIDES
 BF16, F32 = torch.bfloat16, torch.float32
 D_MODEL, HEADS, FFN = 256, 8, 1024
 MAX_CHUNKS = 32
+# key ranges of the one-frame (self / short-term) attention launches: 1 = every workgroup walks all keys and writes the
+# normalised output itself (no partials, no combine launch)
+PLAIN_CHUNKS = int(__import__('os').environ.get('RMEM_PLAIN_CHUNKS', 1))
 
 
 def temporal_slots(T: int, n_slots: int = 4) -> List[int]:
@@ -344,7 +347,7 @@ class ClipRuntime:
             o.append(ops.layernorm256(self.x, P[d + '.ln1.g'], P[d + '.ln1.b'], M=L, y=self.t1b))
             o.append(self._lin(self.t1b, d + '.self_qkv', self.qkv, L, C, 3 * C, residual=self.pos_qk[i]))
             o.append(self._attn(self.qkv, 3 * C, self.qkv.view(-1)[C:], self.qkv.view(-1)[2 * C:], 3 * C, self.att,
-                                nchunks=4, lk_single=L))
+                                nchunks=PLAIN_CHUNKS, lk_single=L))
             o.append(self._lin(self.att, d + '.self_proj', self.x, L, C, C, residual=self.x))
             # --- long/short-term attention (573-680)
             o.append(ops.layernorm256(self.x, P[d + '.ln2.g'], P[d + '.ln2.b'], M=L, y=self.curr_V[i]))
@@ -365,7 +368,7 @@ class ClipRuntime:
             o.append(self._lin(self.att, d + '.long_proj', self.x, L, C, C, residual=self.x))
             o.append(ops.layernorm256(sk, P[d + '.ln4.g'], P[d + '.ln4.b'], M=L, b=cq, y=self.k4))
             o.append(ops.layernorm256(sv, P[d + '.ln4.g'], P[d + '.ln4.b'], M=L, b=self.curr_V[i], y=self.v4))
-            o.append(self._attn(cq, C, self.k4, self.v4, C, self.att, nchunks=4, lk_single=L))
+            o.append(self._attn(cq, C, self.k4, self.v4, C, self.att, nchunks=PLAIN_CHUNKS, lk_single=L))
             o.append(self._lin(self.att, d + '.short_proj', self.x, L, C, C, residual=self.x, y2=self.tgt3[i]))
             if ref_mode:   # short-term memory of the reference frame (675-678)
                 o.append(self._lin(self.tgt3[i], d + '.linear_QMem', self.short_K[i], L, C, C))
