@@ -49,8 +49,9 @@ def gather_stats(frames: float, seconds: float, checksum: float, dist, rank: int
 class ClipSlot:
     """One clip in flight: an engine, its frames on the device, its output label buffer."""
 
-    def __init__(self, engine, out_hw, device):
+    def __init__(self, engine, out_hw, device, lookahead: int = 1):
         self.engine = engine
+        self.lookahead = lookahead          # > 1: the encoder runs this many frames ahead, one launch per layer for all of them
         self.labels: Optional[torch.Tensor] = None
         self.cur_label = torch.zeros(out_hw[0], out_hw[1], dtype=torch.uint8, device=device)   # fixed address (graph-captured)
         self.out_hw = out_hw
@@ -75,7 +76,13 @@ class ClipSlot:
     def step(self):
         """Propagate one frame and update the memory with the predicted labels (all asynchronous)."""
         i = self.cursor
-        self.engine.propagate_to_label(self.frames[i:i + 1], self.cur_label)
+        if self.lookahead > 1:
+            e = (i - 1) % self.lookahead
+            if e == 0:
+                self.engine.encode_ahead(self.frames[i:i + self.lookahead], self.lookahead)
+            self.engine.propagate_to_label(None, self.cur_label, enc_slot=e)
+        else:
+            self.engine.propagate_to_label(self.frames[i:i + 1], self.cur_label)
         self.engine.update_memory_from_label_u8(self.cur_label)
         # the clip's delivered masks stay on the device
         ops.copy_async(self.labels[i], self.cur_label, self.cur_label.numel())(self.engine.aot_engines[0].stream.cuda_stream)

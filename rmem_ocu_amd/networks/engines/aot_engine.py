@@ -219,25 +219,43 @@ class AOTEngine:
             out.record_stream(cur)
         return out
 
-    def propagate_to_label(self, img, label_u8):
+    def encode_ahead(self, imgs, frames: int = 4):
+        """Run the ResNet-50 encoder for the next ``imgs.shape[0] <= frames`` frames of the clip as one launch per layer
+        (frames do not depend on each other before the LSTT; the reference's loader has them ready,
+        dataloaders/eval_datasets.py:57-64).  propagate_to_label(..., enc_slot=e) then consumes frame e."""
+        rt = self.rt
+        be = rt.batch_encoder(frames)
+        n = int(imgs.shape[0])
+        if n > frames:
+            raise ValueError(f'encode_ahead: {n} frames for a look-ahead of {frames}')
+        with self._scope():
+            ops.copy_async(be.img_in, imgs, n * 3 * rt.H * rt.W * 4)(self._stream())
+            self._run(f'encB{frames}', be.prog())
+
+    def propagate_to_label(self, img, label_u8, enc_slot=None):
         """Fused fast path of one frame: propagate, then argmax labels (uint8 [Ho, Wo], caller's device
         buffer at a fixed address) straight from the 1/4-resolution logits -- the evaluator's
-        softmax -> argmax (managers/evaluator.py:430-441) without materialising [11, Ho, Wo] logits."""
+        softmax -> argmax (managers/evaluator.py:430-441) without materialising [11, Ho, Wo] logits.
+        enc_slot: the frame was encoded by encode_ahead (slot index); img is then unused."""
         self.frame_step += 1
         rt = self.rt
         self._resolve_pending()
         Ho, Wo = int(label_u8.shape[-2]), int(label_u8.shape[-1])
         keep = self.obj_nums[0] if self.obj_nums else self.max_obj_num
         with self._scope():
-            ops.copy_async(self.img_in, img, 3 * rt.H * rt.W * 4)(self._stream())
             T = len(rt.slots)
             self._T_at_propagate = T
-            key = f'propl{T}_{label_u8.data_ptr()}_{Ho}_{Wo}'
             pk = f'post_{label_u8.data_ptr()}_{Ho}_{Wo}'
             if pk not in rt._prog:
                 rt._prog[pk] = [ops.logits_post(rt.logits, ldl=16, nc=rt.nc, keep=keep, Hi=rt.H4, Wi=rt.W4, Ho=Ho, Wo=Wo,
                                                 align_corners=self.align_corners, label_u8=label_u8)]
-            self._run(key, rt.prog_encode(self.img_in) + rt.prog_lstt(False, T) + rt.prog_decode() + rt._prog[pk])
+            if enc_slot is None:
+                ops.copy_async(self.img_in, img, 3 * rt.H * rt.W * 4)(self._stream())
+                key = f'propl{T}_{label_u8.data_ptr()}_{Ho}_{Wo}'
+                self._run(key, rt.prog_encode(self.img_in) + rt.prog_lstt(False, T) + rt.prog_decode() + rt._prog[pk])
+            else:
+                key = f'propl{T}e{enc_slot}_{label_u8.data_ptr()}_{Ho}_{Wo}'
+                self._run(key, rt.prog_project(enc_slot) + rt.prog_lstt(False, T) + rt.prog_decode(enc_slot) + rt._prog[pk])
             self.pred_id_logits = rt.logits
 
     def decode_current_logits(self, output_size=None):
@@ -417,10 +435,15 @@ class AOTInferEngine:
             eng.update_short_term_memory(m)
 
     # -- fused fast path (single engine, <= 10 objects): labels in, labels out, everything on the engine's stream
-    def propagate_to_label(self, img, label_u8):
+    def propagate_to_label(self, img, label_u8, enc_slot=None):
         if len(self.aot_engines) != 1:
             raise NotImplementedError('the fused label path covers clips with <= 10 objects')
-        self.aot_engines[0].propagate_to_label(img, label_u8)
+        self.aot_engines[0].propagate_to_label(img, label_u8, enc_slot)
+
+    def encode_ahead(self, imgs, frames: int = 4):
+        if len(self.aot_engines) != 1:
+            raise NotImplementedError('encoder look-ahead covers clips with <= 10 objects')
+        self.aot_engines[0].encode_ahead(imgs, frames)
 
     def update_memory_from_label_u8(self, label_u8):
         self.aot_engines[0].update_memory_from_label_u8(label_u8)

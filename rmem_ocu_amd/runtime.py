@@ -313,10 +313,36 @@ class ClipRuntime:
         self._prog[key] = o
         return o
 
-    def _proj_op(self, cin: int):
+    def _proj_op(self, cin: int, enc3=None):
         """encoder_projector (models/aot.py:25-29): fp32 residual stream + bf16 copy into the decoder's concat buffer."""
-        return self._conv(self.enc3, self.P['proj.w'], self.P['proj.b'], self.x, H=self.L, W=1, Cin=cin, Cout=D_MODEL,
-                          y2=self.dec_in, ld2=4 * D_MODEL)
+        return self._conv(self.enc3 if enc3 is None else enc3, self.P['proj.w'], self.P['proj.b'], self.x, H=self.L, W=1, Cin=cin,
+                          Cout=D_MODEL, y2=self.dec_in, ld2=4 * D_MODEL)
+
+    # ------------------------------------------------------------------ encoder look-ahead
+    def batch_encoder(self, frames: int):
+        """The frames of a clip do not depend on each other before the LSTT, so the ResNet-50 encoder may run ``frames``
+        frames ahead as ONE launch per layer (rmem_ocu_amd.encoder_batch); slot e of its outputs then feeds
+        prog_project(e) / prog_decode(e) of the frame that is propagated."""
+        if self.swin:
+            raise ops.RmemError('encoder look-ahead is built for the ResNet-50 encoder')
+        if getattr(self, '_benc', None) is None or self._benc.B != frames:
+            from .encoder_batch import BatchEncoder
+            self._benc = BatchEncoder(self.P, (self.H, self.W), frames, self.dev)
+            self._prog = {k: v for k, v in self._prog.items() if not k.startswith(('project_', 'decode_'))}
+        return self._benc
+
+    def _enc(self, e):
+        """(enc1, enc2, enc3) of the frame in flight: the runtime's own encoder buffers, or slot e of the look-ahead batch."""
+        if e is None:
+            return self.enc1, self.enc2, self.enc3
+        o = self._benc.enc_out
+        return o[0][e], o[1][e], o[2][e]
+
+    def prog_project(self, e: int) -> list:
+        key = f'project_{e}'
+        if key not in self._prog:
+            self._prog[key] = [self._proj_op(self.enc_ch[2], enc3=self._enc(e)[2])]
+        return self._prog[key]
 
     def _attn(self, q, ldq, k, v, ldkv, out, **kw):
         return ops.mem_read_attn(q, k, v, out, self.attn_ws, Lq=self.L, heads=HEADS, ldq=ldq, ldkv=ldkv, ldo=D_MODEL, **kw)
@@ -386,23 +412,24 @@ class ClipRuntime:
         self._prog[key] = o
         return o
 
-    def prog_decode(self) -> list:
-        key = 'decode'
+    def prog_decode(self, e=None) -> list:
+        key = 'decode' if e is None else f'decode_{e}'
         if key in self._prog:
             return self._prog[key]
         P, o, L = self.P, [], self.L
+        enc1, enc2, enc3 = self._enc(e)
         M8, M4 = self.H8 * self.W8, self.H4 * self.W4
         gn = lambda x, name, y, M, C: ops.groupnorm(x, P[name + '.gn.g'], P[name + '.gn.b'], y, self.gn_ws, M=M, C=C, groups=8, act=1)  # noqa: E731
         o.append(self._conv(self.dec_in, P['dec.conv_in.w'], P['dec.conv_in.b'], self.d16a, H=L, W=1, Cin=self.dec_cin, Cout=256))
         o.append(gn(self.d16a, 'dec.conv_in', self.d16b, L, 256))
         c4, c8, c16 = self.enc_ch
-        o.append(self._conv(self.enc3, P['dec.adapter_16x.w'], P['dec.adapter_16x.b'], self.d16a, H=L, W=1, Cin=c16, Cout=256,
+        o.append(self._conv(enc3, P['dec.adapter_16x.w'], P['dec.adapter_16x.b'], self.d16a, H=L, W=1, Cin=c16, Cout=256,
                             residual=self.d16b))
         o.append(self._conv(self.d16a, P['dec.conv_16x.w'], P['dec.conv_16x.b'], self.d16b, H=self.H16, W=self.W16, Cin=256, Cout=256,
                             KH=3, KW=3, pad=1))
         o.append(gn(self.d16b, 'dec.conv_16x', self.d16a, L, 256))
         o.append(ops.bilinear(self.d16a, self.d8a, Hi=self.H16, Wi=self.W16, Ho=self.H8, Wo=self.W8, C=256, align_corners=self.align))
-        o.append(self._conv(self.enc2, P['dec.adapter_8x.w'], P['dec.adapter_8x.b'], self.d8b, H=M8, W=1, Cin=c8, Cout=256,
+        o.append(self._conv(enc2, P['dec.adapter_8x.w'], P['dec.adapter_8x.b'], self.d8b, H=M8, W=1, Cin=c8, Cout=256,
                             residual=self.d8a))
         d8c = self.d8a.view(-1)[: M8 * 128]
         o.append(self._conv(self.d8b, P['dec.conv_8x.w'], P['dec.conv_8x.b'], d8c, H=self.H8, W=self.W8, Cin=256, Cout=128,
@@ -410,7 +437,7 @@ class ClipRuntime:
         d8d = self.d8b.view(-1)[: M8 * 128]
         o.append(gn(d8c, 'dec.conv_8x', d8d, M8, 128))
         o.append(ops.bilinear(d8d, self.d4a, Hi=self.H8, Wi=self.W8, Ho=self.H4, Wo=self.W4, C=128, align_corners=self.align))
-        o.append(self._conv(self.enc1, P['dec.adapter_4x.w'], P['dec.adapter_4x.b'], self.d4b, H=M4, W=1, Cin=c4, Cout=128,
+        o.append(self._conv(enc1, P['dec.adapter_4x.w'], P['dec.adapter_4x.b'], self.d4b, H=M4, W=1, Cin=c4, Cout=128,
                             residual=self.d4a))
         o.append(self._conv(self.d4b, P['dec.conv_4x.w'], P['dec.conv_4x.b'], self.d4a, H=self.H4, W=self.W4, Cin=128, Cout=128,
                             KH=3, KW=3, pad=1))

@@ -61,9 +61,9 @@ class DeAOTRuntime(ClipRuntime):
         # probabilities [HW, slots * roundup(HW, 64)] bf16 + split-K slabs, sized for a full ring
         self.gp_ws = ops.gated_workspace(self.L, E2, self.S, self.L, GP_ROWS, self.dev)
 
-    def _proj_op(self, cin: int):
-        return self._conv(self.enc3, self.P['proj.w'], self.P['proj.b'], self.xc0, H=self.L, W=1, Cin=cin, Cout=D_MODEL,
-                          ldo=2 * D_MODEL)
+    def _proj_op(self, cin: int, enc3=None):
+        return self._conv(self.enc3 if enc3 is None else enc3, self.P['proj.w'], self.P['proj.b'], self.xc0, H=self.L, W=1, Cin=cin,
+                          Cout=D_MODEL, ldo=2 * D_MODEL)
 
     def prepare_pos(self, stream: int):
         """GatedPropagationModule never adds the spatial positional embedding (with_pos_embed is unused, 1084-1089)."""

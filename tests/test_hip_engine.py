@@ -285,3 +285,27 @@ def test_sequence_evaluator_flip_tta_and_metrics(tmp_path):
     im = Image.open(p)
     assert im.mode == 'P' and np.array_equal(np.array(im), got[0].cpu().numpy())
     assert im.getpalette()[:9] == [0, 0, 0, 128, 0, 0, 0, 128, 0]
+
+
+def test_encoder_lookahead_matches_per_frame_path():
+    """ClipSlot with the ResNet-50 encoder running 4 frames ahead (one launch per layer for 4 frames) delivers the same
+    masks as the frame-by-frame path (split-K plans differ with the GEMM's row count, so logits agree to bf16 noise)."""
+    from rmem_ocu_amd.clip_runner import ClipSlot
+    from rmem_ocu_amd.synth import make_clip
+    dev = torch.device('cuda', 0)
+    frames, mask = make_clip(7, 14, 161, 193, 3)
+    out = []
+    for la in (1, 4):
+        eng = _engine(1, 2, 2)
+        eng.set_async(use_graphs=True)
+        slot = ClipSlot(eng, (160, 192), dev, lookahead=la)
+        slot.start(frames.to(dev), mask.to(dev), 3)
+        while not slot.done:
+            slot.step()
+        eng.synchronize()
+        out.append((slot.labels[:14].cpu().numpy().copy(), list(eng.long_memories_indexes)))
+    (l1, t1), (l4, t4) = out
+    agree = (l1[1:] == l4[1:]).mean()
+    print('look-ahead 4 vs 1: label agreement', agree)
+    assert t1 == t4
+    assert agree > 0.995
