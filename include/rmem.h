@@ -63,6 +63,12 @@ size_t rmem_conv_workspace_bytes(const rmem_conv_desc* desc);
 int rmem_conv2d_nhwc(const rmem_conv_desc* desc, const void* x, const void* w, const float* bias,
                      const void* residual, void* y, void* y2, void* workspace, void* stream);
 
+/* n <= 4 GEMMs of IDENTICAL shape (desc: 1x1, stride 1) with different operands as one launch: the per-layer linears of one
+ * memory update (linear_QMem / linear_VMem / linear_V of layers/transformer.py:279-285 for the 3 LSTT layers) do not depend on
+ * each other, and at M = HW = 1674 a launch costs more than its arithmetic.  bias / residual may be NULL or hold NULLs. */
+int rmem_linear_grouped(const rmem_conv_desc* desc, int n, const void* const* x, const void* const* w,
+                        const float* const* bias, const void* const* residual, void* const* y, void* stream);
+
 /* ------------------------------------------------------------------ memory-read attention
  * out[q, 32h:32h+32] = softmax_k( (Q[q,h]+pe_cur[h]) . (K[k,h]+pe_mem[slot(k),h]) / sqrt(32) ) V[k,h]
  * over the keys named by the chunk table, plus (optionally) the per-memory-frame probability mass
@@ -114,6 +120,11 @@ int rmem_layernorm256(const void* a, int a_is_f32, int lda, const void* b, int b
                       void* y_bf16, int ldy, const float* pos, void* ypos_bf16, int ldyp,
                       float* y_f32, int ldyf, void* stream);
 
+/* Two LayerNorm(256) of summed bf16 inputs with ONE weight set as one launch: y0 = LN(a0 + b0), y1 = LN(a1 + b1), all
+ * [M][256] bf16 contiguous.  Replaces the two norm4 calls of layers/transformer.py:659-660. */
+int rmem_layernorm256_pair(const void* a0, const void* b0, void* y0, const void* a1, const void* b1, void* y1,
+                           const float* gamma, const float* beta, float eps, int M, void* stream);
+
 /* LayerNorm over C in {128, 256, 512, 1024} channels; bf16 and/or fp32 output.  Replaces the nn.LayerNorm call sites of the
  * Swin-B encoder (encoders/swin/swin_transformer.py:266, 318, 354, 538, 704). */
 int rmem_layernorm(const void* a, int a_is_f32, int lda, const float* gamma, const float* beta, float eps, int M, int C,
@@ -136,6 +147,8 @@ int rmem_window_attn(const void* qkv, const float* qkv_bias, const float* bias_m
 
 /* y = a + b (bf16).  Replaces the `curr_v + curr_id_emb` adds of layers/transformer.py:279-285. */
 int rmem_add_bf16(const void* a, const void* b, void* y, long long n, void* stream);
+/* n <= 8 such adds of equal length as one launch (the per-layer adds of one memory update are independent). */
+int rmem_add_bf16_grouped(int n, const void* const* a, const void* const* b, void* const* y, long long count, void* stream);
 
 /* GroupNorm on NHWC bf16 with fused activation (0 none, 1 ReLU, 2 exact GELU).
  * Replaces: layers/basic.py:31-32 (GN(32)+GELU of the conv-FFN) and layers/basic.py:69-70 +

@@ -308,7 +308,7 @@ typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
 template <bool IS1X1, bool SPLITK>
-__global__ __launch_bounds__(256) void k_conv_gemm_dma(ConvParams p) {
+__device__ __forceinline__ void conv_gemm_dma_body(const ConvParams& p, const int zslice) {
   constexpr int BM = 64, BN = 64, BK = 64, ST = 3, TM = 2, TN = 2;
   constexpr int CP = BN + 4;
   constexpr int STAGE_BYTES = (BM + BN) * BK * 2;
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(256) void k_conv_gemm_dma(ConvParams p) {
   const int wm = wave >> 1, wn = wave & 1;
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
   const int nk_total = (p.K + BK - 1) / BK;
-  const int kt0 = SPLITK ? blockIdx.z * p.steps_per_split : 0;
+  const int kt0 = SPLITK ? zslice * p.steps_per_split : 0;
   const int kt1 = SPLITK ? min(nk_total, kt0 + p.steps_per_split) : nk_total;
 
   // this lane's two (row, chunk) pieces of the A tile and of the B tile: instruction i covers rows 16*wave + 8*i .. +7
@@ -440,7 +440,7 @@ __global__ __launch_bounds__(256) void k_conv_gemm_dma(ConvParams p) {
       const f32x4 c0 = *reinterpret_cast<const f32x4*>(c), c1 = *reinterpret_cast<const f32x4*>(c + 4);
       float v[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
       if (SPLITK) {
-        float* s = p.slabs + ((long)blockIdx.z * p.M + m) * p.Cout + n;
+        float* s = p.slabs + ((long)zslice * p.M + m) * p.Cout + n;
         *reinterpret_cast<f32x4*>(s) = c0;
         *reinterpret_cast<f32x4*>(s + 4) = c1;
       } else if (p.vec_ok && n + 8 <= p.Cout) {
@@ -451,6 +451,25 @@ __global__ __launch_bounds__(256) void k_conv_gemm_dma(ConvParams p) {
     }
     __syncthreads();
   }
+}
+
+
+template <bool IS1X1, bool SPLITK>
+__global__ __launch_bounds__(256) void k_conv_gemm_dma(ConvParams p) {
+  conv_gemm_dma_body<IS1X1, SPLITK>(p, blockIdx.z);
+}
+
+// up to 4 GEMMs of identical shape (different operands) as ONE launch: blockIdx.z selects the operand set.  The per-layer
+// memory-update linears of a frame are independent of each other (layers/transformer.py:269-322), and at M = 1674 a launch
+// costs more than its arithmetic.
+struct GroupPtrs {
+  const bf16* x[4]; const bf16* w[4]; const float* bias[4]; const void* res[4]; void* y[4]; bf16* y2[4];
+};
+__global__ __launch_bounds__(256) void k_gemm_dma_grouped(ConvParams p, GroupPtrs g) {
+  const int z = blockIdx.z;
+  ConvParams q = p;
+  q.x = g.x[z]; q.w = g.w[z]; q.bias = g.bias[z]; q.res = g.res[z]; q.y = g.y[z]; q.y2 = g.y2[z];
+  conv_gemm_dma_body<true, false>(q, 0);
 }
 
 // sum the split-K slabs in slice order and apply the fused epilogue; thread = 8 channels of one row
@@ -527,8 +546,8 @@ extern "C" size_t rmem_conv_workspace_bytes(const rmem_conv_desc* d) {
   return s > 1 ? (size_t)s * M * d->Cout * sizeof(float) : 0;
 }
 
-extern "C" int rmem_conv2d_nhwc(const rmem_conv_desc* d, const void* x, const void* w, const float* bias,
-                                const void* residual, void* y, void* y2, void* workspace, void* stream) {
+static int conv_setup(const rmem_conv_desc* d, const void* x, const void* w, const float* bias, const void* residual, void* y,
+                      void* y2, ConvParams& p, bool& is1x1) {
   RMEM_REQUIRE(d && x && w && y, "rmem_conv2d_nhwc: null argument");
   RMEM_REQUIRE(d->Cin > 0 && d->Cin % 8 == 0, "rmem_conv2d_nhwc: Cin must be a positive multiple of 8");
   RMEM_REQUIRE(d->KH > 0 && d->KW > 0 && d->stride > 0 && d->pad >= 0, "rmem_conv2d_nhwc: bad kernel geometry");
@@ -539,7 +558,6 @@ extern "C" int rmem_conv2d_nhwc(const rmem_conv_desc* d, const void* x, const vo
   RMEM_REQUIRE(!residual || d->ldr >= d->Cout, "rmem_conv2d_nhwc: ldr < Cout");
   RMEM_REQUIRE(!y2 || d->ld2 >= d->Cout, "rmem_conv2d_nhwc: ld2 < Cout");
   RMEM_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)w % 16) == 0, "rmem_conv2d_nhwc: x/w must be 16-byte aligned");
-  ConvParams p;
   p.x = (const bf16*)x; p.w = (const bf16*)w; p.bias = bias; p.res = residual; p.y = y; p.y2 = (bf16*)y2;
   p.slabs = nullptr;
   p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Ho = Ho; p.Wo = Wo; p.Cout = d->Cout;
@@ -548,7 +566,7 @@ extern "C" int rmem_conv2d_nhwc(const rmem_conv_desc* d, const void* x, const vo
   p.HoWo = Ho * Wo; p.M = nb * Ho * Wo; p.K = d->KH * d->KW * d->Cin;
   p.ldo = d->ldo; p.ldr = d->ldr; p.ld2 = d->ld2;
   p.relu = d->relu; p.out_f32 = d->out_f32; p.res_f32 = d->res_f32;
-  const bool is1x1 = d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0;
+  is1x1 = d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0;
   RMEM_REQUIRE(d->relu >= 0 && d->relu <= 3, "rmem_conv2d_nhwc: relu must be 0 (none), 1 (ReLU), 2 (GELU) or 3 (SiLU)");
   RMEM_REQUIRE(d->act_begin >= 0 && d->act_begin % 8 == 0, "rmem_conv2d_nhwc: act_begin must be a non-negative multiple of 8");
   RMEM_REQUIRE(d->ldx == 0 || (is1x1 && d->ldx >= d->Cin && d->ldx % 8 == 0),
@@ -559,6 +577,14 @@ extern "C" int rmem_conv2d_nhwc(const rmem_conv_desc* d, const void* x, const vo
   auto al = [](const void* q, int a) { return q == nullptr || ((uintptr_t)q % a) == 0; };
   p.vec_ok = p.Cout % 8 == 0 && p.ldo % 8 == 0 && al(y, 16) && al(bias, 16) &&
              (!residual || (p.ldr % 8 == 0 && al(residual, 16))) && (!y2 || (p.ld2 % 8 == 0 && al(y2, 16)));
+  return 0;
+}
+
+extern "C" int rmem_conv2d_nhwc(const rmem_conv_desc* d, const void* x, const void* w, const float* bias,
+                                const void* residual, void* y, void* y2, void* workspace, void* stream) {
+  ConvParams p;
+  bool is1x1 = false;
+  if (conv_setup(d, x, w, bias, residual, y, y2, p, is1x1)) return -1;
   hipStream_t s = (hipStream_t)stream;
   const long t128 = (long)((p.M + 127) / 128) * ((p.Cout + 127) / 128);
   static const int force_tile = getenv("RMEM_GEMM_TILE") ? atoi(getenv("RMEM_GEMM_TILE")) : -1;   // kernel experiments only
@@ -579,4 +605,23 @@ extern "C" int rmem_conv2d_nhwc(const rmem_conv_desc* d, const void* x, const vo
     launch<64, 64, 4>(p, is1x1, splits, s);
   }
   return rmem_check_launch("rmem_conv2d_nhwc");
+}
+
+extern "C" int rmem_linear_grouped(const rmem_conv_desc* d, int n, const void* const* x, const void* const* w,
+                                   const float* const* bias, const void* const* residual, void* const* y, void* stream) {
+  RMEM_REQUIRE(d && x && w && y && n >= 1 && n <= 4, "rmem_linear_grouped: 1..4 problems");
+  ConvParams p;
+  bool is1x1 = false;
+  GroupPtrs g = {};
+  for (int i = 0; i < n; ++i) {
+    ConvParams pi;
+    if (conv_setup(d, x[i], w[i], bias ? bias[i] : nullptr, residual ? residual[i] : nullptr, y[i], nullptr, pi, is1x1)) return -1;
+    RMEM_REQUIRE(is1x1, "rmem_linear_grouped: 1x1 stride-1 problems only");
+    RMEM_REQUIRE(i == 0 || pi.vec_ok == p.vec_ok, "rmem_linear_grouped: operands of all problems must have the same alignment class");
+    if (i == 0) p = pi;
+    g.x[i] = pi.x; g.w[i] = pi.w; g.bias[i] = pi.bias; g.res[i] = pi.res; g.y[i] = pi.y; g.y2[i] = nullptr;
+  }
+  dim3 grid((p.M + 63) / 64, (p.Cout + 63) / 64, n);
+  hipLaunchKernelGGL(k_gemm_dma_grouped, grid, dim3(256), 0, (hipStream_t)stream, p, g);
+  return rmem_check_launch("rmem_linear_grouped");
 }

@@ -26,7 +26,7 @@ __device__ __forceinline__ f32x4 load4(const void* base, int is_f32, long off) {
 }
 
 // one wave per row of 256 channels, 4 channels per lane
-__global__ __launch_bounds__(256) void k_layernorm256(LnParams p) {
+__device__ __forceinline__ void layernorm256_body(const LnParams& p) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= p.M) return;
@@ -51,6 +51,13 @@ __global__ __launch_bounds__(256) void k_layernorm256(LnParams p) {
     *reinterpret_cast<bf16x4*>(p.ypos + (long)row * p.ldyp + c0) = bf16x4{(bf16)q[0], (bf16)q[1], (bf16)q[2], (bf16)q[3]};
   }
 }
+
+__global__ __launch_bounds__(256) void k_layernorm256(LnParams p) { layernorm256_body(p); }
+
+// two independent LayerNorms of equal row count as one launch (blockIdx.y selects): norm4 of the key and of the value sum
+// (layers/transformer.py:659-660)
+struct LnPair { LnParams p[2]; };
+__global__ __launch_bounds__(256) void k_layernorm256_pair(LnPair pp) { layernorm256_body(pp.p[blockIdx.y]); }
 
 // generic channel count (Swin-B stages: 128 / 256 / 512 / 1024): one wave per row, C / 64 consecutive channels per lane
 template <int C>
@@ -119,6 +126,21 @@ __global__ __launch_bounds__(256) void k_patch_merge_ln(const float* x, int H, i
 
 // ------------------------------------------------------------------ add
 __global__ __launch_bounds__(256) void k_add_bf16(const bf16* a, const bf16* b, bf16* y, long n8) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+    const bf16x8 x = reinterpret_cast<const bf16x8*>(a)[i];
+    const bf16x8 z = reinterpret_cast<const bf16x8*>(b)[i];
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (bf16)((float)x[j] + (float)z[j]);
+    reinterpret_cast<bf16x8*>(y)[i] = o;
+  }
+}
+
+struct AddGroup { const bf16* a[8]; const bf16* b[8]; bf16* y[8]; };
+__global__ __launch_bounds__(256) void k_add_bf16_grouped(AddGroup g, long n8) {
+  const bf16* a = g.a[blockIdx.y];
+  const bf16* b = g.b[blockIdx.y];
+  bf16* y = g.y[blockIdx.y];
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
     const bf16x8 x = reinterpret_cast<const bf16x8*>(a)[i];
     const bf16x8 z = reinterpret_cast<const bf16x8*>(b)[i];
@@ -255,6 +277,16 @@ extern "C" int rmem_layernorm256(const void* a, int a_is_f32, int lda, const voi
   return rmem_check_launch("rmem_layernorm256");
 }
 
+extern "C" int rmem_layernorm256_pair(const void* a0, const void* b0, void* y0, const void* a1, const void* b1, void* y1,
+                                      const float* gamma, const float* beta, float eps, int M, void* stream) {
+  RMEM_REQUIRE(a0 && b0 && y0 && a1 && b1 && y1 && gamma && beta && M > 0, "rmem_layernorm256_pair: null argument");
+  LnPair pp;
+  pp.p[0] = LnParams{a0, 0, 256, b0, 0, 256, gamma, beta, eps, M, (bf16*)y0, 256, nullptr, nullptr, 0, nullptr, 0};
+  pp.p[1] = LnParams{a1, 0, 256, b1, 0, 256, gamma, beta, eps, M, (bf16*)y1, 256, nullptr, nullptr, 0, nullptr, 0};
+  hipLaunchKernelGGL(k_layernorm256_pair, dim3((M + 3) / 4, 2), dim3(256), 0, (hipStream_t)stream, pp);
+  return rmem_check_launch("rmem_layernorm256_pair");
+}
+
 extern "C" int rmem_layernorm(const void* a, int a_is_f32, int lda, const float* gamma, const float* beta, float eps, int M, int C,
                               void* y_bf16, int ldy, float* y_f32, int ldyf, void* stream) {
   RMEM_REQUIRE(a && gamma && beta && M > 0 && (y_bf16 || y_f32), "rmem_layernorm: bad argument");
@@ -287,6 +319,19 @@ extern "C" int rmem_add_bf16(const void* a, const void* b, void* y, long long n,
   const int blocks = (int)min((long)2048, (n8 + 255) / 256);
   hipLaunchKernelGGL(k_add_bf16, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16*)a, (const bf16*)b, (bf16*)y, n8);
   return rmem_check_launch("rmem_add_bf16");
+}
+
+extern "C" int rmem_add_bf16_grouped(int n, const void* const* a, const void* const* b, void* const* y, long long count, void* stream) {
+  RMEM_REQUIRE(n >= 1 && n <= 8 && a && b && y && count > 0 && count % 8 == 0, "rmem_add_bf16_grouped: 1..8 problems, count a positive multiple of 8");
+  AddGroup g = {};
+  for (int i = 0; i < n; ++i) {
+    RMEM_REQUIRE(a[i] && b[i] && y[i], "rmem_add_bf16_grouped: null operand");
+    g.a[i] = (const bf16*)a[i]; g.b[i] = (const bf16*)b[i]; g.y[i] = (bf16*)y[i];
+  }
+  const long n8 = count / 8;
+  const int blocks = (int)min((long)1024, (n8 + 255) / 256);
+  hipLaunchKernelGGL(k_add_bf16_grouped, dim3(blocks, n), dim3(256), 0, (hipStream_t)stream, g, n8);
+  return rmem_check_launch("rmem_add_bf16_grouped");
 }
 
 extern "C" size_t rmem_groupnorm_workspace_bytes(int groups) { return (size_t)groups * GN_SPLITS * 2 * sizeof(float); }

@@ -86,6 +86,42 @@ def linear(x, w, bias, y, *, M, K, N, residual=None, y2=None, relu=False, ldo=No
                   ldx=ldx, act_begin=act_begin)
 
 
+def _ptr_array(ts):
+    return (C.c_void_p * len(ts))(*[_ptr(t) for t in ts])
+
+
+def linear_grouped(xs, ws, biases, ys, *, M, K, N, residuals=None, relu=False) -> Op:
+    """len(xs) <= 4 GEMMs y_i[M, N] = x_i[M, K] @ w_i[N, K]^T + bias_i (+ residual_i) of identical shape as ONE launch."""
+    n = len(xs)
+    assert 1 <= n <= 4 and len(ws) == n and len(ys) == n and (biases is None or len(biases) == n)
+    _dev(*xs, *ws, *ys, *(biases or ()), *(residuals or ()))
+    for x, w, y in zip(xs, ws, ys):
+        assert x.dtype == BF16 and w.dtype == BF16 and w.numel() == N * K and x.numel() >= M * K and y.numel() >= M * N
+    assert len({y.dtype for y in ys}) == 1 and (residuals is None or len({r.dtype for r in residuals}) == 1)
+    d = ConvDesc(M, 1, K, M, 1, N, 1, 1, 1, 0, N, N, N, int(relu), int(ys[0].dtype == F32),
+                 int(residuals is not None and residuals[0].dtype == F32), 0, 1, 0)
+    arrs = (_ptr_array(xs), _ptr_array(ws), _ptr_array(biases) if biases is not None else None,
+            _ptr_array(residuals) if residuals is not None else None, _ptr_array(ys))
+    args = (C.byref(d), n, arrs[0], arrs[1], arrs[2], arrs[3], arrs[4])
+    return Op(_lib.lib().rmem_linear_grouped, args, 'rmem_linear_grouped', (d, arrs, xs, ws, biases, residuals, ys))
+
+
+def add_bf16_grouped(as_, bs, ys, n: int) -> Op:
+    """len(as_) <= 8 adds y_i = a_i + b_i over n elements each as one launch."""
+    _dev(*as_, *bs, *ys)
+    assert len(as_) == len(bs) == len(ys) <= 8 and all(t.dtype == BF16 for t in (*as_, *bs, *ys))
+    arrs = (_ptr_array(as_), _ptr_array(bs), _ptr_array(ys))
+    return Op(_lib.lib().rmem_add_bf16_grouped, (len(as_), arrs[0], arrs[1], arrs[2], n), 'rmem_add_bf16_grouped', (arrs, as_, bs, ys))
+
+
+def layernorm256_pair(a0, b0, y0, a1, b1, y1, gamma, beta, *, M, eps=1e-5) -> Op:
+    """y0 = LN(a0 + b0), y1 = LN(a1 + b1) with one weight set, [M, 256] bf16 contiguous, one launch."""
+    _dev(a0, b0, y0, a1, b1, y1, gamma, beta)
+    assert all(t.dtype == BF16 and t.numel() >= M * 256 for t in (a0, b0, y0, a1, b1, y1)) and gamma.dtype == F32
+    args = (_ptr(a0), _ptr(b0), _ptr(y0), _ptr(a1), _ptr(b1), _ptr(y1), _ptr(gamma), _ptr(beta), eps, M)
+    return Op(_lib.lib().rmem_layernorm256_pair, args, 'rmem_layernorm256_pair', (a0, b0, y0, a1, b1, y1, gamma, beta))
+
+
 def attn_workspace(Lq: int, heads: int, nchunks: int, device) -> torch.Tensor:
     n = _lib.lib().rmem_attn_workspace_bytes(Lq, heads, nchunks)
     return torch.empty(n // 4, dtype=F32, device=device)

@@ -392,8 +392,7 @@ class ClipRuntime:
                                 nchunks=nchunks, lk_single=(1 if ref_mode else T) * L, pe_cur=P['pe_cur'], pe_mem=P['pe_mem'],
                                 mass=self.mass if (i == 0 and not ref_mode) else None, T=T))
             o.append(self._lin(self.att, d + '.long_proj', self.x, L, C, C, residual=self.x))
-            o.append(ops.layernorm256(sk, P[d + '.ln4.g'], P[d + '.ln4.b'], M=L, b=cq, y=self.k4))
-            o.append(ops.layernorm256(sv, P[d + '.ln4.g'], P[d + '.ln4.b'], M=L, b=self.curr_V[i], y=self.v4))
+            o.append(ops.layernorm256_pair(sk, cq, self.k4, sv, self.curr_V[i], self.v4, P[d + '.ln4.g'], P[d + '.ln4.b'], M=L))
             o.append(self._attn(cq, C, self.k4, self.v4, C, self.att, nchunks=PLAIN_CHUNKS, lk_single=L))
             o.append(self._lin(self.att, d + '.short_proj', self.x, L, C, C, residual=self.x, y2=self.tgt3[i]))
             if ref_mode:   # short-term memory of the reference frame (675-678)
@@ -466,14 +465,24 @@ class ClipRuntime:
         if key in self._prog:
             return self._prog[key]
         L, C, o = self.L, D_MODEL, []
-        for i in range(self.NL):
-            d = f'l{i}'
-            o.append(self._lin(self.tgt3[i], d + '.linear_QMem', self.short_K[i], L, C, C))
-            o.append(ops.add_bf16(self.tgt3[i], self.id_emb, self.tmp, L * C))
-            o.append(self._lin(self.tmp, d + '.linear_VMem', self.short_V[i], L, C, C))
-            if append_slot is not None:
-                o.append(ops.add_bf16(self.curr_V[i], self.id_emb, self.tmp, L * C))
-                o.append(self._lin(self.tmp, d + '.linear_V', self.bank_V[i][append_slot], L, C, C))
+        P, NL = self.P, self.NL
+        if NL > 4:
+            raise ops.RmemError('memory update: grouped launches cover up to 4 LSTT layers')
+        if not hasattr(self, 'tmpA'):
+            self.tmpA = [torch.empty(L, C, dtype=BF16, device=self.dev) for _ in range(NL)]
+            self.tmpB = [torch.empty(L, C, dtype=BF16, device=self.dev) for _ in range(NL)]
+        app = append_slot is not None
+        # the three layers' updates are independent: one launch per kind of op for all layers
+        o.append(ops.add_bf16_grouped(self.tgt3 + (self.curr_V if app else []), [self.id_emb] * (NL * (2 if app else 1)),
+                                      self.tmpA + (self.tmpB if app else []), L * C))
+        w = lambda nm: [P[f'l{i}.{nm}.w'] for i in range(NL)]   # noqa: E731
+        b = lambda nm: [P[f'l{i}.{nm}.b'] for i in range(NL)]   # noqa: E731
+        o.append(ops.linear_grouped(self.tgt3, w('linear_QMem'), b('linear_QMem'), self.short_K, M=L, K=C, N=C))
+        o.append(ops.linear_grouped(self.tmpA, w('linear_VMem'), b('linear_VMem'), self.short_V, M=L, K=C, N=C))
+        if app:
+            o.append(ops.linear_grouped(self.tmpB, w('linear_V'), b('linear_V'), [self.bank_V[i][append_slot] for i in range(NL)],
+                                        M=L, K=C, N=C))
+            for i in range(NL):
                 o.append(ops.copy_async(self.bank_K[i][append_slot], self.curr_Q[i], L * C * 2))
         self._prog[key] = o
         return o
