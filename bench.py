@@ -94,7 +94,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=790)
     ap.add_argument('--warmup', type=int, default=79)
-    ap.add_argument('--clips-in-flight', type=int, default=int(os.environ.get('RMEM_CLIPS_IN_FLIGHT', 16)))
+    ap.add_argument('--clips-in-flight', type=int, default=int(os.environ.get('RMEM_CLIPS_IN_FLIGHT', 24)))
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--workload', default='davis17_480p_r50_N8', choices=sorted(WORKLOADS))
     ap.add_argument('--no-graphs', action='store_true')

@@ -407,3 +407,53 @@ def test_frame_ingest(dev, src, dst):
     assert_close(chw, ref, 2e-5, f'ingest {src}->{dst}')
     assert_close(n8[:, :3], rb(ref).permute(1, 2, 0).reshape(-1, 3), 1e-2, 'ingest nhwc8')
     assert n8[:, 3:].abs().max().item() == 0
+
+
+def test_conv2d_batch_of_images(dev):
+    """batch > 1: rows are [image][ho][wo]; every image must equal the single-image launch (3x3 stride 2 with padding, so a
+    row index that ignored the image would bleed across image borders)."""
+    from rmem_ocu_amd import ops
+    B, H, W, Cin, Cout = 3, 23, 31, 64, 128
+    x = rb(seeded(11, (B, Cin, H, W)))
+    w = rb(seeded(12, (Cout, Cin, 3, 3), 1.0 / (Cin * 9) ** 0.5))
+    b = seeded(13, (Cout,), 0.1)
+    ref = F.relu(F.conv2d(x, w, b, stride=2, padding=1))
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    xd = x.permute(0, 2, 3, 1).reshape(B, H * W, Cin).contiguous().to(BF16).to(dev)
+    y = torch.zeros(B, Ho * Wo, Cout, dtype=BF16, device=dev)
+    ops.run(ops.conv2d(xd, pack_w(w).to(dev), b.to(dev), y, H=H, W=W, Cin=Cin, Cout=Cout, KH=3, KW=3, stride=2, pad=1, relu=True, batch=B))
+    y1 = torch.zeros(Ho * Wo, Cout, dtype=BF16, device=dev)
+    for i in range(B):
+        ops.run(ops.conv2d(xd[i], pack_w(w).to(dev), b.to(dev), y1, H=H, W=W, Cin=Cin, Cout=Cout, KH=3, KW=3, stride=2, pad=1, relu=True))
+        torch.cuda.synchronize()
+        assert torch.equal(y[i], y1), f'image {i} differs from the single-image launch'
+    assert_close(y, ref.permute(0, 2, 3, 1).reshape(B, Ho * Wo, Cout), 1e-2, 'batched conv')
+
+
+def test_grouped_launches(dev):
+    """rmem_linear_grouped / rmem_add_bf16_grouped / rmem_layernorm256_pair are bit-identical to the single launches."""
+    from rmem_ocu_amd import ops
+    M, K, N, n = 1674, 256, 256, 3
+    xs = [rb(seeded(20 + i, (M, K))).to(BF16).to(dev) for i in range(n)]
+    ws = [rb(seeded(30 + i, (N, K), 1 / 16.0)).to(BF16).to(dev) for i in range(n)]
+    bs = [seeded(40 + i, (N,), 0.1).to(dev) for i in range(n)]
+    ys = [torch.zeros(M, N, dtype=BF16, device=dev) for _ in range(n)]
+    y1 = [torch.zeros(M, N, dtype=BF16, device=dev) for _ in range(n)]
+    ops.run(ops.linear_grouped(xs, ws, bs, ys, M=M, K=K, N=N))
+    ops.run([ops.linear(xs[i], ws[i], bs[i], y1[i], M=M, K=K, N=N) for i in range(n)])
+    torch.cuda.synchronize()
+    for i in range(n):
+        assert torch.equal(ys[i], y1[i])
+        assert_close(ys[i], xs[i].float() @ ws[i].float().t() + bs[i], 1e-2, 'grouped linear')
+    a = [rb(seeded(50 + i, (M, 256))).to(BF16).to(dev) for i in range(6)]
+    out = [torch.zeros(M, 256, dtype=BF16, device=dev) for _ in range(6)]
+    ops.run(ops.add_bf16_grouped(a, [a[0]] * 6, out, M * 256))
+    torch.cuda.synchronize()
+    for i in range(6):
+        assert torch.equal(out[i], (a[i].float() + a[0].float()).to(BF16))
+    g, be = (1 + seeded(60, (256,), 0.1)).to(dev), seeded(61, (256,), 0.1).to(dev)
+    p0, p1, s0, s1 = (torch.zeros(M, 256, dtype=BF16, device=dev) for _ in range(4))
+    ops.run(ops.layernorm256_pair(a[0], a[1], p0, a[2], a[3], p1, g, be, M=M))
+    ops.run([ops.layernorm256(a[0], g, be, M=M, b=a[1], y=s0), ops.layernorm256(a[2], g, be, M=M, b=a[3], y=s1)])
+    torch.cuda.synchronize()
+    assert torch.equal(p0, s0) and torch.equal(p1, s1)
