@@ -213,7 +213,8 @@ class AOTEngine:
             self.img_in.copy_(img.reshape(3, rt.H, rt.W), non_blocking=True)
             T = len(rt.slots)
             self._T_at_propagate = T
-            self._run(f'prop{T}', rt.prog_encode(self.img_in) + rt.prog_lstt(False, T) + rt.prog_decode())
+            wm = self._mass_needed(T)
+            self._run(f'prop{T}{int(wm)}', rt.prog_encode(self.img_in) + rt.prog_lstt(False, T, want_mass=wm) + rt.prog_decode())
             self.pred_id_logits = rt.logits
             out = self._logits_out(output_size)
             out.record_stream(cur)
@@ -249,14 +250,25 @@ class AOTEngine:
             if pk not in rt._prog:
                 rt._prog[pk] = [ops.logits_post(rt.logits, ldl=16, nc=rt.nc, keep=keep, Hi=rt.H4, Wi=rt.W4, Ho=Ho, Wo=Wo,
                                                 align_corners=self.align_corners, label_u8=label_u8)]
+            wm = self._mass_needed(T)
             if enc_slot is None:
                 ops.copy_async(self.img_in, img, 3 * rt.H * rt.W * 4)(self._stream())
-                key = f'propl{T}_{label_u8.data_ptr()}_{Ho}_{Wo}'
-                self._run(key, rt.prog_encode(self.img_in) + rt.prog_lstt(False, T) + rt.prog_decode() + rt._prog[pk])
+                key = f'propl{T}{int(wm)}_{label_u8.data_ptr()}_{Ho}_{Wo}'
+                self._run(key, rt.prog_encode(self.img_in) + rt.prog_lstt(False, T, want_mass=wm) + rt.prog_decode() + rt._prog[pk])
             else:
-                key = f'propl{T}e{enc_slot}_{label_u8.data_ptr()}_{Ho}_{Wo}'
-                self._run(key, rt.prog_project(enc_slot) + rt.prog_lstt(False, T) + rt.prog_decode(enc_slot) + rt._prog[pk])
+                key = f'propl{T}{int(wm)}e{enc_slot}_{label_u8.data_ptr()}_{Ho}_{Wo}'
+                self._run(key, rt.prog_project(enc_slot) + rt.prog_lstt(False, T, want_mass=wm) + rt.prog_decode(enc_slot) + rt._prog[pk])
             self.pred_id_logits = rt.logits
+
+    def _mass_needed(self, T: int) -> bool:
+        """The per-memory-frame attention mass of layer 0 (layers/transformer.py:636-643) is only read by the eviction policy,
+        i.e. when the update that follows this propagation appends to the bank (aot_engine.py:338-343) and the bank then
+        overflows (or, DeAOT, on every append): both are known now, so the other frames skip the reduction."""
+        will_append = (not getattr(self.cfg, 'NO_LONG_MEMORY', False)) and \
+            (self.frame_step - self.last_mem_step >= self.long_term_mem_gap)
+        need = will_append and (self.policy_every_update or T + 1 > self.cfg.FORMER_MEM_LEN + self.cfg.LATTER_MEM_LEN)
+        self._mass_valid = need
+        return need
 
     def decode_current_logits(self, output_size=None):
         """Logits with unused ids masked (aot_engine.py:450-453), resized to output_size (457-463)."""
@@ -323,6 +335,9 @@ class AOTEngine:
         n_keep = self.cfg.FORMER_MEM_LEN + self.cfg.LATTER_MEM_LEN
         overflow = len(rt.slots) > n_keep
         if overflow or self.policy_every_update:
+            if not getattr(self, '_mass_valid', False):
+                raise RuntimeError('long_term_mem_gap / memory length changed between match_propogate_one_frame and update_memory: '
+                                   'the attention mass of this frame was not recorded')
             Tp = self._T_at_propagate
             keep = self.obj_nums[0] if self.obj_nums else self.max_obj_num
             ops.run([ops.evict_scores(rt.logits, rt.mass, rt.scores, ldl=16, nc=rt.nc, keep=keep, Hi=rt.H4, Wi=rt.W4,

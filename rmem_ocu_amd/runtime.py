@@ -358,10 +358,10 @@ class ClipRuntime:
         self._keep_posb = posb
         self._pos_ready = True
 
-    def prog_lstt(self, ref_mode: bool, T: int, ref_slot: int = 0) -> list:
+    def prog_lstt(self, ref_mode: bool, T: int, ref_slot: int = 0, want_mass: bool = True) -> list:
         """The 3-layer LSTT on self.x.  ref_mode: reference frame (id_emb already in self.id_emb,
         K/V go straight into bank slot ``ref_slot``); else propagate against a bank of T frames."""
-        key = f'lstt_ref{ref_slot}' if ref_mode else f'lstt_prop{T}'
+        key = f'lstt_ref{ref_slot}' if ref_mode else f'lstt_prop{T}{"m" if want_mass else ""}'
         if key in self._prog:
             return self._prog[key]
         P, L, o = self.P, self.L, []
@@ -390,7 +390,7 @@ class ClipRuntime:
                 sk, sv = self.short_K[i], self.short_V[i]
             o.append(self._attn(cq, C, self.bank_K[i], self.bank_V[i], C, self.att, slot_stride=L * C, chunks=self.chunks,
                                 nchunks=nchunks, lk_single=(1 if ref_mode else T) * L, pe_cur=P['pe_cur'], pe_mem=P['pe_mem'],
-                                mass=self.mass if (i == 0 and not ref_mode) else None, T=T))
+                                mass=self.mass if (i == 0 and not ref_mode and want_mass) else None, T=T))
             o.append(self._lin(self.att, d + '.long_proj', self.x, L, C, C, residual=self.x))
             o.append(ops.layernorm256_pair(sk, cq, self.k4, sv, self.curr_V[i], self.v4, P[d + '.ln4.g'], P[d + '.ln4.b'], M=L))
             o.append(self._attn(cq, C, self.k4, self.v4, C, self.att, nchunks=PLAIN_CHUNKS, lk_single=L))

@@ -91,8 +91,8 @@ class DeAOTRuntime(ClipRuntime):
         return [ops.dwconv5x5(self.g1, self.P[name + '_dw.w'], self.g2, H=self.H16, W=self.W16, C=E2),
                 self._lin(self.g2, name + '_proj', self.xc, self.L, E2, 2 * D_MODEL, residual=residual, **kw)]
 
-    def prog_lstt(self, ref_mode: bool, T: int, ref_slot: int = 0) -> list:
-        key = f'lstt_ref{ref_slot}' if ref_mode else f'lstt_prop{T}'
+    def prog_lstt(self, ref_mode: bool, T: int, ref_slot: int = 0, want_mass: bool = True) -> list:
+        key = f'lstt_ref{ref_slot}' if ref_mode else f'lstt_prop{T}{"m" if want_mass else ""}'
         if key in self._prog:
             return self._prog[key]
         P, L, o = self.P, self.L, []
@@ -118,7 +118,7 @@ class DeAOTRuntime(ClipRuntime):
                                     ldk=D_ATT, ldv=E2, ldua=ldua, ldo=E2, k_slot_stride=L * D_ATT, v_slot_stride=L * E2,
                                     chunks=self.chunks, nchunks=nchunks, frames=frames, keys_per_frame=L, pe_cur=P['pe_cur'],
                                     pe_mem=P['pe_mem'], u_b=ub, ldub=E1, usplit=E1,
-                                    mass=self.mass if (i == 0 and not ref_mode) else None))
+                                    mass=self.mass if (i == 0 and not ref_mode and want_mass) else None))
             o += self._tail(d + '.long', xin)
             o.append(self._lin(self.qvu[i], d + '.rel', self.rel, L, D_ATT, 225, ldo=REL_LD, ldx=QVU))
             o.append(ops.local_gated_attn(self.qvu[i], self.short_K[i], self.short_V[i], self.rel, ua, self.g1, self.gp_ws,
