@@ -231,7 +231,7 @@ int rmem_evict_scores(const float* logits_nhwc, int ldl, int num_classes, int ke
 int rmem_copy_async(void* dst, const void* src, size_t bytes, void* stream);
 
 /* Test-time-augmentation merge: softmax of each augmentation's NCHW logits (read horizontally flipped where flips[a] != 0),
- * mean over the <= 4 augmentations, argmax; writes any of uint8 labels, fp32 labels, NCHW mean probabilities.
+ * mean over the <= 8 augmentations (scales x flips), argmax; writes any of uint8 labels, fp32 labels, NCHW mean probabilities.
  * logits_nchw / flips are HOST arrays of n_aug entries.  Replaces managers/evaluator.py:427-441 (flip / multi-scale TTA). */
 int rmem_tta_merge(const float* const* logits_nchw, const int* flips, int n_aug, int num_classes, int H, int W,
                    unsigned char* label_u8, float* label_f32, float* prob_nchw, void* stream);

@@ -588,33 +588,40 @@ def run_clip(engine: OracleEngine, frames: Sequence[Tensor], first_mask: Tensor,
     return labels, all_logits
 
 
-def evaluate_sequence(weights: W, frames: Tensor, labels: Dict[int, Tensor], out_hw, former=1, latter=7, flip=False):
-    """managers/evaluator.py:330-523 for one sequence (gap heuristic, flip TTA with probability averaging, new-object
-    reference frames, memory update), on OracleInferEngine(s).  Returns (label maps, mean probabilities) per frame > 0."""
-    n = frames.shape[0]
+def evaluate_sequence(weights: W, frames, labels: Dict[int, Tensor], out_hw, former=1, latter=7, flip=False):
+    """managers/evaluator.py:330-523 for one sequence (gap heuristic, flip / multi-scale TTA with probability averaging over
+    one engine per (scale, flip) pair, new-object reference frames, memory update), on OracleInferEngine(s).  frames: one
+    [n,3,H,W] tensor or a list of them (one per test scale).  Returns (label maps, mean probabilities) per frame > 0."""
+    per_scale = list(frames) if isinstance(frames, (list, tuple)) else [frames]
+    n = per_scale[0].shape[0]
     gap = max(int(round(n / 30)), 5)
-    augs = [False, True] if flip else [False]
-    net_hw = tuple(frames.shape[2:])
+    augs = [(si, fl) for si in range(len(per_scale)) for fl in ([False, True] if flip else [False])]
     engines = [OracleInferEngine(weights, former, latter, gap) for _ in augs]
-    for e, fl in zip(engines, augs):
-        lab = F.interpolate(labels[0], size=net_hw, mode='nearest')
-        e.add_reference_frame(frames[0:1].flip(3) if fl else frames[0:1], lab.flip(3) if fl else lab, int(labels[0].max()), 0)
+
+    def frame(a, t):
+        si, fl = augs[a]
+        img = per_scale[si][t:t + 1]
+        return img.flip(3) if fl else img
+
+    for a, (e, (si, fl)) in enumerate(zip(engines, augs)):
+        lab = F.interpolate(labels[0], size=tuple(per_scale[si].shape[2:]), mode='nearest')
+        e.add_reference_frame(frame(a, 0), lab.flip(3) if fl else lab, int(labels[0].max()), 0)
     outs, probs = [], []
     for t in range(1, n):
         ps = []
-        for e, fl in zip(engines, augs):
-            lg = e.match_propogate_one_frame(frames[t:t + 1].flip(3) if fl else frames[t:t + 1], out_hw)
+        for a, (e, (si, fl)) in enumerate(zip(engines, augs)):
+            lg = e.match_propogate_one_frame(frame(a, t), out_hw)
             ps.append(torch.softmax(lg.flip(3) if fl else lg, dim=1))
         prob = torch.mean(torch.cat(ps, 0), dim=0, keepdim=True)
         label = torch.argmax(prob, dim=1, keepdim=True).float()
         if t in labels:
             keep = (labels[t] == 0).float()
             label = label * keep + labels[t] * (1 - keep)
-            for e, fl in zip(engines, augs):
+            for a, (e, (si, fl)) in enumerate(zip(engines, augs)):
                 lab = F.interpolate(label.flip(3) if fl else label, size=e.input_size_2d, mode='nearest')
-                e.add_reference_frame(frames[t:t + 1].flip(3) if fl else frames[t:t + 1], lab, int(label.max()), t)
+                e.add_reference_frame(frame(a, t), lab, int(label.max()), t)
         else:
-            for e, fl in zip(engines, augs):
+            for e, (si, fl) in zip(engines, augs):
                 e.update_memory(F.interpolate(label.flip(3) if fl else label, size=e.input_size_2d, mode='nearest'))
         outs.append(label[0, 0].to(torch.uint8))
         probs.append(prob)

@@ -190,7 +190,7 @@ __global__ void k_evict_final(const float* partial, int nblocks, int T, float* s
 
 // test-time augmentation merge (managers/evaluator.py:427-441): softmax of every augmentation's logits (horizontally
 // flipped back where that augmentation was flipped), mean over augmentations, argmax.  logits: up to 4 NCHW fp32 maps.
-struct TtaParams { const float* lg[4]; int flip[4]; int n_aug, nc, H, W; uint8_t* label; float* label_f32; float* prob; };
+struct TtaParams { const float* lg[8]; int flip[8]; int n_aug, nc, H, W; uint8_t* label; float* label_f32; float* prob; };
 
 __global__ __launch_bounds__(256) void k_tta_merge(TtaParams p) {
   const long total = (long)p.H * p.W;
@@ -352,10 +352,10 @@ extern "C" int rmem_evict_scores(const float* logits_nhwc, int ldl, int num_clas
 
 extern "C" int rmem_tta_merge(const float* const* logits_nchw, const int* flips, int n_aug, int num_classes, int H, int W,
                               unsigned char* label_u8, float* label_f32, float* prob_nchw, void* stream) {
-  RMEM_REQUIRE(logits_nchw && flips && n_aug >= 1 && n_aug <= 4 && num_classes >= 1 && num_classes <= 16, "rmem_tta_merge: 1..4 augmentations, <= 16 classes");
+  RMEM_REQUIRE(logits_nchw && flips && n_aug >= 1 && n_aug <= 8 && num_classes >= 1 && num_classes <= 16, "rmem_tta_merge: 1..8 augmentations, <= 16 classes");
   RMEM_REQUIRE(label_u8 || label_f32 || prob_nchw, "rmem_tta_merge: no output requested");
   TtaParams p;
-  for (int a = 0; a < 4; ++a) { p.lg[a] = a < n_aug ? logits_nchw[a] : nullptr; p.flip[a] = a < n_aug ? flips[a] : 0; }
+  for (int a = 0; a < 8; ++a) { p.lg[a] = a < n_aug ? logits_nchw[a] : nullptr; p.flip[a] = a < n_aug ? flips[a] : 0; }
   p.n_aug = n_aug; p.nc = num_classes; p.H = H; p.W = W; p.label = label_u8; p.label_f32 = label_f32; p.prob = prob_nchw;
   hipLaunchKernelGGL(k_tta_merge, dim3(nblk((long)H * W)), dim3(256), 0, (hipStream_t)stream, p);
   return rmem_check_launch("rmem_tta_merge");

@@ -94,42 +94,49 @@ class SequenceEvaluator:
             self.engines.append(e.eval())
         return self.engines[i]
 
-    def run(self, frames: torch.Tensor, labels: Dict[int, torch.Tensor], out_hw: Tuple[int, int]) -> List[torch.Tensor]:
-        """frames: [n, 3, H, W] fp32 device (network size, normalised); labels: {frame index: [1,1,Ho,Wo] fp32 label map at the
-        ORIGINAL size}; labels[0] is the first-frame annotation, later entries are newly appearing objects.
+    def run(self, frames, labels: Dict[int, torch.Tensor], out_hw: Tuple[int, int]) -> List[torch.Tensor]:
+        """frames: [n, 3, H, W] fp32 device (network size, normalised) or, for multi-scale testing, a list of such tensors, one
+        per entry of TEST_MULTISCALE (each at its own stride-aligned size, synth.network_size(..., scale=s));
+        labels: {frame index: [1,1,Ho,Wo] fp32 label map at the ORIGINAL size}; labels[0] is the first-frame annotation,
+        later entries are newly appearing objects.  One engine per (scale, flip) pair (evaluator.py:342-355); their logits
+        are resized to the original size, un-flipped, soft-maxed and averaged (427-438).
         Returns the uint8 label map of every frame after the first, at the original size."""
-        n = frames.shape[0]
+        per_scale = list(frames) if isinstance(frames, (list, tuple)) else [frames]
+        n = per_scale[0].shape[0]
         gap = max(int(round(n / 30)), 5)
-        augs = [False, True] if self.flip else [False]
-        net_hw = tuple(frames.shape[2:])
+        flips = [False, True] if self.flip else [False]
+        augs = [(si, fl) for si in range(len(per_scale)) for fl in flips]      # evaluator.py:342-355 order: scale outer, flip inner
+        if len(augs) > 8:
+            raise ValueError('at most 8 augmentations (scales x flips)')
+        aflips = [fl for _, fl in augs]
         outs: List[torch.Tensor] = []
-        for i, flipped in enumerate(augs):
-            e = self._engine(i)
+
+        def frame(a, t):
+            si, fl = augs[a]
+            img = per_scale[si][t:t + 1]
+            return img.flip(3) if fl else img
+
+        for a, (si, fl) in enumerate(augs):
+            e = self._engine(a)
             e.restart_engine()
             e.long_term_mem_gap = gap
-            img = frames[0:1].flip(3) if flipped else frames[0:1]
-            lab = F.interpolate(labels[0], size=net_hw, mode='nearest')
-            lab = lab.flip(3) if flipped else lab
-            e.add_reference_frame(img, lab, obj_nums=[int(labels[0].max().item())], frame_step=0)
+            lab = F.interpolate(labels[0], size=tuple(per_scale[si].shape[2:]), mode='nearest')
+            e.add_reference_frame(frame(a, 0), lab.flip(3) if fl else lab, obj_nums=[int(labels[0].max().item())], frame_step=0)
         for t in range(1, n):
-            logits = []
-            for i, flipped in enumerate(augs):
-                img = frames[t:t + 1].flip(3) if flipped else frames[t:t + 1]
-                logits.append(self.engines[i].match_propogate_one_frame(img, output_size=out_hw))
-            label_u8, label_f, _ = tta_merge(logits, augs)
+            logits = [self.engines[a].match_propogate_one_frame(frame(a, t), output_size=out_hw) for a in range(len(augs))]
+            label_u8, label_f, _ = tta_merge(logits, aflips)
             if t in labels:                                   # evaluator.py:484-508
                 new = labels[t]
                 keep = (new == 0).float()
                 label_f = label_f * keep + new * (1 - keep)
                 label_u8 = label_f[0, 0].to(torch.uint8)
                 nobj = [int(label_f.max().item())]
-                for i, flipped in enumerate(augs):
-                    lab = F.interpolate(label_f.flip(3) if flipped else label_f, size=self.engines[i].input_size_2d, mode='nearest')
-                    img = frames[t:t + 1].flip(3) if flipped else frames[t:t + 1]
-                    self.engines[i].add_reference_frame(img, lab, obj_nums=nobj, frame_step=t)
+                for a, (si, fl) in enumerate(augs):
+                    lab = F.interpolate(label_f.flip(3) if fl else label_f, size=self.engines[a].input_size_2d, mode='nearest')
+                    self.engines[a].add_reference_frame(frame(a, t), lab, obj_nums=nobj, frame_step=t)
             else:
-                for i, flipped in enumerate(augs):
-                    lab = F.interpolate(label_f.flip(3) if flipped else label_f, size=self.engines[i].input_size_2d, mode='nearest')
-                    self.engines[i].update_memory(lab)
+                for a, (si, fl) in enumerate(augs):
+                    lab = F.interpolate(label_f.flip(3) if fl else label_f, size=self.engines[a].input_size_2d, mode='nearest')
+                    self.engines[a].update_memory(lab)
             outs.append(label_u8)
         return outs

@@ -13,14 +13,14 @@ import torch
 import torch.nn.functional as F
 
 
-def network_size(h: int, w: int, max_long: int = 1040, stride: int = 16, align_corners: bool = True):
+def network_size(h: int, w: int, max_long: int = 1040, stride: int = 16, align_corners: bool = True, scale: float = 1.0):
     """Stride-aligned network input size, dataloaders/video_transforms.py:575-622
-    (max_size branch; TEST_MAX_SIZE = 1.3 * 800 = 1040, tools/eval.py:128)."""
+    (max_size branch; TEST_MAX_SIZE = 1.3 * 800 = 1040, tools/eval.py:128); ``scale`` is one entry of TEST_MULTISCALE."""
     sc = None
     if max(h, w) > max_long:
         sc = float(max_long) / max(h, w)
     nh, nw = (h, w) if sc is None else (sc * h, sc * w)
-    nh, nw = int(nh * 1.0), int(nw * 1.0)
+    nh, nw = int(nh * scale), int(nw * scale)
     if align_corners:
         if (nh - 1) % stride:
             nh = int(np.around((nh - 1) / stride) * stride + 1)

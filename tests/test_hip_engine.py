@@ -309,3 +309,33 @@ def test_encoder_lookahead_matches_per_frame_path():
     print('look-ahead 4 vs 1: label agreement', agree)
     assert t1 == t4
     assert agree > 0.995
+
+
+def test_sequence_evaluator_multiscale_tta():
+    """f3: multi-scale + flip testing (TEST_MULTISCALE = [1.0, 1.3], TEST_FLIP): four engines at two network sizes, logits
+    resized to the original size and averaged (managers/evaluator.py:342-355, 427-438) -- against the oracle."""
+    if not os.path.exists(os.path.join(GOLDEN, 'trained_delta.pt')):
+        pytest.skip('fitted weights missing')
+    from oracle import ref_cpu as O
+    from rmem_ocu_amd import build_vos_model, get_config
+    from rmem_ocu_amd.evaluator import SequenceEvaluator
+    from rmem_ocu_amd.synth import make_clip, network_size
+    from rmem_ocu_amd.weights import fitted_state_dict
+    dev = torch.device('cuda', 0)
+    sd = fitted_state_dict(0)
+    cfg = get_config('pre_vost', 'test', 'r50_aotl')
+    cfg.FORMER_MEM_LEN, cfg.LATTER_MEM_LEN = 1, 2
+    model = build_vos_model(cfg.MODEL_VOS, cfg).cuda(0)
+    model.load_state_dict(sd)
+    out_hw = (160, 192)
+    assert network_size(*out_hw) == (161, 193) and network_size(*out_hw, scale=1.3) == (209, 257)
+    frames, mask = make_clip(72, 6, 161, 193, 2)
+    big = F.interpolate(frames, size=(209, 257), mode='bilinear', align_corners=True)    # stand-in for the loader's resize
+    first = F.interpolate(mask.float(), size=out_hw, mode='nearest')
+    ref_labels, _ = O.evaluate_sequence(sd, [frames, big], {0: first}, out_hw, 1, 2, flip=True)
+    ev = SequenceEvaluator(model, 0, flip=True)
+    got = ev.run([frames.to(dev), big.to(dev)], {0: first.to(dev)}, out_hw)
+    assert len(ev.engines) == 4 and len(got) == 5
+    agree = [(g.cpu() == r).float().mean().item() for g, r in zip(got, ref_labels)]
+    print('multi-scale + flip TTA: label agreement per frame', [round(a, 4) for a in agree])
+    assert agree[0] > 0.997 and min(agree) > 0.97

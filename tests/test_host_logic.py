@@ -76,6 +76,7 @@ def test_state_dict_contract_and_packing():
 def test_network_size_rule():
     from rmem_ocu_amd.synth import network_size
     assert network_size(480, 854) == (481, 849)          # cfg 2
+    assert network_size(480, 854, scale=1.3) == (625, 1105)   # TEST_MULTISCALE entry (video_transforms.py:604-615)
     assert network_size(720, 1280) == (577, 1041)        # cfg 3
     assert network_size(480, 854, align_corners=False) == (480, 848)
 
