@@ -98,6 +98,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--workload', default='davis17_480p_r50_N8', choices=sorted(WORKLOADS))
     ap.add_argument('--no-graphs', action='store_true')
+    ap.add_argument('--host-frames', action='store_true',
+                    help='PCIe-inclusive variant (not the contract line): frames start as decoded uint8 RGB in pinned host memory')
     ap.add_argument('--encoder-lookahead', type=int, default=int(os.environ.get('RMEM_ENC_LOOKAHEAD', 4)),
                     help='frames the ResNet-50 encoder runs ahead inside a clip (one launch per layer for all of them)')
     ap.add_argument('--sample-every', type=int, default=100, help='time the memory-read kernel on 1 in N timed frames (run in isolation)')
@@ -142,7 +144,17 @@ def main():
 
     # two distinct synthetic clips per rank, reused round-robin by the clip slots
     clips_host = [make_clip(1000 * rank + j, CLIP_LEN, net_hw[0], net_hw[1], NUM_OBJS) for j in range(2)]
-    clips = [(f.to(dev), m.to(dev)) for f, m in clips_host]
+    if args.host_frames:
+        # decoded video frames as a loader would hand them over: uint8 RGB [n, Hs, Ws, 3] at the VIDEO size in pinned memory;
+        # every frame crosses PCIe (1.2 MB) and is resized + normalised on the device (rmem_ingest_rgb8)
+        import torch.nn.functional as F
+        clips = []
+        for f, m in clips_host:
+            v = F.interpolate(f, size=VIDEO_HW, mode='bilinear', align_corners=False)
+            u8 = (v * 40.0 + 128.0).clamp(0, 255).to(torch.uint8).permute(0, 2, 3, 1).contiguous().pin_memory()
+            clips.append((u8, m.to(dev)))
+    else:
+        clips = [(f.to(dev), m.to(dev)) for f, m in clips_host]
 
     C = max(1, args.clips_in_flight)
     lookahead = args.encoder_lookahead if cfg.MODEL_ENCODER == 'resnet50' else 1      # the batched encoder is the ResNet-50 one
@@ -232,7 +244,7 @@ def main():
                        'tokens': (net_hw[0] // 16 if wl['net'] else 31) * (net_hw[1] // 16 if wl['net'] else 54), 'objects': NUM_OBJS,
                        'memory_bank': f"{wl['former']}+{wl['latter']}", 'gap': max(int(round(CLIP_LEN / 30)), 5), 'clips_in_flight_per_gpu': C,
                        'parallelism': f'clip-parallel x{world}', 'weights': 'synthetic (no checkpoint offline)',
-                       'hipgraphs': not args.no_graphs, 'encoder_lookahead': lookahead, 'host_enqueue_ms_per_step': round(1e3 * host_enqueue / args.steps, 4)},
+                       'hipgraphs': not args.no_graphs, 'frames_from': 'pinned host uint8 (PCIe-inclusive)' if args.host_frames else 'HBM', 'encoder_lookahead': lookahead, 'host_enqueue_ms_per_step': round(1e3 * host_enqueue / args.steps, 4)},
             'roofline': {'bound': 'mfma', 'kernel': 'k_gp_pv<1, true>' if deaot else 'k_attn_partial<true, true>', 'achieved': None if achieved is None else round(achieved, 2),
                          'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': None if achieved is None else round(achieved / PEAK_BF16_TFLOPS, 4),
                          'traffic': pmc_traffic() if args.workload == 'davis17_480p_r50_N8' else None, 'launches_timed': nl.value,

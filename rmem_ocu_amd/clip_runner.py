@@ -61,17 +61,48 @@ class ClipSlot:
         self.done = True
 
     def start(self, frames: torch.Tensor, first_mask: torch.Tensor, num_objs: int):
-        """frames [n,3,H,W] fp32 device, first_mask [1,1,H,W] at network size."""
+        """frames [n,3,H,W] fp32 device at network size, or decoded uint8 RGB [n,Hs,Ws,3] in PINNED HOST memory (then every
+        frame crosses PCIe as uint8 and is resized + normalised on the device, rmem_ingest_rgb8);
+        first_mask [1,1,H,W] at network size."""
         n = frames.shape[0]
         self.frames = frames
+        self.host_u8 = frames.dtype == torch.uint8
         if self.labels is None or self.labels.shape[0] < n:
             self.labels = torch.zeros(n, self.out_hw[0], self.out_hw[1], dtype=torch.uint8, device=self.device)
         eng = self.engine
         eng.restart_engine()
         eng.long_term_mem_gap = max(int(round(n / 30)), 5)      # evaluator.py:330-335
-        eng.add_reference_frame(frames[0:1], first_mask, obj_nums=[num_objs], frame_step=0)
+        if self.host_u8:
+            if not frames.is_pinned():
+                raise ValueError('uint8 host frames must be in pinned memory')
+            H, W = int(first_mask.shape[-2]), int(first_mask.shape[-1])
+            hs, ws = int(frames.shape[1]), int(frames.shape[2])
+            if getattr(self, '_stage', None) is None or self._stage.shape[1:3] != (hs, ws):
+                self._stage = torch.empty(max(self.lookahead, 1), hs, ws, 3, dtype=torch.uint8, device=self.device)
+                self._first = torch.empty(1, 3, H, W, dtype=torch.float32, device=self.device)
+            self._net_hw = (H, W)
+            cur = torch.cuda.current_stream(self.device)
+            ops.copy_async(self._stage[0], frames[0], hs * ws * 3)(cur.cuda_stream)
+            ops.run(ops.ingest_rgb8(self._stage[0], Hs=hs, Ws=ws, Hd=H, Wd=W, out_chw=self._first[0]), cur.cuda_stream)
+            cur.synchronize()        # once per clip: the engine works on its own stream
+            eng.add_reference_frame(self._first, first_mask, obj_nums=[num_objs], frame_step=0)
+        else:
+            eng.add_reference_frame(frames[0:1], first_mask, obj_nums=[num_objs], frame_step=0)
         self.cursor = 1
         self.done = n <= 1
+
+    def _ingest_group(self, i: int):
+        """Host -> device copy of the next look-ahead group of uint8 frames and their resize + normalise into the encoder's
+        input buffer, all on the clip's stream."""
+        eng = self.engine
+        s = eng.aot_engines[0].stream.cuda_stream
+        la = max(self.lookahead, 1)
+        m = min(la, self.frames.shape[0] - i)
+        hs, ws = int(self.frames.shape[1]), int(self.frames.shape[2])
+        H, W = self._net_hw
+        ops.copy_async(self._stage, self.frames[i:i + m], m * hs * ws * 3)(s)
+        dst = eng.encode_inputs(la) if la > 1 else self._first
+        ops.run([ops.ingest_rgb8(self._stage[b], Hs=hs, Ws=ws, Hd=H, Wd=W, out_chw=dst[b]) for b in range(m)], s)
 
     def step(self):
         """Propagate one frame and update the memory with the predicted labels (all asynchronous)."""
@@ -79,8 +110,15 @@ class ClipSlot:
         if self.lookahead > 1:
             e = (i - 1) % self.lookahead
             if e == 0:
-                self.engine.encode_ahead(self.frames[i:i + self.lookahead], self.lookahead)
+                if self.host_u8:
+                    self._ingest_group(i)
+                    self.engine.encode_ahead(None, self.lookahead)
+                else:
+                    self.engine.encode_ahead(self.frames[i:i + self.lookahead], self.lookahead)
             self.engine.propagate_to_label(None, self.cur_label, enc_slot=e)
+        elif self.host_u8:
+            self._ingest_group(i)
+            self.engine.propagate_to_label(self._first, self.cur_label)
         else:
             self.engine.propagate_to_label(self.frames[i:i + 1], self.cur_label)
         self.engine.update_memory_from_label_u8(self.cur_label)

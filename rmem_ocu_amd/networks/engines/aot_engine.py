@@ -226,12 +226,18 @@ class AOTEngine:
         dataloaders/eval_datasets.py:57-64).  propagate_to_label(..., enc_slot=e) then consumes frame e."""
         rt = self.rt
         be = rt.batch_encoder(frames)
-        n = int(imgs.shape[0])
-        if n > frames:
-            raise ValueError(f'encode_ahead: {n} frames for a look-ahead of {frames}')
         with self._scope():
-            ops.copy_async(be.img_in, imgs, n * 3 * rt.H * rt.W * 4)(self._stream())
+            if imgs is not None:                      # None: the caller already put the frames into encode_inputs(frames)
+                n = int(imgs.shape[0])
+                if n > frames:
+                    raise ValueError(f'encode_ahead: {n} frames for a look-ahead of {frames}')
+                ops.copy_async(be.img_in, imgs, n * 3 * rt.H * rt.W * 4)(self._stream())
             self._run(f'encB{frames}', be.prog())
+
+    def encode_inputs(self, frames: int = 4):
+        """fp32 [frames, 3, H, W] input buffer of encode_ahead (e.g. the target of rmem_ingest_rgb8, so decoded uint8 frames
+        go host -> device -> resize + normalise -> encoder without an extra copy)."""
+        return self.rt.batch_encoder(frames).img_in
 
     def propagate_to_label(self, img, label_u8, enc_slot=None):
         """Fused fast path of one frame: propagate, then argmax labels (uint8 [Ho, Wo], caller's device
@@ -459,6 +465,9 @@ class AOTInferEngine:
         if len(self.aot_engines) != 1:
             raise NotImplementedError('encoder look-ahead covers clips with <= 10 objects')
         self.aot_engines[0].encode_ahead(imgs, frames)
+
+    def encode_inputs(self, frames: int = 4):
+        return self.aot_engines[0].encode_inputs(frames)
 
     def update_memory_from_label_u8(self, label_u8):
         self.aot_engines[0].update_memory_from_label_u8(label_u8)

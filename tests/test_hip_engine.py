@@ -339,3 +339,30 @@ def test_sequence_evaluator_multiscale_tta():
     agree = [(g.cpu() == r).float().mean().item() for g, r in zip(got, ref_labels)]
     print('multi-scale + flip TTA: label agreement per frame', [round(a, 4) for a in agree])
     assert agree[0] > 0.997 and min(agree) > 0.97
+
+
+def test_clip_slot_from_pinned_uint8_frames():
+    """PCIe-inclusive path: decoded uint8 frames in pinned host memory -> H2D -> rmem_ingest_rgb8 -> look-ahead encoder gives
+    the same masks as feeding the ingested fp32 frames from device memory."""
+    from rmem_ocu_amd import ops
+    from rmem_ocu_amd.clip_runner import ClipSlot
+    from rmem_ocu_amd.synth import make_clip
+    dev = torch.device('cuda', 0)
+    frames, mask = make_clip(9, 11, 161, 193, 2)
+    vid = F.interpolate(frames, size=(160, 192), mode='bilinear', align_corners=False)
+    u8 = (vid * 40.0 + 128.0).clamp(0, 255).to(torch.uint8).permute(0, 2, 3, 1).contiguous().pin_memory()
+    u8d = u8.to(dev)
+    ing = torch.empty(11, 3, 161, 193, dtype=torch.float32, device=dev)
+    ops.run([ops.ingest_rgb8(u8d[i], Hs=160, Ws=192, Hd=161, Wd=193, out_chw=ing[i]) for i in range(11)])
+    torch.cuda.synchronize()
+    out = []
+    for src in (ing, u8):
+        eng = _engine(1, 2, 2)
+        eng.set_async(use_graphs=True)
+        slot = ClipSlot(eng, (160, 192), dev, lookahead=4)
+        slot.start(src, mask.to(dev), 2)
+        while not slot.done:
+            slot.step()
+        eng.synchronize()
+        out.append(slot.labels[:11].cpu().numpy().copy())
+    assert np.array_equal(out[0][1:], out[1][1:])
