@@ -198,6 +198,12 @@ int rmem_gated_profile_stop(double* total_ms, double* total_flops, int* launches
 /* strided 2-D device copy (rows of row_bytes): the torch.cat / slice bookkeeping of transformer.py:840-872 */
 int rmem_copy2d_async(void* dst, long long dst_pitch, const void* src, long long src_pitch, long long row_bytes, int rows, void* stream);
 
+/* GroupNorm + activation + depth-wise 5x5 as two launches (statistics; normalise + activate + convolve through an LDS tile)
+ * instead of three, bit-identical to rmem_groupnorm_nhwc followed by rmem_dwconv5x5_nhwc.  Replaces layers/basic.py:27-35
+ * (GNActDWConv2d.forward).  C % 64 == 0, channels per group in {8, 16, 32, 64}. */
+int rmem_gn_act_dwconv5x5_nhwc(const void* x, int H, int W, int C, int groups, const float* gamma, const float* beta, float eps,
+                               int act, const float* w_t, void* y, float* workspace, void* stream);
+
 /* ------------------------------------------------------------------ layout / resampling */
 /* fp32 [3][H][W] image -> bf16 [H][W][8] (channels 3..7 zero): input of encoders/resnet.py:179. */
 int rmem_image_to_nhwc8(const float* img_chw, void* out, int H, int W, void* stream);

@@ -262,6 +262,83 @@ __global__ __launch_bounds__(256) void k_dwconv5(const bf16* x, const float* w, 
   reinterpret_cast<bf16x8*>(y)[i] = o;
 }
 
+// GroupNorm apply + activation + depth-wise 5x5 in one pass (basic.py:31-33: gn -> GELU -> conv of GNActDWConv2d): a tile of
+// 8 x 16 pixels x 64 channels with its 2-pixel halo is normalised + activated ONCE into LDS (bf16, the same rounding the
+// two-kernel path stores), then the 25 taps read LDS.  ws holds the (sum, sumsq) partials of k_gn_stats.
+constexpr int DT_H = 8, DT_W = 16, DT_C = 64, DT_HW = (DT_H + 4) * (DT_W + 4);
+__global__ __launch_bounds__(256) void k_gn_dwconv5(const bf16* x, const float* ws, const float* gamma, const float* beta, float eps,
+                                                    int cpg, int act, const float* w, bf16* y, int H, int W, int C, int M) {
+  __shared__ __attribute__((aligned(16))) bf16 tile[DT_HW * DT_C];
+  __shared__ __attribute__((aligned(16))) float wl[25 * DT_C];
+  __shared__ float s_mean[8], s_rstd[8];
+  const int tid = threadIdx.x;
+  const int tiles_x = (W + DT_W - 1) / DT_W;
+  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+  const int c0 = blockIdx.y * DT_C;
+  const int ng = DT_C / cpg, g0 = c0 / cpg;
+  if (tid < ng) {
+    float s = 0.f, ss = 0.f;
+    for (int i = 0; i < GN_SPLITS; ++i) {
+      s += ws[((g0 + tid) * GN_SPLITS + i) * 2];
+      ss += ws[((g0 + tid) * GN_SPLITS + i) * 2 + 1];
+    }
+    const float n = (float)M * (float)cpg;
+    const float mean = s / n;
+    const float var = fmaxf(ss / n - mean * mean, 0.f);
+    s_mean[tid] = mean;
+    s_rstd[tid] = rsqrtf(var + eps);
+  }
+  for (int i = tid; i < 25 * DT_C; i += 256) wl[i] = w[(i / DT_C) * C + c0 + (i % DT_C)];
+  __syncthreads();
+  for (int i = tid; i < DT_HW * (DT_C / 8); i += 256) {
+    const int pix = i >> 3, ch8 = i & 7;
+    const int hy = pix / (DT_W + 4), hx = pix - hy * (DT_W + 4);
+    const int gy = ty * DT_H + hy - 2, gx = tx * DT_W + hx - 2;
+    bf16x8 o = {0, 0, 0, 0, 0, 0, 0, 0};
+    if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) {
+      const int cc = c0 + ch8 * 8;
+      float d[8];
+      gn_load8(x + ((long)gy * W + gx) * C + cc, d);
+      const int g = (ch8 * 8) / cpg;
+      const float mean = s_mean[g], rstd = s_rstd[g];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float f = (d[j] - mean) * rstd * gamma[cc + j] + beta[cc + j];
+        if (act == 1) f = fmaxf(f, 0.f);
+        else if (act == 2) f = gelu_erf(f);
+        o[j] = (bf16)f;
+      }
+    }
+    *reinterpret_cast<bf16x8*>(&tile[pix * DT_C + ch8 * 8]) = o;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < DT_H * DT_W * (DT_C / 8) / 256; ++k) {
+    const int item = tid + 256 * k;
+    const int ch8 = item & 7, pp = item >> 3;
+    const int oy = pp / DT_W, ox = pp - oy * DT_W;
+    const int gy = ty * DT_H + oy, gx = tx * DT_W + ox;
+    if (gy >= H || gx >= W) continue;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+    for (int dy = 0; dy < 5; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 5; ++dx) {
+        const bf16x8 d = *reinterpret_cast<const bf16x8*>(&tile[((oy + dy) * (DT_W + 4) + ox + dx) * DT_C + ch8 * 8]);
+        const float* wt = &wl[(dy * 5 + dx) * DT_C + ch8 * 8];
+        const f32x4 w0 = *reinterpret_cast<const f32x4*>(wt), w1 = *reinterpret_cast<const f32x4*>(wt + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { acc[j] += (float)d[j] * w0[j]; acc[4 + j] += (float)d[4 + j] * w1[j]; }
+      }
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (bf16)acc[j];
+    *reinterpret_cast<bf16x8*>(y + ((long)gy * W + gx) * C + c0 + ch8 * 8) = o;
+  }
+}
+
 }  // namespace
 
 extern "C" int rmem_layernorm256(const void* a, int a_is_f32, int lda, const void* b, int b_is_f32, int ldb,
@@ -364,6 +441,21 @@ extern "C" int rmem_groupnorm_f32_nhwc(const float* x, int M, int C, int groups,
   const int blocks = (int)min((long)2048, (total + 255) / 256);
   hipLaunchKernelGGL(k_gn_apply<float>, dim3(blocks), dim3(256), 0, s, x, M, C, cpg, groups, workspace, gamma, beta, eps, act, (bf16*)y);
   return rmem_check_launch("rmem_groupnorm_f32_nhwc");
+}
+
+extern "C" int rmem_gn_act_dwconv5x5_nhwc(const void* x, int H, int W, int C, int groups, const float* gamma, const float* beta,
+                                          float eps, int act, const float* w_t, void* y, float* workspace, void* stream) {
+  RMEM_REQUIRE(x && y && gamma && beta && w_t && workspace && H > 0 && W > 0, "rmem_gn_act_dwconv5x5_nhwc: bad argument");
+  RMEM_REQUIRE(groups >= 1 && groups <= 64 && C % groups == 0 && C % DT_C == 0, "rmem_gn_act_dwconv5x5_nhwc: C must be a multiple of 64 and of groups (<= 64)");
+  const int cpg = C / groups;
+  RMEM_REQUIRE(cpg % 8 == 0 && DT_C % cpg == 0, "rmem_gn_act_dwconv5x5_nhwc: channels per group must be 8, 16, 32 or 64");
+  RMEM_REQUIRE(act >= 0 && act <= 2, "rmem_gn_act_dwconv5x5_nhwc: bad act");
+  const int M = H * W;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_gn_stats<bf16>, dim3(groups, GN_SPLITS), dim3(256), 0, s, (const bf16*)x, M, C, cpg, workspace);
+  const dim3 grid(((W + DT_W - 1) / DT_W) * ((H + DT_H - 1) / DT_H), C / DT_C);
+  hipLaunchKernelGGL(k_gn_dwconv5, grid, dim3(256), 0, s, (const bf16*)x, workspace, gamma, beta, eps, cpg, act, w_t, (bf16*)y, H, W, C, M);
+  return rmem_check_launch("rmem_gn_act_dwconv5x5_nhwc");
 }
 
 extern "C" int rmem_dwconv5x5_nhwc(const void* x, const float* w_t, void* y, int H, int W, int C, void* stream) {

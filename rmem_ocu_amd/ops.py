@@ -201,6 +201,14 @@ def groupnorm(x, gamma, beta, y, ws, *, M, C, groups, act=0, eps=1e-5) -> Op:
     return Op(_lib.lib().rmem_groupnorm_nhwc, args, 'rmem_groupnorm_nhwc', (x, gamma, beta, y, ws))
 
 
+def gn_act_dwconv5x5(x, gamma, beta, w_t, y, ws, *, H, W, C, groups, act=2, eps=1e-5) -> Op:
+    """y = dwconv5x5(act(GroupNorm(x))): statistics launch + one fused normalise / activate / convolve launch."""
+    _dev(x, gamma, beta, w_t, y, ws)
+    assert x.dtype == BF16 and y.dtype == BF16 and w_t.dtype == F32 and w_t.numel() == 25 * C and gamma.numel() == C
+    args = (_ptr(x), H, W, C, groups, _ptr(gamma), _ptr(beta), eps, act, _ptr(w_t), _ptr(y), _ptr(ws))
+    return Op(_lib.lib().rmem_gn_act_dwconv5x5_nhwc, args, 'rmem_gn_act_dwconv5x5_nhwc', (x, gamma, beta, w_t, y, ws))
+
+
 def dwconv5x5(x, w_t, y, *, H, W, C) -> Op:
     _dev(x, w_t, y)
     assert x.dtype == BF16 and y.dtype == BF16 and w_t.dtype == F32 and w_t.numel() == 25 * C

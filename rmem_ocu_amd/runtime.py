@@ -402,8 +402,8 @@ class ClipRuntime:
             # --- feed-forward (683-687)
             o.append(ops.layernorm256(self.x, P[d + '.ln3.g'], P[d + '.ln3.b'], M=L, y=self.t3))
             o.append(self._lin(self.t3, d + '.linear1', self.h1, L, C, FFN))
-            o.append(ops.groupnorm(self.h1, P[d + '.gn.g'], P[d + '.gn.b'], self.h2, self.gn_ws, M=L, C=FFN, groups=32, act=2))
-            o.append(ops.dwconv5x5(self.h2, P[d + '.dw.w'], self.h3, H=self.H16, W=self.W16, C=FFN))
+            o.append(ops.gn_act_dwconv5x5(self.h1, P[d + '.gn.g'], P[d + '.gn.b'], P[d + '.dw.w'], self.h3, self.gn_ws, H=self.H16,
+                                          W=self.W16, C=FFN, groups=32, act=2))
             o.append(self._lin(self.h3, d + '.linear2', self.x, L, FFN, C, residual=self.x))
             # --- decoder norm of this layer's output into the concat buffer (248-259)
             o.append(ops.layernorm256(self.x, P[f'dec_norm{i}.g'], P[f'dec_norm{i}.b'], M=L,

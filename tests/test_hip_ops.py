@@ -457,3 +457,22 @@ def test_grouped_launches(dev):
     ops.run([ops.layernorm256(a[0], g, be, M=M, b=a[1], y=s0), ops.layernorm256(a[2], g, be, M=M, b=a[3], y=s1)])
     torch.cuda.synchronize()
     assert torch.equal(p0, s0) and torch.equal(p1, s1)
+
+
+@pytest.mark.parametrize('H,W,C,groups,act', [(31, 54, 1024, 32, 2), (11, 13, 1024, 32, 2), (9, 20, 128, 8, 1)])
+def test_gn_act_dwconv_fused_is_bit_identical(dev, H, W, C, groups, act):
+    """The fused GroupNorm + activation + depth-wise 5x5 equals rmem_groupnorm_nhwc followed by rmem_dwconv5x5_nhwc bit for bit
+    (ragged tiles at the right / bottom border included)."""
+    from rmem_ocu_amd import ops
+    M = H * W
+    x = rb(seeded(71, (M, C), 2.0)).to(BF16).to(dev)
+    g, b = (1 + seeded(72, (C,), 0.1)).to(dev), seeded(73, (C,), 0.1).to(dev)
+    wt = seeded(74, (25, C), 0.2).to(dev)
+    ws = ops.groupnorm_workspace(64, dev)
+    mid = torch.zeros(M, C, dtype=BF16, device=dev)
+    y0 = torch.zeros(M, C, dtype=BF16, device=dev)
+    y1 = torch.zeros(M, C, dtype=BF16, device=dev)
+    ops.run([ops.groupnorm(x, g, b, mid, ws, M=M, C=C, groups=groups, act=act), ops.dwconv5x5(mid, wt, y0, H=H, W=W, C=C)])
+    ops.run(ops.gn_act_dwconv5x5(x, g, b, wt, y1, ws, H=H, W=W, C=C, groups=groups, act=act))
+    torch.cuda.synchronize()
+    assert torch.equal(y0, y1)
