@@ -184,14 +184,17 @@ int rmem_gated_attn(const void* q, int ldq,                                     
                     const rmem_attn_chunk* chunks, int nchunks, int frames, int keys_per_frame,
                     const float* pe_cur, const float* pe_mem,                      /* fp32 [128], [4][128] or NULL */
                     int Lq, int DV, const void* u_a, int ldua, const void* u_b, int ldub, int usplit,
-                    void* out, int ldo, float* attn_mass, void* workspace, void* stream);
+                    void* out, int ldo, float* attn_mass,
+                    const float* dw_w_t, int H, int W,   /* optional: out = dw_conv5x5(gated) (attention.py:210), weights [25][DV],
+                                                            H * W == Lq; NULL: out = gated */
+                    void* workspace, void* stream);
 /* 15x15 local window flavour (layers/attention.py:281-349, use_linear False, one head): keys/values are the previous
  * frame's [H*W] tokens; a key contributes to a query iff |dy| <= 7 and |dx| <= 7 (the zero padding + 1e8 mask of
  * 299-303, 338); rel: fp32 [H*W][ldrel] = relative_emb_k(q) (attention.py:305, a rmem_conv2d_nhwc call with fp32 output),
  * column (dy+7)*15 + (dx+7).  Workspace: rmem_gated_attn_workspace_bytes(H*W, DV, 1, H*W, 8). */
 int rmem_local_gated_attn(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const float* rel, int ldrel,
                           int H, int W, int DV, const void* u_a, int ldua, const void* u_b, int ldub, int usplit,
-                          void* out, int ldo, void* workspace, void* stream);
+                          void* out, int ldo, const float* dw_w_t, void* workspace, void* stream);
 /* HIP-event timing of the k_gp_pv launches of rmem_gated_attn calls that carry a chunk table (bench.py's roofline leg) */
 int rmem_gated_profile_start(void);
 int rmem_gated_profile_stop(double* total_ms, double* total_flops, int* launches);

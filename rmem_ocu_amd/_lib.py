@@ -65,8 +65,8 @@ SIGNATURES = {
     'rmem_copy2d_async': (_i, [_vp, _ll, _vp, _ll, _ll, _i, _vp]),
     'rmem_gated_attn_workspace_bytes': (C.c_size_t, [_i, _i, _i, _i, _i]),
     'rmem_gated_attn': (_i, [_vp, _i, _vp, _ll, _i, _vp, _ll, _i, _vp, _i, _i, _i, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _i, _vp, _i,
-                             _vp, _vp, _vp]),
-    'rmem_local_gated_attn': (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _i, _vp, _i, _vp, _vp]),
+                             _vp, _vp, _i, _i, _vp, _vp]),
+    'rmem_local_gated_attn': (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _vp]),
     'rmem_gated_profile_start': (_i, []),
     'rmem_gated_profile_stop': (_i, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i)]),
     'rmem_graph_begin': (_i, [_vp]),

@@ -541,6 +541,7 @@ struct GpCombine {
   const bf16* ua; int ldua; const bf16* ub; int ldub; int usplit;
   bf16* out; int ldo;
   const rmem_attn_chunk* rows; float* mass; int T;
+  const float* dw; int H, W;        // optional: depth-wise 5x5 (weights [25][DV]) applied to the gated output in the same launch
 };
 
 // out[q, c] = (sum_g slab[g][q][c]) / l[q] * U[q][c]; thread = 8 columns of one query
@@ -573,6 +574,88 @@ __global__ __launch_bounds__(256) void k_gp_combine(GpCombine p) {
     for (int j = 0; j < 8; ++j) o[j] = (bf16)(v[j] * inv);
   }
   *reinterpret_cast<bf16x8*>(p.out + (long)q * p.ldo + c) = o;
+}
+
+// combine + depth-wise 5x5 in one launch (attention.py:208-210: outputs * U -> dw_conv): a tile of 8 x 16 queries x 64 value
+// columns with its 2-pixel halo is combined ONCE into LDS (bf16, the rounding the two-launch path stores), then the 25 taps
+// read LDS.  Saves the [Lq, DV] round trip and a launch per attention call.
+constexpr int CT_H = 8, CT_W = 16, CT_C = 64, CT_HW = (CT_H + 4) * (CT_W + 4);
+__global__ __launch_bounds__(256) void k_gp_combine_dwconv(GpCombine p) {
+  __shared__ __attribute__((aligned(16))) bf16 tile[CT_HW * CT_C];
+  __shared__ __attribute__((aligned(16))) float wl[25 * CT_C];
+  __shared__ float inv_l[CT_HW];
+  const int tid = threadIdx.x;
+  const int tiles_x = (p.W + CT_W - 1) / CT_W;
+  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+  const int c0 = blockIdx.y * CT_C;
+  for (int i = tid; i < 25 * CT_C; i += 256) wl[i] = p.dw[(i / CT_C) * p.DV + c0 + (i % CT_C)];
+  for (int i = tid; i < CT_HW; i += 256) {
+    const int hy = i / (CT_W + 4), hx = i - hy * (CT_W + 4);
+    const int gy = ty * CT_H + hy - 2, gx = tx * CT_W + hx - 2;
+    float v = 0.f;
+    if ((unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W) {
+      const int q = gy * p.W + gx;
+      float l = 0.f;
+      for (int r = 0; r < p.nrows; ++r) l += p.lpart[(long)r * p.Lqp + q];
+      v = 1.f / l;
+    }
+    inv_l[i] = v;
+  }
+  __syncthreads();
+  const bf16* up = c0 < p.usplit ? p.ua + c0 : (p.ub ? p.ub + (c0 - p.usplit) : nullptr);
+  const int ldu = c0 < p.usplit ? p.ldua : p.ldub;
+  for (int i = tid; i < CT_HW * (CT_C / 8); i += 256) {
+    const int pix = i >> 3, ch8 = i & 7;
+    const int hy = pix / (CT_W + 4), hx = pix - hy * (CT_W + 4);
+    const int gy = ty * CT_H + hy - 2, gx = tx * CT_W + hx - 2;
+    bf16x8 o = {0, 0, 0, 0, 0, 0, 0, 0};
+    if ((unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W) {
+      const int q = gy * p.W + gx;
+      float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      for (int g = 0; g < p.groups; ++g) {
+        const float* sp = p.slabs + ((long)g * p.Lqp + q) * p.DV + c0 + ch8 * 8;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(sp), b = *reinterpret_cast<const f32x4*>(sp + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[j] += a[j]; v[4 + j] += b[j]; }
+      }
+      const float inv = inv_l[pix];
+      if (up) {
+        const bf16x8 u = *reinterpret_cast<const bf16x8*>(up + (long)q * ldu + ch8 * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (bf16)(v[j] * inv * (float)u[j]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (bf16)(v[j] * inv);
+      }
+    }
+    *reinterpret_cast<bf16x8*>(&tile[pix * CT_C + ch8 * 8]) = o;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < CT_H * CT_W * (CT_C / 8) / 256; ++k) {
+    const int item = tid + 256 * k;
+    const int ch8 = item & 7, pp = item >> 3;
+    const int oy = pp / CT_W, ox = pp - oy * CT_W;
+    const int gy = ty * CT_H + oy, gx = tx * CT_W + ox;
+    if (gy >= p.H || gx >= p.W) continue;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+    for (int dy = 0; dy < 5; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 5; ++dx) {
+        const bf16x8 d = *reinterpret_cast<const bf16x8*>(&tile[((oy + dy) * (CT_W + 4) + ox + dx) * CT_C + ch8 * 8]);
+        const float* wt = &wl[(dy * 5 + dx) * CT_C + ch8 * 8];
+        const f32x4 w0 = *reinterpret_cast<const f32x4*>(wt), w1 = *reinterpret_cast<const f32x4*>(wt + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { acc[j] += (float)d[j] * w0[j]; acc[4 + j] += (float)d[4 + j] * w1[j]; }
+      }
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (bf16)acc[j];
+    *reinterpret_cast<bf16x8*>(p.out + ((long)gy * p.W + gx) * p.ldo + c0 + ch8 * 8) = o;
+  }
 }
 
 // mass[q][t] = sum of the row sums of frame t / total (transformer.py:1185-1192 with one head); grid = (query blocks, T)
@@ -660,7 +743,8 @@ void launch_all(GpParams& p, const GpPlan& g, GpCombine& c, bool timed, double f
   } else {
     hipLaunchKernelGGL((k_gp_pv<PM, false>), pg, dim3(256), 0, s, p);
   }
-  hipLaunchKernelGGL(k_gp_combine, dim3((unsigned)(((long)c.Lq * (c.DV / 8) + 255) / 256)), dim3(256), 0, s, c);
+  if (c.dw) hipLaunchKernelGGL(k_gp_combine_dwconv, dim3(((c.W + CT_W - 1) / CT_W) * ((c.H + CT_H - 1) / CT_H), c.DV / CT_C), dim3(256), 0, s, c);
+  else hipLaunchKernelGGL(k_gp_combine, dim3((unsigned)(((long)c.Lq * (c.DV / 8) + 255) / 256)), dim3(256), 0, s, c);
   if (c.mass) hipLaunchKernelGGL(k_gp_mass, dim3((c.Lq + 255) / 256, c.T), dim3(256), 0, s, c);
   (void)g;
 }
@@ -720,7 +804,7 @@ extern "C" int rmem_gated_attn(const void* q, int ldq, const void* k_bank, long 
                                long long v_slot_stride, int ldv, const rmem_attn_chunk* chunks, int nchunks, int frames,
                                int keys_per_frame, const float* pe_cur, const float* pe_mem, int Lq, int DV, const void* u_a,
                                int ldua, const void* u_b, int ldub, int usplit, void* out, int ldo, float* attn_mass,
-                               void* workspace, void* stream) {
+                               const float* dw_w_t, int H, int W, void* workspace, void* stream) {
   if (check_common(q, ldq, k_bank, ldk, v_bank, ldv, Lq, DV, u_a, ldua, u_b, ldub, usplit, out, ldo, workspace, "rmem_gated_attn")) return -1;
   RMEM_REQUIRE(frames >= 1 && keys_per_frame >= 1, "rmem_gated_attn: frames and keys_per_frame must be >= 1");
   RMEM_REQUIRE(nchunks >= 1 && nchunks <= MAX_ROWS, "rmem_gated_attn: 1 <= nchunks <= 64");
@@ -728,6 +812,7 @@ extern "C" int rmem_gated_attn(const void* q, int ldq, const void* k_bank, long 
   RMEM_REQUIRE(!attn_mass || (chunks && frames <= 32), "rmem_gated_attn: the mass output needs a chunk table and <= 32 frames");
   RMEM_REQUIRE(!pe_mem || chunks, "rmem_gated_attn: pe_mem needs a chunk table");
   RMEM_REQUIRE(k_slot_stride % 8 == 0 && v_slot_stride % 8 == 0, "rmem_gated_attn: slot strides must be multiples of 8 elements");
+  RMEM_REQUIRE(!dw_w_t || (H > 0 && W > 0 && H * W == Lq && usplit % 64 == 0), "rmem_gated_attn: the fused depth-wise conv needs H * W == Lq and usplit % 64 == 0");
   GpParams p = {};
   p.q = (const bf16*)q; p.ldq = ldq; p.k = (const bf16*)k_bank; p.k_slot_stride = k_slot_stride; p.ldk = ldk;
   p.v = (const bf16*)v_bank; p.v_slot_stride = v_slot_stride; p.ldv = ldv;
@@ -750,6 +835,7 @@ extern "C" int rmem_gated_attn(const void* q, int ldq, const void* k_bank, long 
   c.slabs = p.slabs; c.groups = g.groups; c.lpart = p.lpart; c.nrows = nrows; c.Lq = Lq; c.Lqp = g.Lqp; c.DV = DV;
   c.ua = (const bf16*)u_a; c.ldua = ldua; c.ub = (const bf16*)u_b; c.ldub = ldub; c.usplit = usplit;
   c.out = (bf16*)out; c.ldo = ldo; c.rows = chunks; c.mass = attn_mass; c.T = frames;
+  c.dw = dw_w_t; c.H = H; c.W = W;
   hipStream_t s = (hipStream_t)stream;
   const double flops = 2.0 * (double)Lq * (double)frames * (double)keys_per_frame * (double)DV;
   if (chunks) launch_all<1>(p, g, c, true, flops, s);
@@ -759,7 +845,7 @@ extern "C" int rmem_gated_attn(const void* q, int ldq, const void* k_bank, long 
 
 extern "C" int rmem_local_gated_attn(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const float* rel,
                                      int ldrel, int H, int W, int DV, const void* u_a, int ldua, const void* u_b, int ldub,
-                                     int usplit, void* out, int ldo, void* workspace, void* stream) {
+                                     int usplit, void* out, int ldo, const float* dw_w_t, void* workspace, void* stream) {
   const int L = H * W;
   if (check_common(q, ldq, k, ldk, v, ldv, L, DV, u_a, ldua, u_b, ldub, usplit, out, ldo, workspace, "rmem_local_gated_attn")) return -1;
   RMEM_REQUIRE(rel && H > 0 && W > 0 && W < 32768 && ldrel >= WIN * WIN, "rmem_local_gated_attn: bad rel / H / W");
@@ -781,6 +867,8 @@ extern "C" int rmem_local_gated_attn(const void* q, int ldq, const void* k, int 
   c.slabs = p.slabs; c.groups = g.groups; c.lpart = p.lpart; c.nrows = p.nrows; c.Lq = L; c.Lqp = g.Lqp; c.DV = DV;
   c.ua = (const bf16*)u_a; c.ldua = ldua; c.ub = (const bf16*)u_b; c.ldub = ldub; c.usplit = usplit;
   c.out = (bf16*)out; c.ldo = ldo;
+  RMEM_REQUIRE(!dw_w_t || usplit % 64 == 0, "rmem_local_gated_attn: the fused depth-wise conv needs usplit % 64 == 0");
+  c.dw = dw_w_t; c.H = H; c.W = W;
   launch_all<2>(p, g, c, false, 0.0, (hipStream_t)stream);
   return rmem_check_launch("rmem_local_gated_attn");
 }

@@ -87,9 +87,9 @@ class DeAOTRuntime(ClipRuntime):
         return self.qvu[i].view(-1)[D_ATT + E1:], QVU, (self.idu if i > 0 else None)
 
     def _tail(self, name: str, residual, **kw):
-        """depth-wise 5x5 + projection (attention.py:210-211) added into both residual streams."""
-        return [ops.dwconv5x5(self.g1, self.P[name + '_dw.w'], self.g2, H=self.H16, W=self.W16, C=E2),
-                self._lin(self.g2, name + '_proj', self.xc, self.L, E2, 2 * D_MODEL, residual=residual, **kw)]
+        """projection (attention.py:211) added into both residual streams; the depth-wise 5x5 before it (210) runs inside
+        the attention call's combine launch and leaves its result in g2."""
+        return [self._lin(self.g2, name + '_proj', self.xc, self.L, E2, 2 * D_MODEL, residual=residual, **kw)]
 
     def prog_lstt(self, ref_mode: bool, T: int, ref_slot: int = 0, want_mass: bool = True) -> list:
         key = f'lstt_ref{ref_slot}' if ref_mode else f'lstt_prop{T}{"m" if want_mass else ""}'
@@ -114,25 +114,26 @@ class DeAOTRuntime(ClipRuntime):
                 o += self._write_memory(i, self.bank_K[i][ref_slot], self.bank_V[i][ref_slot])
                 o += self._copy_memory(i, self.bank_K[i][ref_slot], self.bank_V[i][ref_slot], self.short_K[i], self.short_V[i])
             ua, ldua, ub = self._gate(i)
-            o.append(ops.gated_attn(self.qvu[i], self.bank_K[i], self.bank_V[i], ua, self.g1, self.gp_ws, Lq=L, DV=E2, ldq=QVU,
+            o.append(ops.gated_attn(self.qvu[i], self.bank_K[i], self.bank_V[i], ua, self.g2, self.gp_ws, Lq=L, DV=E2, ldq=QVU,
                                     ldk=D_ATT, ldv=E2, ldua=ldua, ldo=E2, k_slot_stride=L * D_ATT, v_slot_stride=L * E2,
                                     chunks=self.chunks, nchunks=nchunks, frames=frames, keys_per_frame=L, pe_cur=P['pe_cur'],
                                     pe_mem=P['pe_mem'], u_b=ub, ldub=E1, usplit=E1,
-                                    mass=self.mass if (i == 0 and not ref_mode and want_mass) else None))
+                                    mass=self.mass if (i == 0 and not ref_mode and want_mass) else None,
+                                    dw=P[d + '.long_dw.w'], H=self.H16, W=self.W16))
             o += self._tail(d + '.long', xin)
             o.append(self._lin(self.qvu[i], d + '.rel', self.rel, L, D_ATT, 225, ldo=REL_LD, ldx=QVU))
-            o.append(ops.local_gated_attn(self.qvu[i], self.short_K[i], self.short_V[i], self.rel, ua, self.g1, self.gp_ws,
+            o.append(ops.local_gated_attn(self.qvu[i], self.short_K[i], self.short_V[i], self.rel, ua, self.g2, self.gp_ws,
                                           H=self.H16, W=self.W16, DV=E2, ldq=QVU, ldk=D_ATT, ldv=E2, ldrel=REL_LD, ldua=ldua, ldo=E2,
-                                          u_b=ub, ldub=E1, usplit=E1))
+                                          u_b=ub, ldub=E1, usplit=E1, dw=P[d + '.short_dw.w']))
             o += self._tail(d + '.short', self.xc)
             # --- gated self-attention over [LN(tgt) | LN(tgt_id)] (1222-1232)
             o.append(ops.layernorm256(self.xc, P[d + '.ln2.g'], P[d + '.ln2.b'], M=L, lda=2 * C, y=self.xn, ldy=2 * C))
             o.append(ops.layernorm256(self.xc.view(-1)[C:], P[d + '.idn2.g'], P[d + '.idn2.b'], M=L, lda=2 * C,
                                       y=self.xn.view(-1)[C:], ldy=2 * C))
             o.append(self._lin(self.xn, d + '.self', self.sqvu, L, 2 * C, SQVU, relu=3, act_begin=D_ATT))
-            o.append(ops.gated_attn(self.sqvu, self.sqvu, self.sqvu.view(-1)[D_ATT:], self.sqvu.view(-1)[D_ATT + E2:], self.g1,
+            o.append(ops.gated_attn(self.sqvu, self.sqvu, self.sqvu.view(-1)[D_ATT:], self.sqvu.view(-1)[D_ATT + E2:], self.g2,
                                     self.gp_ws, Lq=L, DV=E2, ldq=SQVU, ldk=SQVU, ldv=SQVU, ldua=SQVU, ldo=E2, nchunks=8, frames=1,
-                                    keys_per_frame=L))
+                                    keys_per_frame=L, dw=P[d + '.self_dw.w'], H=self.H16, W=self.W16))
             o += self._tail(d + '.self', self.xc)
         o.append(ops.groupnorm(self.xc, P['dec_gn.g'], P['dec_gn.b'], self.dec_in, self.gn_ws, M=L, C=2 * C, groups=2))
         self._prog[key] = o

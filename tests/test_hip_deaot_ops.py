@@ -244,3 +244,24 @@ def test_linear_silu_act_begin_ldx(dev):
     ops.run(ops.linear(xd.view(-1)[256:], wt.to(BF16).to(dev), b.to(dev), y, M=M, K=K, N=N, relu=3, act_begin=128, ldx=512))
     torch.cuda.synchronize()
     assert_close(y, ref, 1e-2, 'silu/act_begin/ldx')
+
+
+@pytest.mark.parametrize('h,wd', [(9, 11), (31, 54)])
+def test_gated_attn_fused_dwconv_is_bit_identical(dev, h, wd):
+    """dw=...: the combine launch also applies the depth-wise 5x5 (through an LDS tile); same bits as combine + rmem_dwconv5x5."""
+    from rmem_ocu_amd import ops
+    T, L = 2, h * wd
+    q, k = rb(seeded(101, (L, 128))), rb(seeded(102, (T, L, 128)))
+    v, u = rb(seeded(103, (T, L, 1024))), rb(seeded(104, (L, 1024)))
+    dw = seeded(105, (25, 1024), 0.2).to(dev)
+    rows = frame_rows(T, L, 2)
+    ws = ops.gated_workspace(L, 1024, T, L, len(rows), dev)
+    a, b, c = (torch.zeros(L, 1024, dtype=BF16, device=dev) for _ in range(3))
+    common = dict(Lq=L, DV=1024, ldq=128, ldk=128, ldv=1024, ldua=512, ldo=1024, k_slot_stride=L * 128, v_slot_stride=L * 1024,
+                  chunks=chunk_table(rows, dev), nchunks=len(rows), frames=T, keys_per_frame=L, u_b=u[:, 512:].contiguous().to(BF16).to(dev),
+                  ldub=512, usplit=512)
+    args = (q.to(BF16).to(dev), k.to(BF16).to(dev), v.to(BF16).to(dev), u[:, :512].contiguous().to(BF16).to(dev))
+    ops.run([ops.gated_attn(*args, a, ws, **common), ops.dwconv5x5(a, dw, b, H=h, W=wd, C=1024)])
+    ops.run(ops.gated_attn(*args, c, ws, dw=dw, H=h, W=wd, **common))
+    torch.cuda.synchronize()
+    assert torch.equal(b, c)
