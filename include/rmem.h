@@ -103,6 +103,16 @@ int rmem_mem_read_attn(const void* q, int ldq,                     /* bf16 [Lq][
                        float* attn_mass, int T,                    /* fp32 [Lq][T] or NULL */
                        void* workspace, void* stream);
 
+/* The same for nclips independent clips of identical shape in ONE launch (clips of a group advance in lockstep): clip c's
+ * queries / one-frame keys / outputs sit c * {q, kv, out}_clip_stride elements further, its chunk-table rows are
+ * chunks[c * nchunks ...] (bank slots in them are global indexes into k_bank / v_bank), its mass is attn_mass + c * Lq * T,
+ * the workspace is nclips times rmem_attn_workspace_bytes. */
+int rmem_mem_read_attn_clips(const void* q, int ldq, const void* k_bank, const void* v_bank, long long slot_stride, int ldkv,
+                             const rmem_attn_chunk* chunks, int nchunks, int lk_single, const float* pe_cur, const float* pe_mem,
+                             int Lq, int heads, void* out, int ldo, float* attn_mass, int T, int nclips,
+                             long long q_clip_stride, long long kv_clip_stride, long long out_clip_stride,
+                             void* workspace, void* stream);
+
 /* Optional timing of the memory-read launches (chunks != NULL) with HIP events on the launch stream:
  * between start and stop every such launch outside a graph capture is bracketed by two events;
  * start() also calibrates what an event bracket costs around an empty kernel and stop() subtracts that per launch;
@@ -161,6 +171,14 @@ int rmem_groupnorm_nhwc(const void* x, int M, int C, int groups, const float* ga
  * stack (layers/transformer.py:755-758, 806-808; layers/basic.py:6-12). */
 int rmem_groupnorm_f32_nhwc(const float* x, int M, int C, int groups, const float* gamma, const float* beta,
                             float eps, int act, void* y, float* workspace, void* stream);
+
+/* Batched forms: x / y hold `images` maps back to back ([images][M][C]); statistics are per image.  workspace: images times
+ * rmem_groupnorm_workspace_bytes(groups). */
+int rmem_groupnorm_nhwc_images(const void* x, int images, int M, int C, int groups, const float* gamma, const float* beta,
+                               float eps, int act, void* y, float* workspace, void* stream);
+int rmem_gn_act_dwconv5x5_nhwc_images(const void* x, int images, int H, int W, int C, int groups, const float* gamma,
+                                      const float* beta, float eps, int act, const float* w_t, void* y, float* workspace, void* stream);
+int rmem_bilinear_nhwc_images(const void* x, void* y, int images, int Hi, int Wi, int Ho, int Wo, int C, int align_corners, void* stream);
 
 /* Depth-wise 5x5, pad 2, NHWC bf16; w_t is [25][C] fp32.  Replaces layers/basic.py:19-25, 33. */
 int rmem_dwconv5x5_nhwc(const void* x, const float* w_t, void* y, int H, int W, int C, void* stream);

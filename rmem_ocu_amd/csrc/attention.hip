@@ -49,6 +49,8 @@ struct AttnParams {
   float* opart; float* ml;
   float qscale;
   bf16* direct_out; int ldo;      // one chunk only: normalised bf16 output straight from this kernel (no combine launch)
+  // several clips in one launch (identical shapes; clip c's operands sit c * stride further, its chunk rows at c * nchunks)
+  int nclips; long q_cs, kv_cs, out_cs, opart_cs, ml_cs;
 };
 
 __device__ __forceinline__ int kswz(int row, int chunk) { return row * D + ((chunk ^ ((row >> 2) & 3)) << 3); }
@@ -71,7 +73,8 @@ __device__ __forceinline__ float pair_max(float x) {
 // TIMED changes nothing but the symbol: launches bracketed by rmem_profile_* HIP events use the <true, true> instance, so
 // a kernel trace of the same run lists exactly the launches bench.py timed under their own name.
 template <bool MEM, bool TIMED = false>
-__global__ __launch_bounds__(256) void k_attn_partial(AttnParams p) {
+__global__ __launch_bounds__(256) void k_attn_partial(AttnParams pin) {
+  AttnParams p = pin;
   __shared__ __attribute__((aligned(16))) bf16 Ks[2][KT * D];   // [key][32], 16-byte chunks XOR-swizzled
   __shared__ __attribute__((aligned(16))) bf16 Vs[2][KT * D];   // [key][32] row-major, read transposed (ds_read_b64_tr_b16)
 
@@ -82,14 +85,22 @@ __global__ __launch_bounds__(256) void k_attn_partial(AttnParams p) {
   // read the same K/V chunk run on one XCD and share its L2 (speed only; any placement is correct).
   int qt, head, c;
   {
-    const int nq = p.nq, total = nq * p.heads * p.nchunks;
+    const int nq = p.nq, total = nq * p.heads * p.nchunks * p.nclips;
     const int b = blockIdx.x, xcd = b & 7, j = b >> 3;
     const int qd = total >> 3, rm = total & 7;
     const int idx = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + j;
     const int pair = idx / nq;
     qt = idx - pair * nq;
     head = pair % p.heads;
-    c = pair / p.heads;
+    const int rest = pair / p.heads;
+    c = rest % p.nchunks;
+    const int clip = rest / p.nchunks;
+    p.q += clip * p.q_cs;
+    if (!MEM) { p.k += clip * p.kv_cs; p.v += clip * p.kv_cs; }
+    else p.chunks += clip * p.nchunks;          // bank slots in the table are global (clip * slots + slot)
+    p.opart += clip * p.opart_cs;
+    p.ml += clip * p.ml_cs;
+    if (p.direct_out) p.direct_out += clip * p.out_cs;
   }
 
   int slot, kb, kn, pe_slot;
@@ -260,12 +271,15 @@ struct CombineParams {
   int Lq, heads;
   bf16* out; int ldo;
   float* mass; int T;
+  long out_cs, opart_cs, ml_cs, mass_cs;     // per-clip strides (blockIdx.z = clip)
 };
 
 // merge the key chunks.  grid = (query blocks of 64, 16); thread = (query, head, 4 channels): consecutive lanes
 // read consecutive queries of the [chunk][head][G][q] partial layout.  Blocks with blockIdx.y == 0 also
 // reduce the per-chunk (m, l) pairs to the per-memory-frame probability mass (mean over heads).
-__global__ __launch_bounds__(256) void k_attn_combine(CombineParams p) {
+__global__ __launch_bounds__(256) void k_attn_combine(CombineParams pin) {
+  CombineParams p = pin;
+  p.opart += blockIdx.z * p.opart_cs; p.ml += blockIdx.z * p.ml_cs; p.out += blockIdx.z * p.out_cs;
   const int tid = threadIdx.x;
   const int ql = tid & 63;
   const int q = blockIdx.x * 64 + ql;
@@ -295,7 +309,9 @@ __global__ __launch_bounds__(256) void k_attn_combine(CombineParams p) {
 
 // per-memory-frame probability mass from the per-chunk (m, l) pairs: mass[q][t] = mean_h sum_{c in t} w_c l_c / den_h.
 // thread = (query, head pair); 64 queries per block
-__global__ __launch_bounds__(256) void k_attn_mass(CombineParams p) {
+__global__ __launch_bounds__(256) void k_attn_mass(CombineParams pin) {
+  CombineParams p = pin;
+  p.ml += blockIdx.z * p.ml_cs; p.chunks += blockIdx.z * p.nchunks; p.mass += blockIdx.z * p.mass_cs;
   __shared__ float macc[4][64][33];
   __shared__ int ct[32];
   const int tid = threadIdx.x, ql = tid & 63, hq = tid >> 6;
@@ -395,10 +411,13 @@ extern "C" size_t rmem_attn_workspace_bytes(int Lq, int heads, int nchunks) {
   return (size_t)nchunks * heads * Lq * (D + 2) * sizeof(float);
 }
 
-extern "C" int rmem_mem_read_attn(const void* q, int ldq, const void* k_bank, const void* v_bank, long long slot_stride,
-                                  int ldkv, const rmem_attn_chunk* chunks, int nchunks, int lk_single,
-                                  const float* pe_cur, const float* pe_mem, int Lq, int heads, void* out, int ldo,
-                                  float* attn_mass, int T, void* workspace, void* stream) {
+extern "C" int rmem_mem_read_attn_clips(const void* q, int ldq, const void* k_bank, const void* v_bank, long long slot_stride,
+                                        int ldkv, const rmem_attn_chunk* chunks, int nchunks, int lk_single,
+                                        const float* pe_cur, const float* pe_mem, int Lq, int heads, void* out, int ldo,
+                                        float* attn_mass, int T, int nclips, long long q_clip_stride, long long kv_clip_stride,
+                                        long long out_clip_stride, void* workspace, void* stream) {
+  RMEM_REQUIRE(nclips >= 1 && nclips <= 64, "rmem_mem_read_attn: 1..64 clips");
+  RMEM_REQUIRE(q_clip_stride % 8 == 0 && kv_clip_stride % 8 == 0 && out_clip_stride % 8 == 0, "rmem_mem_read_attn: clip strides must be multiples of 8 elements");
   const long long prof_keys = chunks ? (long long)lk_single : 0;   // with a chunk table lk_single carries the total key count (timing only)
   RMEM_REQUIRE(q && k_bank && v_bank && out && workspace, "rmem_mem_read_attn: null argument");
   RMEM_REQUIRE(heads >= 1 && heads <= 8, "rmem_mem_read_attn: heads must be in 1..8 (head dim is fixed at 32)");
@@ -416,13 +435,15 @@ extern "C" int rmem_mem_read_attn(const void* q, int ldq, const void* k_bank, co
   p.lk = lk_single; p.per_chunk = chunks ? 0 : (lk_single + nchunks - 1) / nchunks;
   RMEM_REQUIRE(chunks || (long)p.per_chunk * (nchunks - 1) < lk_single, "rmem_mem_read_attn: too many chunks for lk_single");
   p.pe_cur = pe_cur; p.pe_mem = pe_mem; p.Lq = Lq; p.heads = heads; p.C = heads * D;
-  p.opart = (float*)workspace; p.ml = p.opart + (size_t)nchunks * heads * Lq * D;
+  p.nclips = nclips; p.q_cs = q_clip_stride; p.kv_cs = kv_clip_stride; p.out_cs = out_clip_stride;
+  p.opart_cs = (long)nchunks * heads * Lq * D; p.ml_cs = (long)nchunks * heads * Lq * 2;
+  p.opart = (float*)workspace; p.ml = p.opart + (size_t)nclips * p.opart_cs;
   p.qscale = 1.4426950408889634f / sqrtf((float)D);
   p.nq = (Lq + 127) / 128;
   const bool direct = !chunks && nchunks == 1;          // a single key range: no partials to merge
   p.direct_out = direct ? (bf16*)out : nullptr;
   p.ldo = ldo;
-  dim3 grid(p.nq * heads * nchunks);
+  dim3 grid(p.nq * heads * nchunks * nclips);
   if (chunks) {
     // time this launch if asked to (never while the stream is being captured into a graph)
     long slot_i = -1;
@@ -440,7 +461,7 @@ extern "C" int rmem_mem_read_attn(const void* q, int ldq, const void* k_bank, co
     else hipLaunchKernelGGL((k_attn_partial<true, false>), grid, dim3(256), 0, s, p);
     if (slot_i >= 0) {
       (void)hipEventRecord(g_prof.ev[2 * slot_i + 1], s);
-      g_prof.flops[slot_i] = 4.0 * (double)Lq * keys * (double)(heads * D);   // QK^T + PV
+      g_prof.flops[slot_i] = 4.0 * (double)Lq * keys * (double)(heads * D) * nclips;   // QK^T + PV
     }
   } else {
     hipLaunchKernelGGL((k_attn_partial<false, false>), grid, dim3(256), 0, s, p);
@@ -449,7 +470,16 @@ extern "C" int rmem_mem_read_attn(const void* q, int ldq, const void* k_bank, co
   CombineParams cp;
   cp.opart = p.opart; cp.ml = p.ml; cp.chunks = chunks; cp.nchunks = nchunks; cp.Lq = Lq; cp.heads = heads;
   cp.out = (bf16*)out; cp.ldo = ldo; cp.mass = attn_mass; cp.T = T;
-  hipLaunchKernelGGL(k_attn_combine, dim3((Lq + 63) / 64, 16), dim3(256), 0, s, cp);
-  if (attn_mass) hipLaunchKernelGGL(k_attn_mass, dim3((Lq + 63) / 64), dim3(256), 0, s, cp);
+  cp.out_cs = out_clip_stride; cp.opart_cs = p.opart_cs; cp.ml_cs = p.ml_cs; cp.mass_cs = (long)Lq * T;
+  hipLaunchKernelGGL(k_attn_combine, dim3((Lq + 63) / 64, 16, nclips), dim3(256), 0, s, cp);
+  if (attn_mass) hipLaunchKernelGGL(k_attn_mass, dim3((Lq + 63) / 64, 1, nclips), dim3(256), 0, s, cp);
   return rmem_check_launch("rmem_mem_read_attn");
+}
+
+extern "C" int rmem_mem_read_attn(const void* q, int ldq, const void* k_bank, const void* v_bank, long long slot_stride,
+                                  int ldkv, const rmem_attn_chunk* chunks, int nchunks, int lk_single,
+                                  const float* pe_cur, const float* pe_mem, int Lq, int heads, void* out, int ldo,
+                                  float* attn_mass, int T, void* workspace, void* stream) {
+  return rmem_mem_read_attn_clips(q, ldq, k_bank, v_bank, slot_stride, ldkv, chunks, nchunks, lk_single, pe_cur, pe_mem, Lq, heads, out,
+                                  ldo, attn_mass, T, 1, 0, 0, 0, workspace, stream);
 }

@@ -166,8 +166,11 @@ __device__ __forceinline__ void gn_load8(const float* p, float (&f)[8]) {
 }
 
 // partial (sum, sumsq) per (group, split); deterministic two-stage reduction
+// blockIdx.z = image of a batch ([images][M][C]; statistics are per image and group)
 template <typename TI>
 __global__ __launch_bounds__(256) void k_gn_stats(const TI* x, int M, int C, int cpg, float* ws) {
+  x += (long)blockIdx.z * M * C;
+  ws += (long)blockIdx.z * gridDim.x * GN_SPLITS * 2;
   const int g = blockIdx.x, sp = blockIdx.y;
   const int vec = cpg / 8;                       // 16-byte pieces per pixel in this group
   const int rows_per = (M + GN_SPLITS - 1) / GN_SPLITS;
@@ -196,6 +199,9 @@ __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + er
 template <typename TI>
 __global__ __launch_bounds__(256) void k_gn_apply(const TI* x, int M, int C, int cpg, int groups, const float* ws,
                                                   const float* gamma, const float* beta, float eps, int act, bf16* y) {
+  x += (long)blockIdx.y * M * C;
+  y += (long)blockIdx.y * M * C;
+  ws += (long)blockIdx.y * groups * GN_SPLITS * 2;
   __shared__ float s_mean[64], s_rstd[64];
   if (threadIdx.x < groups) {
     float s = 0.f, ss = 0.f;
@@ -272,6 +278,9 @@ __global__ __launch_bounds__(256) void k_gn_dwconv5(const bf16* x, const float* 
   __shared__ __attribute__((aligned(16))) float wl[25 * DT_C];
   __shared__ float s_mean[8], s_rstd[8];
   const int tid = threadIdx.x;
+  x += (long)blockIdx.z * M * C;
+  y += (long)blockIdx.z * M * C;
+  ws += (long)blockIdx.z * (C / cpg) * GN_SPLITS * 2;
   const int tiles_x = (W + DT_W - 1) / DT_W;
   const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
   const int c0 = blockIdx.y * DT_C;
@@ -413,6 +422,27 @@ extern "C" int rmem_add_bf16_grouped(int n, const void* const* a, const void* co
 
 extern "C" size_t rmem_groupnorm_workspace_bytes(int groups) { return (size_t)groups * GN_SPLITS * 2 * sizeof(float); }
 
+static int gn_check(const void* x, const void* y, const float* gamma, const float* beta, const float* ws, int groups, int C, int act,
+                    int M, int images) {
+  RMEM_REQUIRE(x && y && gamma && beta && ws, "rmem_groupnorm: null argument");
+  RMEM_REQUIRE(groups >= 1 && groups <= 64 && C % groups == 0 && (C / groups) % 8 == 0,
+               "rmem_groupnorm: channels per group must be a multiple of 8 and groups <= 64");
+  RMEM_REQUIRE(act >= 0 && act <= 2 && M > 0 && images >= 1, "rmem_groupnorm: bad act / M / images");
+  return 0;
+}
+
+extern "C" int rmem_groupnorm_nhwc_images(const void* x, int images, int M, int C, int groups, const float* gamma, const float* beta,
+                                          float eps, int act, void* y, float* workspace, void* stream) {
+  if (gn_check(x, y, gamma, beta, workspace, groups, C, act, M, images)) return -1;
+  const int cpg = C / groups;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_gn_stats<bf16>, dim3(groups, GN_SPLITS, images), dim3(256), 0, s, (const bf16*)x, M, C, cpg, workspace);
+  const long total = (long)M * (C / 8);
+  const int blocks = (int)min((long)2048, (total + 255) / 256);
+  hipLaunchKernelGGL(k_gn_apply<bf16>, dim3(blocks, images), dim3(256), 0, s, (const bf16*)x, M, C, cpg, groups, workspace, gamma, beta, eps, act, (bf16*)y);
+  return rmem_check_launch("rmem_groupnorm_nhwc_images");
+}
+
 extern "C" int rmem_groupnorm_nhwc(const void* x, int M, int C, int groups, const float* gamma, const float* beta, float eps,
                                    int act, void* y, float* workspace, void* stream) {
   RMEM_REQUIRE(x && y && gamma && beta && workspace, "rmem_groupnorm_nhwc: null argument");
@@ -443,8 +473,18 @@ extern "C" int rmem_groupnorm_f32_nhwc(const float* x, int M, int C, int groups,
   return rmem_check_launch("rmem_groupnorm_f32_nhwc");
 }
 
+extern "C" int rmem_gn_act_dwconv5x5_nhwc_images(const void* x, int images, int H, int W, int C, int groups, const float* gamma,
+                                                 const float* beta, float eps, int act, const float* w_t, void* y, float* workspace,
+                                                 void* stream);
 extern "C" int rmem_gn_act_dwconv5x5_nhwc(const void* x, int H, int W, int C, int groups, const float* gamma, const float* beta,
                                           float eps, int act, const float* w_t, void* y, float* workspace, void* stream) {
+  return rmem_gn_act_dwconv5x5_nhwc_images(x, 1, H, W, C, groups, gamma, beta, eps, act, w_t, y, workspace, stream);
+}
+
+extern "C" int rmem_gn_act_dwconv5x5_nhwc_images(const void* x, int images, int H, int W, int C, int groups, const float* gamma,
+                                                 const float* beta, float eps, int act, const float* w_t, void* y, float* workspace,
+                                                 void* stream) {
+  RMEM_REQUIRE(images >= 1, "rmem_gn_act_dwconv5x5_nhwc: images must be >= 1");
   RMEM_REQUIRE(x && y && gamma && beta && w_t && workspace && H > 0 && W > 0, "rmem_gn_act_dwconv5x5_nhwc: bad argument");
   RMEM_REQUIRE(groups >= 1 && groups <= 64 && C % groups == 0 && C % DT_C == 0, "rmem_gn_act_dwconv5x5_nhwc: C must be a multiple of 64 and of groups (<= 64)");
   const int cpg = C / groups;
@@ -452,8 +492,8 @@ extern "C" int rmem_gn_act_dwconv5x5_nhwc(const void* x, int H, int W, int C, in
   RMEM_REQUIRE(act >= 0 && act <= 2, "rmem_gn_act_dwconv5x5_nhwc: bad act");
   const int M = H * W;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_gn_stats<bf16>, dim3(groups, GN_SPLITS), dim3(256), 0, s, (const bf16*)x, M, C, cpg, workspace);
-  const dim3 grid(((W + DT_W - 1) / DT_W) * ((H + DT_H - 1) / DT_H), C / DT_C);
+  hipLaunchKernelGGL(k_gn_stats<bf16>, dim3(groups, GN_SPLITS, images), dim3(256), 0, s, (const bf16*)x, M, C, cpg, workspace);
+  const dim3 grid(((W + DT_W - 1) / DT_W) * ((H + DT_H - 1) / DT_H), C / DT_C, images);
   hipLaunchKernelGGL(k_gn_dwconv5, grid, dim3(256), 0, s, (const bf16*)x, workspace, gamma, beta, eps, cpg, act, w_t, (bf16*)y, H, W, C, M);
   return rmem_check_launch("rmem_gn_act_dwconv5x5_nhwc");
 }

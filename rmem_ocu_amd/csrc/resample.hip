@@ -68,6 +68,8 @@ __global__ __launch_bounds__(256) void k_bilinear_nhwc(const bf16* x, bf16* y, i
   const long total = (long)Ho * Wo * vpr;
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
+  x += (long)blockIdx.y * Hi * Wi * C;            // blockIdx.y = image of a batch
+  y += (long)blockIdx.y * Ho * Wo * C;
   const int c0 = (int)(i % vpr) * 8;
   const int pix = (int)(i / vpr);
   const int oy = pix / Wo, ox = pix - oy * Wo;
@@ -317,10 +319,16 @@ extern "C" int rmem_maxpool3x3s2_nhwc(const void* x, void* y, int H, int W, int 
   return rmem_check_launch("rmem_maxpool3x3s2_nhwc");
 }
 
-extern "C" int rmem_bilinear_nhwc(const void* x, void* y, int Hi, int Wi, int Ho, int Wo, int C, int align_corners, void* stream) {
-  RMEM_REQUIRE(x && y && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C % 8 == 0, "rmem_bilinear_nhwc: bad argument");
-  hipLaunchKernelGGL(k_bilinear_nhwc, dim3(nblk((long)Ho * Wo * (C / 8))), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, (bf16*)y, Hi, Wi, Ho, Wo, C, align_corners);
+extern "C" int rmem_bilinear_nhwc_images(const void* x, void* y, int images, int Hi, int Wi, int Ho, int Wo, int C, int align_corners,
+                                         void* stream) {
+  RMEM_REQUIRE(x && y && images >= 1 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C % 8 == 0, "rmem_bilinear_nhwc: bad argument");
+  hipLaunchKernelGGL(k_bilinear_nhwc, dim3(nblk((long)Ho * Wo * (C / 8)), images), dim3(256), 0, (hipStream_t)stream, (const bf16*)x,
+                     (bf16*)y, Hi, Wi, Ho, Wo, C, align_corners);
   return rmem_check_launch("rmem_bilinear_nhwc");
+}
+
+extern "C" int rmem_bilinear_nhwc(const void* x, void* y, int Hi, int Wi, int Ho, int Wo, int C, int align_corners, void* stream) {
+  return rmem_bilinear_nhwc_images(x, y, 1, Hi, Wi, Ho, Wo, C, align_corners, stream);
 }
 
 extern "C" int rmem_logits_post(const float* logits_nhwc, int ldl, int num_classes, int keep_max_id, int Hi, int Wi, int Ho, int Wo,

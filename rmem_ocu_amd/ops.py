@@ -122,8 +122,8 @@ def layernorm256_pair(a0, b0, y0, a1, b1, y1, gamma, beta, *, M, eps=1e-5) -> Op
     return Op(_lib.lib().rmem_layernorm256_pair, args, 'rmem_layernorm256_pair', (a0, b0, y0, a1, b1, y1, gamma, beta))
 
 
-def attn_workspace(Lq: int, heads: int, nchunks: int, device) -> torch.Tensor:
-    n = _lib.lib().rmem_attn_workspace_bytes(Lq, heads, nchunks)
+def attn_workspace(Lq: int, heads: int, nchunks: int, device, nclips: int = 1) -> torch.Tensor:
+    n = nclips * _lib.lib().rmem_attn_workspace_bytes(Lq, heads, nchunks)
     return torch.empty(n // 4, dtype=F32, device=device)
 
 
@@ -136,15 +136,17 @@ def make_chunk_table(chunks: Sequence[Sequence[int]]) -> torch.Tensor:
 
 
 def mem_read_attn(q, k_bank, v_bank, out, workspace, *, Lq, heads=8, ldq, ldkv, ldo, slot_stride=0, chunks=None,
-                  nchunks=1, lk_single=0, pe_cur=None, pe_mem=None, mass=None, T=0) -> Op:
+                  nchunks=1, lk_single=0, pe_cur=None, pe_mem=None, mass=None, T=0, nclips=1, q_cs=0, kv_cs=0, out_cs=0) -> Op:
+    """nclips > 1: that many clips of identical shape in one launch (clip c's operands c * {q,kv,out}_cs elements further, its
+    chunk rows at chunks[c * nchunks:], its mass at mass[c * Lq * T:])."""
     _dev(q, k_bank, v_bank, out, workspace, chunks, pe_cur, pe_mem, mass)
     assert q.dtype == BF16 and k_bank.dtype == BF16 and v_bank.dtype == BF16 and out.dtype == BF16
-    assert workspace.numel() * 4 >= _lib.lib().rmem_attn_workspace_bytes(Lq, heads, nchunks)
-    assert chunks is None or (chunks.dtype == torch.int32 and chunks.numel() >= nchunks * 8)
-    assert mass is None or (mass.dtype == F32 and mass.numel() >= Lq * T)
+    assert workspace.numel() * 4 >= nclips * _lib.lib().rmem_attn_workspace_bytes(Lq, heads, nchunks)
+    assert chunks is None or (chunks.dtype == torch.int32 and chunks.numel() >= nclips * nchunks * 8)
+    assert mass is None or (mass.dtype == F32 and mass.numel() >= nclips * Lq * T)
     args = (_ptr(q), ldq, _ptr(k_bank), _ptr(v_bank), slot_stride, ldkv, _ptr(chunks), nchunks, lk_single,
-            _ptr(pe_cur), _ptr(pe_mem), Lq, heads, _ptr(out), ldo, _ptr(mass), T, _ptr(workspace))
-    return Op(_lib.lib().rmem_mem_read_attn, args, 'rmem_mem_read_attn',
+            _ptr(pe_cur), _ptr(pe_mem), Lq, heads, _ptr(out), ldo, _ptr(mass), T, nclips, q_cs, kv_cs, out_cs, _ptr(workspace))
+    return Op(_lib.lib().rmem_mem_read_attn_clips, args, 'rmem_mem_read_attn',
               (q, k_bank, v_bank, out, workspace, chunks, pe_cur, pe_mem, mass))
 
 
@@ -188,25 +190,32 @@ def add_bf16(a, b, y, n: int) -> Op:
     return Op(_lib.lib().rmem_add_bf16, (_ptr(a), _ptr(b), _ptr(y), n), 'rmem_add_bf16', (a, b, y))
 
 
-def groupnorm_workspace(groups: int, device) -> torch.Tensor:
-    return torch.empty(_lib.lib().rmem_groupnorm_workspace_bytes(groups) // 4, dtype=F32, device=device)
+def groupnorm_workspace(groups: int, device, images: int = 1) -> torch.Tensor:
+    return torch.empty(images * _lib.lib().rmem_groupnorm_workspace_bytes(groups) // 4, dtype=F32, device=device)
 
 
-def groupnorm(x, gamma, beta, y, ws, *, M, C, groups, act=0, eps=1e-5) -> Op:
+def groupnorm(x, gamma, beta, y, ws, *, M, C, groups, act=0, eps=1e-5, images=1) -> Op:
+    """images > 1: x / y are [images][M][C], statistics per image."""
     _dev(x, gamma, beta, y, ws)
     assert x.dtype in (BF16, F32) and y.dtype == BF16 and gamma.dtype == F32 and gamma.numel() == C
+    assert ws.numel() * 4 >= images * _lib.lib().rmem_groupnorm_workspace_bytes(groups)
+    if images > 1:
+        assert x.dtype == BF16
+        args = (_ptr(x), images, M, C, groups, _ptr(gamma), _ptr(beta), eps, act, _ptr(y), _ptr(ws))
+        return Op(_lib.lib().rmem_groupnorm_nhwc_images, args, 'rmem_groupnorm_nhwc', (x, gamma, beta, y, ws))
     args = (_ptr(x), M, C, groups, _ptr(gamma), _ptr(beta), eps, act, _ptr(y), _ptr(ws))
     if x.dtype == F32:
         return Op(_lib.lib().rmem_groupnorm_f32_nhwc, args, 'rmem_groupnorm_f32_nhwc', (x, gamma, beta, y, ws))
     return Op(_lib.lib().rmem_groupnorm_nhwc, args, 'rmem_groupnorm_nhwc', (x, gamma, beta, y, ws))
 
 
-def gn_act_dwconv5x5(x, gamma, beta, w_t, y, ws, *, H, W, C, groups, act=2, eps=1e-5) -> Op:
+def gn_act_dwconv5x5(x, gamma, beta, w_t, y, ws, *, H, W, C, groups, act=2, eps=1e-5, images=1) -> Op:
     """y = dwconv5x5(act(GroupNorm(x))): statistics launch + one fused normalise / activate / convolve launch."""
     _dev(x, gamma, beta, w_t, y, ws)
     assert x.dtype == BF16 and y.dtype == BF16 and w_t.dtype == F32 and w_t.numel() == 25 * C and gamma.numel() == C
-    args = (_ptr(x), H, W, C, groups, _ptr(gamma), _ptr(beta), eps, act, _ptr(w_t), _ptr(y), _ptr(ws))
-    return Op(_lib.lib().rmem_gn_act_dwconv5x5_nhwc, args, 'rmem_gn_act_dwconv5x5_nhwc', (x, gamma, beta, w_t, y, ws))
+    assert ws.numel() * 4 >= images * _lib.lib().rmem_groupnorm_workspace_bytes(groups)
+    args = (_ptr(x), images, H, W, C, groups, _ptr(gamma), _ptr(beta), eps, act, _ptr(w_t), _ptr(y), _ptr(ws))
+    return Op(_lib.lib().rmem_gn_act_dwconv5x5_nhwc_images, args, 'rmem_gn_act_dwconv5x5_nhwc', (x, gamma, beta, w_t, y, ws))
 
 
 def dwconv5x5(x, w_t, y, *, H, W, C) -> Op:
@@ -234,10 +243,11 @@ def maxpool3x3s2(x, y, *, H, W, C) -> Op:
     return Op(_lib.lib().rmem_maxpool3x3s2_nhwc, (_ptr(x), _ptr(y), H, W, C), 'rmem_maxpool3x3s2_nhwc', (x, y))
 
 
-def bilinear(x, y, *, Hi, Wi, Ho, Wo, C, align_corners=True) -> Op:
+def bilinear(x, y, *, Hi, Wi, Ho, Wo, C, align_corners=True, images=1) -> Op:
     _dev(x, y)
-    assert x.dtype == BF16 and y.dtype == BF16
-    return Op(_lib.lib().rmem_bilinear_nhwc, (_ptr(x), _ptr(y), Hi, Wi, Ho, Wo, C, int(align_corners)), 'rmem_bilinear_nhwc', (x, y))
+    assert x.dtype == BF16 and y.dtype == BF16 and x.numel() >= images * Hi * Wi * C and y.numel() >= images * Ho * Wo * C
+    return Op(_lib.lib().rmem_bilinear_nhwc_images, (_ptr(x), _ptr(y), images, Hi, Wi, Ho, Wo, C, int(align_corners)),
+              'rmem_bilinear_nhwc', (x, y))
 
 
 def logits_post(logits, *, ldl, nc, keep, Hi, Wi, Ho, Wo, align_corners=True, out=None, label_u8=None, label_f32=None) -> Op:

@@ -476,3 +476,56 @@ def test_gn_act_dwconv_fused_is_bit_identical(dev, H, W, C, groups, act):
     ops.run(ops.gn_act_dwconv5x5(x, g, b, wt, y1, ws, H=H, W=W, C=C, groups=groups, act=act))
     torch.cuda.synchronize()
     assert torch.equal(y0, y1)
+
+
+def test_batched_forms_match_single_launches(dev):
+    """images / clips > 1 (several clips per launch): GroupNorm, the fused GN + dw-conv, bilinear and both attention flavours give
+    bit-identical results to one launch per clip."""
+    from rmem_ocu_amd import ops
+    B, H, W, C = 3, 9, 14, 256
+    M = H * W
+    x = rb(seeded(81, (B, M, C), 2.0)).to(BF16).to(dev)
+    g, b = (1 + seeded(82, (C,), 0.1)).to(dev), seeded(83, (C,), 0.1).to(dev)
+    wt = seeded(84, (25, C), 0.2).to(dev)
+    ws = ops.groupnorm_workspace(8, dev, images=B)
+    yb, y1 = torch.zeros(B, M, C, dtype=BF16, device=dev), torch.zeros(B, M, C, dtype=BF16, device=dev)
+    ops.run(ops.groupnorm(x, g, b, yb, ws, M=M, C=C, groups=8, act=1, images=B))
+    ops.run([ops.groupnorm(x[i], g, b, y1[i], ws, M=M, C=C, groups=8, act=1) for i in range(B)])
+    torch.cuda.synchronize()
+    assert torch.equal(yb, y1)
+    ops.run(ops.gn_act_dwconv5x5(x, g, b, wt, yb, ws, H=H, W=W, C=C, groups=8, act=2, images=B))
+    ops.run([ops.gn_act_dwconv5x5(x[i], g, b, wt, y1[i], ws, H=H, W=W, C=C, groups=8, act=2) for i in range(B)])
+    torch.cuda.synchronize()
+    assert torch.equal(yb, y1)
+    ub, u1 = torch.zeros(B, 17 * 27, C, dtype=BF16, device=dev), torch.zeros(B, 17 * 27, C, dtype=BF16, device=dev)
+    ops.run(ops.bilinear(x, ub, Hi=H, Wi=W, Ho=17, Wo=27, C=C, images=B))
+    ops.run([ops.bilinear(x[i], u1[i], Hi=H, Wi=W, Ho=17, Wo=27, C=C) for i in range(B)])
+    torch.cuda.synchronize()
+    assert torch.equal(ub, u1)
+    # attention: one-frame flavour (direct output) and memory read over per-clip banks with different slot orders
+    L, T, S = 150, 3, 4
+    q = rb(seeded(85, (B, L, 768))).to(BF16).to(dev)
+    ob, o1 = torch.zeros(B, L, 256, dtype=BF16, device=dev), torch.zeros(B, L, 256, dtype=BF16, device=dev)
+    wsa = ops.attn_workspace(L, 8, 8, dev, nclips=B)
+    ops.run(ops.mem_read_attn(q, q.view(-1)[256:], q.view(-1)[512:], ob, wsa, Lq=L, ldq=768, ldkv=768, ldo=256, nchunks=1, lk_single=L,
+                              nclips=B, q_cs=L * 768, kv_cs=L * 768, out_cs=L * 256))
+    ops.run([ops.mem_read_attn(q[i], q[i].view(-1)[256:], q[i].view(-1)[512:], o1[i], wsa, Lq=L, ldq=768, ldkv=768, ldo=256, nchunks=1,
+                               lk_single=L) for i in range(B)])
+    torch.cuda.synchronize()
+    assert torch.equal(ob, o1)
+    kb = rb(seeded(86, (B * S, L, 256))).to(BF16).to(dev)
+    vb = rb(seeded(87, (B * S, L, 256))).to(BF16).to(dev)
+    pe_cur, pe_mem = seeded(88, (256,), 0.3).to(dev), seeded(89, (4, 256), 0.3).to(dev)
+    orders = [[0, 1, 2], [3, 0, 2], [1, 3, 0]]
+    rows = [(c * S + orders[c][t], 0, L, t, t) for c in range(B) for t in range(T)]
+    tab = ops.make_chunk_table(rows).to(dev)
+    mb, m1 = torch.zeros(B, L, T, dtype=F32, device=dev), torch.zeros(B, L, T, dtype=F32, device=dev)
+    qq = q[:, :, :256].contiguous()
+    ops.run(ops.mem_read_attn(qq, kb, vb, ob, wsa, Lq=L, ldq=256, ldkv=256, ldo=256, slot_stride=L * 256, chunks=tab, nchunks=T,
+                              lk_single=T * L, pe_cur=pe_cur, pe_mem=pe_mem, mass=mb, T=T, nclips=B, q_cs=L * 256, out_cs=L * 256))
+    for c in range(B):
+        tc = ops.make_chunk_table(rows[c * T:(c + 1) * T]).to(dev)
+        ops.run(ops.mem_read_attn(qq[c], kb, vb, o1[c], wsa, Lq=L, ldq=256, ldkv=256, ldo=256, slot_stride=L * 256, chunks=tc, nchunks=T,
+                                  lk_single=T * L, pe_cur=pe_cur, pe_mem=pe_mem, mass=m1[c], T=T))
+    torch.cuda.synchronize()
+    assert torch.equal(ob, o1) and torch.equal(mb, m1)
