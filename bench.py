@@ -98,9 +98,11 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--workload', default='davis17_480p_r50_N8', choices=sorted(WORKLOADS))
     ap.add_argument('--no-graphs', action='store_true')
+    ap.add_argument('--clips-per-group', type=int, default=int(os.environ.get('RMEM_CLIPS_PER_GROUP', 4)),
+                    help='> 1: that many clips advance in lockstep on one GroupEngine (one launch per layer for the group); R50-AOTL only')
     ap.add_argument('--host-frames', action='store_true',
                     help='PCIe-inclusive variant (not the contract line): frames start as decoded uint8 RGB in pinned host memory')
-    ap.add_argument('--encoder-lookahead', type=int, default=int(os.environ.get('RMEM_ENC_LOOKAHEAD', 4)),
+    ap.add_argument('--encoder-lookahead', type=int, default=int(os.environ.get('RMEM_ENC_LOOKAHEAD', 2)),
                     help='frames the ResNet-50 encoder runs ahead inside a clip (one launch per layer for all of them)')
     ap.add_argument('--sample-every', type=int, default=100, help='time the memory-read kernel on 1 in N timed frames (run in isolation)')
     args = ap.parse_args()
@@ -158,22 +160,36 @@ def main():
 
     C = max(1, args.clips_in_flight)
     lookahead = args.encoder_lookahead if cfg.MODEL_ENCODER == 'resnet50' else 1      # the batched encoder is the ResNet-50 one
+    G = args.clips_per_group if (wl['model'] == 'r50_aotl' and not args.host_frames) else 1
     slots = []
-    for j in range(C):
-        eng = build_engine(cfg.MODEL_ENGINE, phase='eval', aot_model=model, gpu_id=local_rank, long_term_mem_gap=5)
-        eng.set_async(use_graphs=not args.no_graphs)
-        slots.append(ClipSlot(eng, VIDEO_HW, dev, lookahead=lookahead))
+    if G > 1:
+        from rmem_ocu_amd.clip_runner import GroupSlot
+        from rmem_ocu_amd.networks.engines.group_engine import GroupEngine
+        C = max(1, C // G)                    # C groups of G clips each
+        for j in range(C):
+            eng = GroupEngine(model, G, local_rank, 5, lookahead=lookahead)
+            eng.use_graphs = not args.no_graphs
+            slots.append(GroupSlot(eng, VIDEO_HW, dev))
+        inner_of = lambda s: s.engine                                            # noqa: E731
+        start = lambda s, k: s.start([clips[(k + c) % 2][0] for c in range(G)], [clips[(k + c) % 2][1] for c in range(G)], NUM_OBJS)  # noqa: E731
+    else:
+        for j in range(C):
+            eng = build_engine(cfg.MODEL_ENGINE, phase='eval', aot_model=model, gpu_id=local_rank, long_term_mem_gap=5)
+            eng.set_async(use_graphs=not args.no_graphs)
+            slots.append(ClipSlot(eng, VIDEO_HW, dev, lookahead=lookahead))
+        inner_of = lambda s: s.engine.aot_engines[0]                             # noqa: E731
+        start = lambda s, k: s.start(*clips[k % 2], NUM_OBJS)                    # noqa: E731
 
     # ---- priming (untimed setup): every slot runs one whole clip, interleaved exactly like the timed region, which builds
     # every launch list / hipGraph (T = 1..8); then the slots are staggered so they sit at different clip positions ----
     for j, s in enumerate(slots):
-        s.start(*clips[j % 2], NUM_OBJS)
+        start(s, j)
     while not all(s.done for s in slots):
         for s in slots:
             if not s.done:
                 s.step()
     for j, s in enumerate(slots):
-        s.start(*clips[j % 2], NUM_OBJS)
+        start(s, j)
     for k in range(CLIP_LEN - 1):
         for j, s in enumerate(slots):
             if k < (j * (CLIP_LEN - 1)) // C:
@@ -183,6 +199,7 @@ def main():
     next_clip = [0]
 
     def run_steps(n, sample_every=0):
+        """n propagated frames in total (a group step propagates G frames)."""
         done = 0
         j = 0
         while done < n:
@@ -190,9 +207,9 @@ def main():
             j += 1
             if s.done:
                 next_clip[0] += 1
-                s.start(*clips[next_clip[0] % 2], NUM_OBJS)      # reference frame: executed, not counted
-            inner = s.engine.aot_engines[0]
-            eager = sample_every and (done % sample_every == sample_every // 2)
+                start(s, next_clip[0])      # reference frame(s): executed, not counted
+            inner = inner_of(s)
+            eager = sample_every and (done % sample_every) < G and done >= sample_every // 2
             if eager:
                 # roofline sample: this frame runs alone on the GPU as direct launches, its memory-read kernels bracketed by
                 # HIP events (symbol k_attn_partial<true, true>), so the event time is the kernel's own duration
@@ -202,7 +219,7 @@ def main():
             if eager:
                 inner.use_graphs = not args.no_graphs
                 inner.stream.synchronize()
-            done += 1
+            done += G
 
     run_steps(args.warmup)
     torch.cuda.synchronize()
@@ -242,7 +259,7 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
             'config': {'workload': args.workload, 'clip_frames': CLIP_LEN, 'video_hw': list(VIDEO_HW), 'network_hw': list(net_hw),
                        'tokens': (net_hw[0] // 16 if wl['net'] else 31) * (net_hw[1] // 16 if wl['net'] else 54), 'objects': NUM_OBJS,
-                       'memory_bank': f"{wl['former']}+{wl['latter']}", 'gap': max(int(round(CLIP_LEN / 30)), 5), 'clips_in_flight_per_gpu': C,
+                       'memory_bank': f"{wl['former']}+{wl['latter']}", 'gap': max(int(round(CLIP_LEN / 30)), 5), 'clips_in_flight_per_gpu': C * G, 'clips_per_group': G, 'frames_executed_in_timed_region': -(-args.steps // G) * G,
                        'parallelism': f'clip-parallel x{world}', 'weights': 'synthetic (no checkpoint offline)',
                        'hipgraphs': not args.no_graphs, 'frames_from': 'pinned host uint8 (PCIe-inclusive)' if args.host_frames else 'HBM', 'encoder_lookahead': lookahead, 'host_enqueue_ms_per_step': round(1e3 * host_enqueue / args.steps, 4)},
             'roofline': {'bound': 'mfma', 'kernel': 'k_gp_pv<1, true>' if deaot else 'k_attn_partial<true, true>', 'achieved': None if achieved is None else round(achieved, 2),

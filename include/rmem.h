@@ -216,6 +216,11 @@ int rmem_local_gated_attn(const void* q, int ldq, const void* k, int ldk, const 
 /* HIP-event timing of the k_gp_pv launches of rmem_gated_attn calls that carry a chunk table (bench.py's roofline leg) */
 int rmem_gated_profile_start(void);
 int rmem_gated_profile_stop(double* total_ms, double* total_flops, int* launches);
+/* Memory-bank append for a group of clips: block c of src ([nclips][block_bytes], the new K or V entries of all clips) goes to
+ * dst + slots_dev[c] * slot_bytes.  slots_dev is a device table, so one captured launch serves whatever slots the clips'
+ * eviction policies have freed (layers/transformer.py:305-322 appends, 432-433 removes). */
+int rmem_scatter_blocks(const void* src, void* dst, const int* slots_dev, int nclips, long long block_bytes, long long slot_bytes,
+                        void* stream);
 /* strided 2-D device copy (rows of row_bytes): the torch.cat / slice bookkeeping of transformer.py:840-872 */
 int rmem_copy2d_async(void* dst, long long dst_pitch, const void* src, long long src_pitch, long long row_bytes, int rows, void* stream);
 

@@ -66,6 +66,7 @@ SIGNATURES = {
     'rmem_tta_merge': (_i, [C.POINTER(_vp), C.POINTER(_i), _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     'rmem_mask_iou_counts': (_i, [_vp, _vp, _ll, _i, _i, _vp, _vp]),
     'rmem_copy_async': (_i, [_vp, _vp, C.c_size_t, _vp]),
+    'rmem_scatter_blocks': (_i, [_vp, _vp, _vp, _i, _ll, _ll, _vp]),
     'rmem_copy2d_async': (_i, [_vp, _ll, _vp, _ll, _ll, _i, _vp]),
     'rmem_gated_attn_workspace_bytes': (C.c_size_t, [_i, _i, _i, _i, _i]),
     'rmem_gated_attn': (_i, [_vp, _i, _vp, _ll, _i, _vp, _ll, _i, _vp, _i, _i, _i, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _i, _vp, _i,

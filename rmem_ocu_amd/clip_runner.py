@@ -126,3 +126,62 @@ class ClipSlot:
         ops.copy_async(self.labels[i], self.cur_label, self.cur_label.numel())(self.engine.aot_engines[0].stream.cuda_stream)
         self.cursor += 1
         self.done = self.cursor >= self.frames.shape[0]
+
+
+class GroupSlot:
+    """B clips of equal length in flight on one GroupEngine (networks/engines/group_engine.py): same protocol as ClipSlot, one
+    launch per layer for the whole group."""
+
+    def __init__(self, engine, out_hw, device):
+        self.engine = engine
+        self.B = engine.B
+        self.out_hw = out_hw
+        self.device = device
+        self.cur_label = torch.zeros(self.B, out_hw[0], out_hw[1], dtype=torch.uint8, device=device)   # fixed address (graph-captured)
+        self.labels: Optional[torch.Tensor] = None
+        self.frames = None
+        self.cursor = 0
+        self.done = True
+
+    def start(self, frames: Sequence[torch.Tensor], first_masks: Sequence[torch.Tensor], num_objs: int):
+        """frames: B tensors [n, 3, H, W] fp32 device (equal n); first_masks: B tensors [1, 1, H, W] at the network size."""
+        assert len(frames) == self.B and len({int(f.shape[0]) for f in frames}) == 1
+        n = int(frames[0].shape[0])
+        self.frames = list(frames)
+        if self.labels is None or self.labels.shape[1] < n:
+            self.labels = torch.zeros(self.B, n, self.out_hw[0], self.out_hw[1], dtype=torch.uint8, device=self.device)
+        eng = self.engine
+        eng.restart_engine()
+        eng.long_term_mem_gap = max(int(round(n / 30)), 5)      # evaluator.py:330-335
+        with torch.cuda.stream(eng.stream):
+            imgs = torch.cat([f[0:1] for f in frames], 0)
+            masks = torch.cat([m.reshape(1, 1, m.shape[-2], m.shape[-1]).float() for m in first_masks], 0)
+        eng.add_reference_frames(imgs, masks, num_objs)
+        self.cursor = 1
+        self.done = n <= 1
+
+    def step(self):
+        eng, B, i = self.engine, self.B, self.cursor
+        la = eng.lookahead
+        s = eng.stream.cuda_stream
+        if la > 1:
+            e = (i - 1) % la
+            if e == 0:
+                dst = eng.encode_inputs()
+                n = self.frames[0].shape[0]
+                m = min(la, n - i)
+                fb = dst[0].numel() * 4
+                for c in range(B):
+                    for k in range(m):
+                        ops.copy_async(dst[k * B + c], self.frames[c][i + k], fb)(s)
+                eng.encode_ahead()
+            eng.propagate_to_labels(self.cur_label, enc_slot=e)
+        else:
+            with torch.cuda.stream(eng.stream):
+                imgs = torch.cat([f[i:i + 1] for f in self.frames], 0)
+            eng.propagate_to_labels(self.cur_label, imgs=imgs)
+        eng.update_from_labels(self.cur_label)
+        for c in range(B):
+            ops.copy_async(self.labels[c, i], self.cur_label[c], self.cur_label[c].numel())(s)
+        self.cursor += 1
+        self.done = self.cursor >= self.frames[0].shape[0]

@@ -304,7 +304,29 @@ __global__ __launch_bounds__(256) void k_ingest(const uint8_t* src, int Hs, int 
 
 inline unsigned nblk(long total) { return (unsigned)((total + 255) / 256); }
 
+// block c of src ([nclips][block_bytes]) -> dst + slots[c] * slot_bytes; slots is a DEVICE table (a captured graph stays valid
+// while the clips' free bank slots diverge after evictions); slots[c] < 0 skips the clip
+__global__ __launch_bounds__(256) void k_scatter_blocks(const uint4* src, uint4* dst, const int* slots, long block16, long slot16) {
+  const int c = blockIdx.y;
+  const int sl = slots[c];
+  if (sl < 0) return;
+  const uint4* s = src + (long)c * block16;
+  uint4* d = dst + (long)sl * slot16;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < block16; i += (long)gridDim.x * 256) d[i] = s[i];
+}
+
 }  // namespace
+
+extern "C" int rmem_scatter_blocks(const void* src, void* dst, const int* slots_dev, int nclips, long long block_bytes,
+                                   long long slot_bytes, void* stream) {
+  RMEM_REQUIRE(src && dst && slots_dev && nclips >= 1 && block_bytes > 0 && block_bytes % 16 == 0 && slot_bytes % 16 == 0,
+               "rmem_scatter_blocks: bad argument (sizes must be multiples of 16 bytes)");
+  const long b16 = block_bytes / 16;
+  const int blocks = (int)min((long)256, (b16 + 255) / 256);
+  hipLaunchKernelGGL(k_scatter_blocks, dim3(blocks, nclips), dim3(256), 0, (hipStream_t)stream, (const uint4*)src, (uint4*)dst, slots_dev,
+                     b16, slot_bytes / 16);
+  return rmem_check_launch("rmem_scatter_blocks");
+}
 
 extern "C" int rmem_image_to_nhwc8(const float* img_chw, void* out, int H, int W, void* stream) {
   RMEM_REQUIRE(img_chw && out && H > 0 && W > 0, "rmem_image_to_nhwc8: bad argument");

@@ -1,0 +1,303 @@
+"""Device state and launch lists for a GROUP of clips that advance in lockstep (R50-AOTL path).
+
+At HW = 1674 tokens a launch costs about as much as its arithmetic and only four kernels are in flight on the GPU
+(DESIGN.md §7b), so the throughput path does not run one clip per launch list: B clips of equal length share one
+``GroupRuntime``.  Every activation buffer of runtime.ClipRuntime gets a leading clip dimension ([B * rows, C], clip-major),
+which turns
+
+    every linear / LayerNorm / add      into the same launch over B * HW rows,
+    every convolution                   into one launch over a batch of B images (rmem_conv_desc.batch),
+    GroupNorm / depth-wise / bilinear   into the per-image batched forms (statistics per clip),
+    the three attentions                into one launch with a clip dimension (rmem_mem_read_attn_clips).
+
+The clips are independent; what differs between them is the memory bank's content and, after evictions, its slot order:
+the bank is [B * slots, HW, 256] per layer, clip c owns slots c * S .. c * S + S - 1, the chunk table has one block of rows
+per clip, and appends go through a device table of destination slots (rmem_scatter_blocks), so ONE captured hipGraph per
+bank size serves the whole group.  Frame counters, append schedule and bank size T are the same for all clips of a group
+(equal length => same gap, evaluator.py:330-335); the eviction decision is per clip (engines/group_engine.py).
+
+The per-op arithmetic is exactly ClipRuntime's (same kernels, same operands per clip), cf. the citations there.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import ops
+from .encoder_batch import BatchEncoder
+from .pack import R50_BLOCKS, R50_STRIDES
+from .runtime import BF16, D_MODEL, F32, FFN, HEADS, MAX_CHUNKS, PLAIN_CHUNKS, _out, sine_pos_emb, temporal_slots
+
+
+class GroupRuntime:
+    def __init__(self, P: Dict[str, torch.Tensor], in_hw: Tuple[int, int], bank_slots: int, device, clips: int,
+                 num_lstt: int = 3, align_corners: bool = True, num_classes: int = 11, lookahead: int = 4):
+        if 'pe.w' in P or 'g0.qvu.w' in P:
+            raise ops.RmemError('GroupRuntime covers the R50-AOTL path')
+        self.P, self.dev, self.NL, self.B = P, device, num_lstt, clips
+        self.align, self.nc = align_corners, num_classes
+        H, W = in_hw
+        self.H, self.W = H, W
+        B = clips
+        self.H2, self.W2 = _out(H, 7, 2, 3), _out(W, 7, 2, 3)
+        self.H4, self.W4 = _out(self.H2, 3, 2, 1), _out(self.W2, 3, 2, 1)
+        self.H8, self.W8 = _out(self.H4, 3, 2, 1), _out(self.W4, 3, 2, 1)
+        self.H16, self.W16 = _out(self.H8, 3, 2, 1), _out(self.W8, 3, 2, 1)
+        self.L = self.H16 * self.W16
+        L, M4, M8 = self.L, self.H4 * self.W4, self.H8 * self.W8
+        self.M4, self.M8 = M4, M8
+        e = lambda *shape, dt=BF16: torch.empty(*shape, dtype=dt, device=device)  # noqa: E731
+        # ---- encoders: one for the frame in flight (reference frames), one running `lookahead` frames ahead; image = e * B + c
+        self.enc_now = BatchEncoder(P, in_hw, B, device)
+        self.lookahead = lookahead
+        self.enc_ahead = BatchEncoder(P, in_hw, B * lookahead, device) if lookahead > 1 else None
+        # ---- LSTT buffers, [B * L, .] clip-major ----
+        R = B * L
+        self.x = e(R, D_MODEL, dt=F32)
+        self.dec_in = e(R, 4 * D_MODEL)
+        self.t1b = e(R, D_MODEL)
+        self.qkv = e(R, 3 * D_MODEL)
+        self.att = e(R, D_MODEL)
+        self.t3 = e(R, D_MODEL)
+        self.k4, self.v4 = e(R, D_MODEL), e(R, D_MODEL)
+        self.h1, self.h3 = e(R, FFN), e(R, FFN)
+        self.curr_Q = [e(R, D_MODEL) for _ in range(num_lstt)]
+        self.curr_V = [e(R, D_MODEL) for _ in range(num_lstt)]
+        self.new_V = [e(R, D_MODEL) for _ in range(num_lstt)]       # linear_V(curr_V + id): the bank entry before it is scattered
+        self.tgt3 = [e(R, D_MODEL) for _ in range(num_lstt)]
+        self.short_K = [e(R, D_MODEL) for _ in range(num_lstt)]
+        self.short_V = [e(R, D_MODEL) for _ in range(num_lstt)]
+        self.tmpA = [e(R, D_MODEL) for _ in range(num_lstt)]
+        self.tmpB = [e(R, D_MODEL) for _ in range(num_lstt)]
+        self.id_emb = e(R, D_MODEL)
+        self.onehot = e(B * H * W, 16)
+        pos = sine_pos_emb(self.H16, self.W16).to(device)
+        self.posb = pos.to(BF16).repeat(B, 1).contiguous()
+        self.pos_qk = [torch.zeros(R, 3 * D_MODEL, dtype=F32, device=device) for _ in range(num_lstt)]
+        self._pos_ready = False
+        self.attn_ws = ops.attn_workspace(L, HEADS, MAX_CHUNKS, device, nclips=B)
+        self.gn_ws = ops.groupnorm_workspace(32, device, images=B)
+        self.conv_ws = torch.empty(16 * R * D_MODEL, dtype=F32, device=device)
+        self.mass = torch.zeros(B * L * MAX_CHUNKS, dtype=F32, device=device)          # [B][L][T] compact for the current T
+        self.scores = torch.zeros(B, 32 + 64 * 32, dtype=F32, device=device)
+        self.scores_host = torch.zeros(B, MAX_CHUNKS, dtype=F32).pin_memory()
+        # ---- decoder buffers ----
+        self.d16a, self.d16b = e(R, 256), e(R, 256)
+        self.d8a, self.d8b = e(B * M8, 256), e(B * M8, 256)
+        self.d4a, self.d4b = e(B * M4, 128), e(B * M4, 128)
+        self.logits = torch.zeros(B * M4, 16, dtype=F32, device=device)
+        # ---- memory bank: [B * S, L, 256] per layer, clip c owns slots c * S .. ----
+        self.S = bank_slots
+        self.bank_K = [e(B * bank_slots, L, D_MODEL) for _ in range(num_lstt)]
+        self.bank_V = [e(B * bank_slots, L, D_MODEL) for _ in range(num_lstt)]
+        self.slots: List[List[int]] = [[] for _ in range(B)]            # per clip: logical order t -> local slot
+        self.free: List[List[int]] = [list(range(bank_slots)) for _ in range(B)]
+        self.chunks = torch.zeros(B * MAX_CHUNKS, 8, dtype=torch.int32, device=device)
+        self.chunks_host = torch.zeros(8, B * MAX_CHUNKS, 8, dtype=torch.int32).pin_memory()
+        self.append_slots = torch.full((B,), -1, dtype=torch.int32, device=device)   # global destination slot per clip
+        self.append_host = torch.zeros(8, B, dtype=torch.int32).pin_memory()
+        self._stage = 0
+        self._prog: Dict[str, list] = {}
+
+    # ------------------------------------------------------------------ bank bookkeeping (host) + device tables
+    def reset_bank(self):
+        self.slots = [[] for _ in range(self.B)]
+        self.free = [list(range(self.S)) for _ in range(self.B)]
+
+    @property
+    def T(self) -> int:
+        return len(self.slots[0])
+
+    def chunk_plan(self, T: int) -> Tuple[int, int]:
+        if T > MAX_CHUNKS:
+            raise ops.RmemError(f'memory bank of {T} frames exceeds the {MAX_CHUNKS}-chunk table')
+        splits = max(1, min(8 // T, MAX_CHUNKS // T))
+        return splits, T * splits
+
+    def upload_chunks(self, stream: int):
+        """One block of rows per clip for the current (equal) bank size; bank slots are global indexes c * S + local slot."""
+        T = self.T
+        assert all(len(s) == T for s in self.slots)
+        splits, n = self.chunk_plan(T)
+        pes = temporal_slots(T)
+        per = (self.L + splits - 1) // splits
+        rows = []
+        for c in range(self.B):
+            for t, s in enumerate(self.slots[c]):
+                for kb in range(0, self.L, per):
+                    rows.append((c * self.S + s, kb, min(per, self.L - kb), pes[t], t))
+        self._stage = (self._stage + 1) % self.chunks_host.shape[0]
+        host = self.chunks_host[self._stage]
+        host.zero_()
+        host[:len(rows), :5] = torch.tensor(rows, dtype=torch.int32)
+        ops.copy_async(self.chunks, host, self.B * n * 8 * 4)(stream)
+
+    def upload_append_slots(self, local_slots: List[int], stream: int):
+        host = self.append_host[self._stage % self.append_host.shape[0]]
+        self._stage += 1
+        for c, s in enumerate(local_slots):
+            host[c] = c * self.S + s if s >= 0 else -1
+        ops.copy_async(self.append_slots, host, self.B * 4)(stream)
+
+    # ------------------------------------------------------------------ helpers
+    def _conv(self, *a, **kw):
+        return ops.conv2d(*a, ws=self.conv_ws, batch=self.B, **kw)
+
+    def _lin(self, x, name, y, K, N, **kw):
+        return ops.linear(x, self.P[name + '.w'], self.P[name + '.b'], y, M=self.B * self.L, K=K, N=N, ws=self.conv_ws, **kw)
+
+    def _attn(self, q, ldq, k, v, ldkv, out, **kw):
+        L = self.L
+        return ops.mem_read_attn(q, k, v, out, self.attn_ws, Lq=L, heads=HEADS, ldq=ldq, ldkv=ldkv, ldo=D_MODEL, nclips=self.B,
+                                 q_cs=L * ldq, out_cs=L * D_MODEL, **kw)
+
+    def _scatter(self, src, bank):
+        nb = self.L * D_MODEL * 2
+        return ops.scatter_blocks(src, bank, self.append_slots, nclips=self.B, block_bytes=nb, slot_bytes=nb)
+
+    def prepare_pos(self, stream: int):
+        if self._pos_ready:
+            return
+        for i in range(self.NL):
+            ops.run(ops.linear(self.posb, self.P[f'l{i}.self_qk.w'], None, self.pos_qk[i], M=self.B * self.L, K=D_MODEL, N=2 * D_MODEL,
+                               ldo=3 * D_MODEL), stream)
+        self._pos_ready = True
+
+    def _enc(self, e: Optional[int]):
+        """(enc1, enc2, enc3) [B * rows, C] of the frame in flight: the group's own encoder or look-ahead slot e."""
+        if e is None:
+            return self.enc_now.enc_out
+        B = self.B
+        o = self.enc_ahead.enc_out
+        return tuple(t[e * B:(e + 1) * B] for t in o)
+
+    # ------------------------------------------------------------------ programs
+    def prog_encode(self) -> list:
+        return self.enc_now.prog()
+
+    def prog_project(self, e: Optional[int]) -> list:
+        key = f'project_{e}'
+        if key not in self._prog:
+            self._prog[key] = [ops.conv2d(self._enc(e)[2], self.P['proj.w'], self.P['proj.b'], self.x, H=self.B * self.L, W=1, Cin=1024,
+                                          Cout=D_MODEL, y2=self.dec_in, ld2=4 * D_MODEL, ws=self.conv_ws)]
+        return self._prog[key]
+
+    def prog_lstt(self, ref_mode: bool, T: int, want_mass: bool = True) -> list:
+        """ClipRuntime.prog_lstt over B clips (layers/transformer.py:553-692).  ref_mode: the frame's own K / V are computed
+        into curr_Q / new_V and scattered into each clip's first bank slot before the long-term read."""
+        key = 'lstt_ref' if ref_mode else f'lstt_prop{T}{"m" if want_mass else ""}'
+        if key in self._prog:
+            return self._prog[key]
+        P, L, B, o = self.P, self.L, self.B, []
+        C = D_MODEL
+        R = B * L
+        _, nchunks = self.chunk_plan(1 if ref_mode else T)
+        for i in range(self.NL):
+            d = f'l{i}'
+            o.append(ops.layernorm256(self.x, P[d + '.ln1.g'], P[d + '.ln1.b'], M=R, y=self.t1b))
+            o.append(self._lin(self.t1b, d + '.self_qkv', self.qkv, C, 3 * C, residual=self.pos_qk[i]))
+            o.append(self._attn(self.qkv, 3 * C, self.qkv.view(-1)[C:], self.qkv.view(-1)[2 * C:], 3 * C, self.att,
+                                nchunks=PLAIN_CHUNKS, lk_single=L, kv_cs=L * 3 * C))
+            o.append(self._lin(self.att, d + '.self_proj', self.x, C, C, residual=self.x))
+            o.append(ops.layernorm256(self.x, P[d + '.ln2.g'], P[d + '.ln2.b'], M=R, y=self.curr_V[i]))
+            cq = self.curr_Q[i]
+            o.append(self._lin(self.curr_V[i], d + '.linear_Q', cq, C, C))
+            if ref_mode:
+                o.append(ops.add_bf16(self.curr_V[i], self.id_emb, self.tmpB[i], R * C))
+                o.append(self._lin(self.tmpB[i], d + '.linear_V', self.new_V[i], C, C))
+                o.append(self._scatter(cq, self.bank_K[i]))
+                o.append(self._scatter(self.new_V[i], self.bank_V[i]))
+                sk, sv = cq, self.new_V[i]                          # local_K/V = global_K/V (transformer.py:585-586)
+            else:
+                sk, sv = self.short_K[i], self.short_V[i]
+            o.append(self._attn(cq, C, self.bank_K[i], self.bank_V[i], C, self.att, slot_stride=L * C, chunks=self.chunks,
+                                nchunks=nchunks, lk_single=(1 if ref_mode else T) * L, pe_cur=P['pe_cur'], pe_mem=P['pe_mem'],
+                                mass=self.mass if (i == 0 and not ref_mode and want_mass) else None, T=T))
+            o.append(self._lin(self.att, d + '.long_proj', self.x, C, C, residual=self.x))
+            o.append(ops.layernorm256_pair(sk, cq, self.k4, sv, self.curr_V[i], self.v4, P[d + '.ln4.g'], P[d + '.ln4.b'], M=R))
+            o.append(self._attn(cq, C, self.k4, self.v4, C, self.att, nchunks=PLAIN_CHUNKS, lk_single=L, kv_cs=L * C))
+            o.append(self._lin(self.att, d + '.short_proj', self.x, C, C, residual=self.x, y2=self.tgt3[i]))
+            if ref_mode:   # short-term memory of the reference frame (675-678)
+                o.append(self._lin(self.tgt3[i], d + '.linear_QMem', self.short_K[i], C, C))
+                o.append(ops.add_bf16(self.tgt3[i], self.id_emb, self.tmpA[i], R * C))
+                o.append(self._lin(self.tmpA[i], d + '.linear_VMem', self.short_V[i], C, C))
+            o.append(ops.layernorm256(self.x, P[d + '.ln3.g'], P[d + '.ln3.b'], M=R, y=self.t3))
+            o.append(self._lin(self.t3, d + '.linear1', self.h1, C, FFN))
+            o.append(ops.gn_act_dwconv5x5(self.h1, P[d + '.gn.g'], P[d + '.gn.b'], P[d + '.dw.w'], self.h3, self.gn_ws, H=self.H16,
+                                          W=self.W16, C=FFN, groups=32, act=2, images=B))
+            o.append(self._lin(self.h3, d + '.linear2', self.x, FFN, C, residual=self.x))
+            o.append(ops.layernorm256(self.x, P[f'dec_norm{i}.g'], P[f'dec_norm{i}.b'], M=R,
+                                      y=self.dec_in.view(-1)[(i + 1) * C:], ldy=4 * C))
+        self._prog[key] = o
+        return o
+
+    def prog_decode(self, e: Optional[int]) -> list:
+        key = f'decode_{e}'
+        if key in self._prog:
+            return self._prog[key]
+        P, o, L, B = self.P, [], self.L, self.B
+        M8, M4 = self.M8, self.M4
+        enc1, enc2, enc3 = self._enc(e)
+        gn = lambda x, name, y, M, C: ops.groupnorm(x, P[name + '.gn.g'], P[name + '.gn.b'], y, self.gn_ws, M=M, C=C, groups=8, act=1,  # noqa: E731
+                                                    images=B)
+        lin = lambda x, name, y, M, K, N, **kw: ops.conv2d(x, P[name + '.w'], P[name + '.b'], y, H=B * M, W=1, Cin=K, Cout=N,  # noqa: E731
+                                                           ws=self.conv_ws, **kw)
+        o.append(lin(self.dec_in, 'dec.conv_in', self.d16a, L, 1024, 256))
+        o.append(gn(self.d16a, 'dec.conv_in', self.d16b, L, 256))
+        o.append(lin(enc3, 'dec.adapter_16x', self.d16a, L, 1024, 256, residual=self.d16b))
+        o.append(self._conv(self.d16a, P['dec.conv_16x.w'], P['dec.conv_16x.b'], self.d16b, H=self.H16, W=self.W16, Cin=256, Cout=256,
+                            KH=3, KW=3, pad=1))
+        o.append(gn(self.d16b, 'dec.conv_16x', self.d16a, L, 256))
+        o.append(ops.bilinear(self.d16a, self.d8a, Hi=self.H16, Wi=self.W16, Ho=self.H8, Wo=self.W8, C=256, align_corners=self.align,
+                              images=B))
+        o.append(lin(enc2, 'dec.adapter_8x', self.d8b, M8, 512, 256, residual=self.d8a))
+        d8c = self.d8a.view(-1)[: B * M8 * 128]
+        o.append(self._conv(self.d8b, P['dec.conv_8x.w'], P['dec.conv_8x.b'], d8c, H=self.H8, W=self.W8, Cin=256, Cout=128, KH=3, KW=3,
+                            pad=1))
+        d8d = self.d8b.view(-1)[: B * M8 * 128]
+        o.append(gn(d8c, 'dec.conv_8x', d8d, M8, 128))
+        o.append(ops.bilinear(d8d, self.d4a, Hi=self.H8, Wi=self.W8, Ho=self.H4, Wo=self.W4, C=128, align_corners=self.align, images=B))
+        o.append(lin(enc1, 'dec.adapter_4x', self.d4b, M4, 256, 128, residual=self.d4a))
+        o.append(self._conv(self.d4b, P['dec.conv_4x.w'], P['dec.conv_4x.b'], self.d4a, H=self.H4, W=self.W4, Cin=128, Cout=128, KH=3,
+                            KW=3, pad=1))
+        o.append(gn(self.d4a, 'dec.conv_4x', self.d4b, M4, 128))
+        o.append(lin(self.d4b, 'dec.conv_out', self.logits, M4, 128, self.nc, ldo=16))
+        self._prog[key] = o
+        return o
+
+    def prog_id_emb(self, labels: torch.Tensor, hs: int, ws: int) -> list:
+        """labels: uint8 or fp32 [B, hs, ws] device tensor at a fixed address -> self.id_emb (aot_engine.py:208-232)."""
+        key = f'id_{labels.data_ptr()}_{hs}_{ws}'
+        if key in self._prog:
+            return self._prog[key]
+        P, B = self.P, self.B
+        k, s, p = (17, 16, 8) if self.align else (16, 16, 0)
+        o = [ops.label_to_onehot16(labels[c], self.onehot[c * self.H * self.W:(c + 1) * self.H * self.W], Hs=hs, Ws=ws, Hd=self.H,
+                                   Wd=self.W, ncls=self.nc) for c in range(B)]
+        o.append(self._conv(self.onehot, P['idbank.w'], P['idbank.b'], self.id_emb, H=self.H, W=self.W, Cin=16, Cout=D_MODEL,
+                            KH=k, KW=k, stride=s, pad=p))
+        self._prog[key] = o
+        return o
+
+    def prog_update(self, append: bool) -> list:
+        """Memory update of the frame just propagated for all clips (layers/transformer.py:269-322); with ``append`` the new bank
+        entries are scattered to the per-clip slots named by the device table."""
+        key = f'update_{int(append)}'
+        if key in self._prog:
+            return self._prog[key]
+        P, NL, L, C, B = self.P, self.NL, self.L, D_MODEL, self.B
+        R = B * L
+        o = [ops.add_bf16_grouped(self.tgt3 + (self.curr_V if append else []), [self.id_emb] * (NL * (2 if append else 1)),
+                                  self.tmpA + (self.tmpB if append else []), R * C)]
+        w = lambda nm: [P[f'l{i}.{nm}.w'] for i in range(NL)]   # noqa: E731
+        b = lambda nm: [P[f'l{i}.{nm}.b'] for i in range(NL)]   # noqa: E731
+        o.append(ops.linear_grouped(self.tgt3, w('linear_QMem'), b('linear_QMem'), self.short_K, M=R, K=C, N=C))
+        o.append(ops.linear_grouped(self.tmpA, w('linear_VMem'), b('linear_VMem'), self.short_V, M=R, K=C, N=C))
+        if append:
+            o.append(ops.linear_grouped(self.tmpB, w('linear_V'), b('linear_V'), self.new_V, M=R, K=C, N=C))
+            for i in range(NL):
+                o.append(self._scatter(self.curr_Q[i], self.bank_K[i]))
+                o.append(self._scatter(self.new_V[i], self.bank_V[i]))
+        self._prog[key] = o
+        return o

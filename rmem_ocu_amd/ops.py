@@ -278,6 +278,14 @@ def copy_async(dst, src, nbytes: int) -> Op:
     return Op(_lib.lib().rmem_copy_async, (_ptr(dst), _ptr(src), nbytes), 'rmem_copy_async', (dst, src))
 
 
+def scatter_blocks(src, dst, slots, *, nclips, block_bytes, slot_bytes) -> Op:
+    """block c of src -> dst + slots[c] * slot_bytes (slots: device int32 table, negative = skip)."""
+    _dev(src, dst, slots)
+    assert slots.dtype == torch.int32 and slots.numel() >= nclips and src.numel() * src.element_size() >= nclips * block_bytes
+    return Op(_lib.lib().rmem_scatter_blocks, (_ptr(src), _ptr(dst), _ptr(slots), nclips, block_bytes, slot_bytes), 'rmem_scatter_blocks',
+              (src, dst, slots))
+
+
 def copy2d_async(dst, dst_pitch: int, src, src_pitch: int, row_bytes: int, rows: int) -> Op:
     """rows x row_bytes device copy between pitched buffers (pitches in bytes)."""
     _dev(dst, src)

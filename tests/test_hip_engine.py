@@ -366,3 +366,43 @@ def test_clip_slot_from_pinned_uint8_frames():
         eng.synchronize()
         out.append(slot.labels[:11].cpu().numpy().copy())
     assert np.array_equal(out[0][1:], out[1][1:])
+
+
+def test_group_engine_matches_per_clip_engines():
+    """Three clips in lockstep on one GroupEngine (one launch per layer for the group, per-clip banks / eviction policies) deliver
+    the masks and eviction traces of three per-clip engines."""
+    from rmem_ocu_amd import build_vos_model, get_config
+    from rmem_ocu_amd.clip_runner import ClipSlot, GroupSlot
+    from rmem_ocu_amd.networks.engines.group_engine import GroupEngine
+    from rmem_ocu_amd.synth import make_clip
+    from rmem_ocu_amd.weights import synth_state_dict
+    dev = torch.device('cuda', 0)
+    B, n = 3, 26
+    clips = [make_clip(40 + c, n, 161, 193, 3) for c in range(B)]
+    ref_labels, ref_traces = [], []
+    for f, m in clips:
+        eng = _engine(1, 2, 5)
+        eng.set_async(use_graphs=True)
+        slot = ClipSlot(eng, (160, 192), dev, lookahead=4)
+        slot.start(f.to(dev), m.to(dev), 3)
+        while not slot.done:
+            slot.step()
+        eng.synchronize()
+        ref_labels.append(slot.labels[:n].cpu().numpy().copy())
+        ref_traces.append((list(eng.long_memories_indexes), list(eng.aot_engines[0].drop_trace)))
+    cfg = get_config('pre_vost', 'test', 'r50_aotl')
+    cfg.FORMER_MEM_LEN, cfg.LATTER_MEM_LEN = 1, 2
+    model = build_vos_model(cfg.MODEL_VOS, cfg).cuda(0)
+    model.load_state_dict(synth_state_dict(0))
+    ge = GroupEngine(model, B, 0, 5, lookahead=4)
+    gs = GroupSlot(ge, (160, 192), dev)
+    gs.start([f.to(dev) for f, _ in clips], [m.to(dev) for _, m in clips], 3)
+    while not gs.done:
+        gs.step()
+    ge.synchronize()
+    got = gs.labels[:, :n].cpu().numpy()
+    for c in range(B):
+        agree = (got[c][1:] == ref_labels[c][1:]).mean()
+        print(f'clip {c}: label agreement {agree:.5f}, indexes {ge.long_memories_indexes(c)}, drops {ge.drop_trace[c]}')
+        assert agree > 0.995
+        assert (ge.long_memories_indexes(c), ge.drop_trace[c]) == ref_traces[c]
