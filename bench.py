@@ -78,12 +78,15 @@ def cpu_baseline(frames, mask, n_timed=8):
             'sample': f'{n_timed} propagated frames at 481x849, bank T=8 (steady state of the 80-frame clip), fp32, after 9 untimed frames'}
 
 
-def pmc_traffic():
+def pmc_traffic(clips_per_launch=1):
     """HBM bytes per T = 8 launch of the memory-read kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
-    WRITE_SIZE in separate runs, gfx950 FETCH correction applied): profiles/r01/attn_pmc.json.  bench.py cannot collect
-    counters itself; the figure is per launch like `achieved`."""
+    WRITE_SIZE in separate runs, gfx950 FETCH correction applied): profiles/r01/attn_pmc.json (one clip per launch) or
+    attn_pmc_group4.json (4 clips per launch).  bench.py cannot collect counters itself; the figure is per launch like `achieved`."""
+    name = {1: 'attn_pmc.json', 4: 'attn_pmc_group4.json'}.get(clips_per_launch)
+    if name is None:
+        return None
     try:
-        with open(os.path.join(ROOT, 'profiles', 'r01', 'attn_pmc.json')) as f:
+        with open(os.path.join(ROOT, 'profiles', 'r01', name)) as f:
             return json.load(f)['hbm_bytes_per_launch']
     except Exception:
         return None
@@ -102,7 +105,7 @@ def main():
                     help='> 1: that many clips advance in lockstep on one GroupEngine (one launch per layer for the group); R50-AOTL only')
     ap.add_argument('--host-frames', action='store_true',
                     help='PCIe-inclusive variant (not the contract line): frames start as decoded uint8 RGB in pinned host memory')
-    ap.add_argument('--encoder-lookahead', type=int, default=int(os.environ.get('RMEM_ENC_LOOKAHEAD', 2)),
+    ap.add_argument('--encoder-lookahead', type=int, default=int(os.environ.get('RMEM_ENC_LOOKAHEAD', 0)),
                     help='frames the ResNet-50 encoder runs ahead inside a clip (one launch per layer for all of them)')
     ap.add_argument('--sample-every', type=int, default=100, help='time the memory-read kernel on 1 in N timed frames (run in isolation)')
     args = ap.parse_args()
@@ -159,8 +162,9 @@ def main():
         clips = [(f.to(dev), m.to(dev)) for f, m in clips_host]
 
     C = max(1, args.clips_in_flight)
-    lookahead = args.encoder_lookahead if cfg.MODEL_ENCODER == 'resnet50' else 1      # the batched encoder is the ResNet-50 one
     G = args.clips_per_group if (wl['model'] == 'r50_aotl' and not args.host_frames) else 1
+    # frames the encoder runs ahead (0 = default: 2 with clip groups -- 8 images per launch --, 4 for single clips)
+    lookahead = (args.encoder_lookahead or (2 if G > 1 else 4)) if cfg.MODEL_ENCODER == 'resnet50' else 1
     slots = []
     if G > 1:
         from rmem_ocu_amd.clip_runner import GroupSlot
@@ -264,7 +268,7 @@ def main():
                        'hipgraphs': not args.no_graphs, 'frames_from': 'pinned host uint8 (PCIe-inclusive)' if args.host_frames else 'HBM', 'encoder_lookahead': lookahead, 'host_enqueue_ms_per_step': round(1e3 * host_enqueue / args.steps, 4)},
             'roofline': {'bound': 'mfma', 'kernel': 'k_gp_pv<1, true>' if deaot else 'k_attn_partial<true, true>', 'achieved': None if achieved is None else round(achieved, 2),
                          'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': None if achieved is None else round(achieved / PEAK_BF16_TFLOPS, 4),
-                         'traffic': pmc_traffic() if args.workload == 'davis17_480p_r50_N8' else None, 'launches_timed': nl.value,
+                         'traffic': pmc_traffic(G) if args.workload == 'davis17_480p_r50_N8' else None, 'launches_timed': nl.value,
                          'avg_launch_us': None if not nl.value else round(1e3 * ms.value / nl.value, 2)},
         }
         if world == 1 and not args.no_cpu_baseline and args.workload == 'davis17_480p_r50_N8':
