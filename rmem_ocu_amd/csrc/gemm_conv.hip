@@ -300,16 +300,16 @@ __global__ __launch_bounds__(256) void k_conv_gemm(ConvParams p) {
 // LDS-DMA variant of the 64x64 tile (the one every shape of this path uses).  Global -> LDS goes through
 // global_load_lds_dwordx4 (no VGPR staging, no ds_write: the ~79 B/clk ds_write path was the per-k-step bottleneck of the
 // register-staged kernel).  Each wave-instruction fills 8 rows x 128 B of the tile linearly, so the XOR swizzle is
-// applied to the per-lane SOURCE address; padded / out-of-range pieces read a 16-byte zero buffer.  3-deep LDS ring,
-// two tiles in flight, counted vmcnt + raw s_barrier (one barrier per k-step, DMA stays in flight across it).
+// applied to the per-lane SOURCE address; padded / out-of-range pieces read a 16-byte zero buffer.  ST-deep LDS ring with
+// counted vmcnt + raw s_barrier; the default is ST = 1 (a single 16 KB buffer, 8 workgroups per CU: see launch()).
 __device__ uint4 g_zero16[1];
 
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-template <bool IS1X1, bool SPLITK>
+template <bool IS1X1, bool SPLITK, int ST = 1>
 __device__ __forceinline__ void conv_gemm_dma_body(const ConvParams& p, const int zslice) {
-  constexpr int BM = 64, BN = 64, BK = 64, ST = 3, TM = 2, TN = 2;
+  constexpr int BM = 64, BN = 64, BK = 64, TM = 2, TN = 2;
   constexpr int CP = BN + 4;
   constexpr int STAGE_BYTES = (BM + BN) * BK * 2;
   __shared__ __attribute__((aligned(16))) char smem[ST * STAGE_BYTES];   // the ONLY shared object (epilogue staging aliases it)
@@ -389,16 +389,27 @@ __device__ __forceinline__ void conv_gemm_dma_body(const ConvParams& p, const in
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int fr = lane & 15, fc = lane >> 4;
-  if (kt0 < kt1) issue(kt0, 0);
-  if (kt0 + 1 < kt1) issue(kt0 + 1, 1);
+#pragma unroll
+  for (int i = 0; i < ST - 1; ++i)
+    if (kt0 + i < kt1) issue(kt0 + i, i);
   int stage = 0;
   for (int kt = kt0; kt < kt1; ++kt) {
-    // tile kt has landed once at most the 4 DMA pieces of tile kt+1 are still outstanding for this wave
-    if (kt + 1 < kt1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                     // everyone's pieces of tile kt landed; everyone finished reading tile kt-1
-    const int nxt = stage == 0 ? 2 : stage - 1;       // slot of tile kt+2 == slot of tile kt-1
-    if (kt + 2 < kt1) issue(kt + 2, nxt);
+    if (ST == 1) {                                    // single buffer: other resident workgroups hide the load
+      if (kt > kt0) __builtin_amdgcn_s_barrier();     // everyone finished reading tile kt-1
+      issue(kt, 0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    } else {
+      // tile kt has landed once only the 4 DMA pieces per later tile (at most ST - 2 of them) are still outstanding for this wave
+      switch (min(ST - 2, kt1 - 1 - kt)) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+      }
+      __builtin_amdgcn_s_barrier();                     // everyone's pieces of tile kt landed; everyone finished reading tile kt-1
+      const int nxt = stage == 0 ? ST - 1 : stage - 1;  // slot of tile kt+ST-1 == slot of tile kt-1
+      if (kt + ST - 1 < kt1) issue(kt + ST - 1, nxt);
+    }
     const bf16* As = reinterpret_cast<const bf16*>(smem + stage * STAGE_BYTES);
     const bf16* Bs = As + BM * BK;
 #pragma unroll
@@ -414,7 +425,7 @@ __device__ __forceinline__ void conv_gemm_dma_body(const ConvParams& p, const in
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
     }
-    stage = stage == 2 ? 0 : stage + 1;
+    stage = stage == ST - 1 ? 0 : stage + 1;
   }
   __syncthreads();                                     // all DMA drained (vmcnt(0) above) and all fragment reads done
 
@@ -454,9 +465,9 @@ __device__ __forceinline__ void conv_gemm_dma_body(const ConvParams& p, const in
 }
 
 
-template <bool IS1X1, bool SPLITK>
+template <bool IS1X1, bool SPLITK, int ST = 1>
 __global__ __launch_bounds__(256) void k_conv_gemm_dma(ConvParams p) {
-  conv_gemm_dma_body<IS1X1, SPLITK>(p, blockIdx.z);
+  conv_gemm_dma_body<IS1X1, SPLITK, ST>(p, blockIdx.z);
 }
 
 // up to 4 GEMMs of identical shape (different operands) as ONE launch: blockIdx.z selects the operand set.  The per-layer
@@ -502,8 +513,19 @@ void launch(const ConvParams& p, bool is1x1, int splits, hipStream_t s) {
       const long total = (long)p.M * (p.Cout / 8);
       hipLaunchKernelGGL(k_splitk_epilogue, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p, splits);
     } else {
-      if (is1x1) hipLaunchKernelGGL((k_conv_gemm_dma<true, false>), grid, dim3(256), 0, s, p);
-      else hipLaunchKernelGGL((k_conv_gemm_dma<false, false>), grid, dim3(256), 0, s, p);
+      // ring depth: measured with 4 clips per launch, 1 / 2 / 3 / 4 stages give 2146 / 2044 / 1978 / 1735 frames/s -- a
+      // 16 KB single buffer lets 8 workgroups share a CU, and their DMA in flight beats any prefetch depth inside one
+      static const int st = getenv("RMEM_GEMM_ST") ? atoi(getenv("RMEM_GEMM_ST")) : 1;     // kernel experiments only
+      if (st == 2) {
+        if (is1x1) hipLaunchKernelGGL((k_conv_gemm_dma<true, false, 2>), grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((k_conv_gemm_dma<false, false, 2>), grid, dim3(256), 0, s, p);
+      } else if (st == 3) {
+        if (is1x1) hipLaunchKernelGGL((k_conv_gemm_dma<true, false, 3>), grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((k_conv_gemm_dma<false, false, 3>), grid, dim3(256), 0, s, p);
+      } else {
+        if (is1x1) hipLaunchKernelGGL((k_conv_gemm_dma<true, false>), grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((k_conv_gemm_dma<false, false>), grid, dim3(256), 0, s, p);
+      }
     }
     return;
   }
