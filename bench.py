@@ -8,14 +8,16 @@ Workload (config.workload = "davis17_480p_r50_N8"): synthetic 480x854 clips of 8
 size 481x849 (HW = 1674 tokens), ResNet-50 + 3-layer LSTT + FPN, memory bank N = 8 (1 + 7),
 per-clip gap = max(round(80/30), 5) = 5, 3 objects, bf16 operands / fp32 accumulation.
 A *step* is one propagated frame of one clip: match-propagate + argmax + memory update -- the
-reference's own FPS unit (managers/evaluator.py:399-404, 525-535).  Clips are independent, so
-each rank keeps several clips in flight on separate HIP streams and ranks never exchange data on
-the hot path (weak scaling: per-GPU work is fixed); the only collectives are the barriers around
-the timed region and one final gather of (frames, seconds, checksum) to rank 0.
-Reference frames that fall inside the timed region are executed but not counted as steps.
-Inside a clip the ResNet-50 encoder runs 4 frames ahead of the LSTT (frames do not depend on each other before the
-memory read): one launch per encoder layer covers 4 frames, every frame is still encoded exactly once (config.encoder_lookahead).
-Inputs are resident in HBM when the timed region starts.
+reference's own FPS unit (managers/evaluator.py:399-404, 525-535).  Clips are independent; a GPU is filled by keeping 24 of
+them in flight, as 6 groups of 4 clips that advance in lockstep on one GroupEngine each (one launch per layer for the 4
+clips: rmem_ocu_amd/networks/engines/group_engine.py; --clips-per-group 1 selects the per-clip engines of the drop-in API),
+every group on its own HIP stream with its own hipGraphs.  Ranks never exchange data on the hot path (weak scaling: per-GPU
+work is fixed); the only collectives are the barriers around the timed region and one final gather of (frames, seconds,
+checksum) to rank 0.  Reference frames that fall inside the timed region are executed but not counted as steps.  Inside a
+clip the ResNet-50 encoder runs 2 frames ahead of the LSTT (frames do not depend on each other before the memory read): one
+launch per encoder layer covers 2 frames x 4 clips, every frame is still encoded exactly once (config.encoder_lookahead).
+A group step propagates 4 frames, so the timed region executes ceil(K / 4) * 4 frames while `value` = K / elapsed (never
+over-reports; config.frames_executed_in_timed_region).  Inputs are resident in HBM when the timed region starts.
 
 The single JSON line also carries
   roofline     -- the dominant kernel (k_attn_partial, the long-term memory read): algorithmic FLOPs
