@@ -164,7 +164,7 @@ def main():
         clips = [(f.to(dev), m.to(dev)) for f, m in clips_host]
 
     C = max(1, args.clips_in_flight)
-    G = args.clips_per_group if (wl['model'] == 'r50_aotl' and not args.host_frames) else 1
+    G = args.clips_per_group if wl['model'] == 'r50_aotl' else 1
     # frames the encoder runs ahead (0 = default: 2 with clip groups -- 8 images per launch --, 4 for single clips)
     lookahead = (args.encoder_lookahead or (2 if G > 1 else 4)) if cfg.MODEL_ENCODER == 'resnet50' else 1
     slots = []

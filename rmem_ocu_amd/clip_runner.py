@@ -144,21 +144,56 @@ class GroupSlot:
         self.done = True
 
     def start(self, frames: Sequence[torch.Tensor], first_masks: Sequence[torch.Tensor], num_objs: int):
-        """frames: B tensors [n, 3, H, W] fp32 device (equal n); first_masks: B tensors [1, 1, H, W] at the network size."""
+        """frames: B tensors [n, 3, H, W] fp32 device (equal n), or B uint8 [n, Hs, Ws, 3] tensors in PINNED HOST memory (every
+        frame then crosses PCIe as uint8 and is resized + normalised on the device); first_masks: B tensors [1, 1, H, W] at the
+        network size."""
         assert len(frames) == self.B and len({int(f.shape[0]) for f in frames}) == 1
         n = int(frames[0].shape[0])
         self.frames = list(frames)
+        self.host_u8 = frames[0].dtype == torch.uint8
         if self.labels is None or self.labels.shape[1] < n:
             self.labels = torch.zeros(self.B, n, self.out_hw[0], self.out_hw[1], dtype=torch.uint8, device=self.device)
         eng = self.engine
         eng.restart_engine()
         eng.long_term_mem_gap = max(int(round(n / 30)), 5)      # evaluator.py:330-335
+        H, W = int(first_masks[0].shape[-2]), int(first_masks[0].shape[-1])
         with torch.cuda.stream(eng.stream):
-            imgs = torch.cat([f[0:1] for f in frames], 0)
+            s = eng.stream.cuda_stream
+            if self.host_u8:
+                hs, ws = int(frames[0].shape[1]), int(frames[0].shape[2])
+                la = max(eng.lookahead, 1)
+                if getattr(self, '_stage', None) is None or tuple(self._stage.shape[1:3]) != (hs, ws):
+                    self._stage = torch.empty(la * self.B, hs, ws, 3, dtype=torch.uint8, device=self.device)
+                    self._first = torch.empty(self.B, 3, H, W, dtype=torch.float32, device=self.device)
+                for c in range(self.B):
+                    if not frames[c].is_pinned():
+                        raise ValueError('uint8 host frames must be in pinned memory')
+                    ops.copy_async(self._stage[c], frames[c][0], hs * ws * 3)(s)
+                ops.run([ops.ingest_rgb8(self._stage[c], Hs=hs, Ws=ws, Hd=H, Wd=W, out_chw=self._first[c]) for c in range(self.B)], s)
+                imgs = self._first
+            else:
+                imgs = torch.cat([f[0:1] for f in frames], 0)
             masks = torch.cat([m.reshape(1, 1, m.shape[-2], m.shape[-1]).float() for m in first_masks], 0)
         eng.add_reference_frames(imgs, masks, num_objs)
         self.cursor = 1
         self.done = n <= 1
+
+    def _fill_encoder_inputs(self, dst: torch.Tensor, i: int, m: int):
+        """frames i .. i + m - 1 of every clip into rows k * B + c of dst ([., 3, H, W] fp32) on the engine's stream."""
+        eng, B = self.engine, self.B
+        s = eng.stream.cuda_stream
+        if self.host_u8:
+            hs, ws = int(self.frames[0].shape[1]), int(self.frames[0].shape[2])
+            H, W = int(dst.shape[-2]), int(dst.shape[-1])
+            for c in range(B):
+                ops.copy_async(self._stage[c * m:(c + 1) * m], self.frames[c][i:i + m], m * hs * ws * 3)(s)
+            ops.run([ops.ingest_rgb8(self._stage[c * m + k], Hs=hs, Ws=ws, Hd=H, Wd=W, out_chw=dst[k * B + c]) for c in range(B)
+                     for k in range(m)], s)
+        else:
+            fb = dst[0].numel() * 4
+            for c in range(B):
+                for k in range(m):
+                    ops.copy_async(dst[k * B + c], self.frames[c][i + k], fb)(s)
 
     def step(self):
         eng, B, i = self.engine, self.B, self.cursor
@@ -167,18 +202,16 @@ class GroupSlot:
         if la > 1:
             e = (i - 1) % la
             if e == 0:
-                dst = eng.encode_inputs()
-                n = self.frames[0].shape[0]
-                m = min(la, n - i)
-                fb = dst[0].numel() * 4
-                for c in range(B):
-                    for k in range(m):
-                        ops.copy_async(dst[k * B + c], self.frames[c][i + k], fb)(s)
+                self._fill_encoder_inputs(eng.encode_inputs(), i, min(la, self.frames[0].shape[0] - i))
                 eng.encode_ahead()
             eng.propagate_to_labels(self.cur_label, enc_slot=e)
         else:
-            with torch.cuda.stream(eng.stream):
-                imgs = torch.cat([f[i:i + 1] for f in self.frames], 0)
+            if self.host_u8:
+                self._fill_encoder_inputs(self._first, i, 1)
+                imgs = self._first
+            else:
+                with torch.cuda.stream(eng.stream):
+                    imgs = torch.cat([f[i:i + 1] for f in self.frames], 0)
             eng.propagate_to_labels(self.cur_label, imgs=imgs)
         eng.update_from_labels(self.cur_label)
         for c in range(B):

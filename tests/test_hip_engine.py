@@ -406,3 +406,39 @@ def test_group_engine_matches_per_clip_engines():
         print(f'clip {c}: label agreement {agree:.5f}, indexes {ge.long_memories_indexes(c)}, drops {ge.drop_trace[c]}')
         assert agree > 0.995
         assert (ge.long_memories_indexes(c), ge.drop_trace[c]) == ref_traces[c]
+
+
+def test_group_slot_from_pinned_uint8_frames():
+    """Clip group fed from decoded uint8 frames in pinned host memory (H2D + ingest kernel into the look-ahead encoder's input)
+    gives the masks of the same group fed with the ingested fp32 frames from device memory."""
+    from rmem_ocu_amd import build_vos_model, get_config, ops
+    from rmem_ocu_amd.clip_runner import GroupSlot
+    from rmem_ocu_amd.networks.engines.group_engine import GroupEngine
+    from rmem_ocu_amd.synth import make_clip
+    from rmem_ocu_amd.weights import synth_state_dict
+    dev = torch.device('cuda', 0)
+    B, n = 2, 9
+    cfg = get_config('pre_vost', 'test', 'r50_aotl')
+    cfg.FORMER_MEM_LEN, cfg.LATTER_MEM_LEN = 1, 2
+    model = build_vos_model(cfg.MODEL_VOS, cfg).cuda(0)
+    model.load_state_dict(synth_state_dict(0))
+    u8s, ings, masks = [], [], []
+    for c in range(B):
+        f, m = make_clip(60 + c, n, 161, 193, 2)
+        vid = F.interpolate(f, size=(160, 192), mode='bilinear', align_corners=False)
+        u8 = (vid * 40.0 + 128.0).clamp(0, 255).to(torch.uint8).permute(0, 2, 3, 1).contiguous().pin_memory()
+        u8d = u8.to(dev)
+        ing = torch.empty(n, 3, 161, 193, dtype=torch.float32, device=dev)
+        ops.run([ops.ingest_rgb8(u8d[i], Hs=160, Ws=192, Hd=161, Wd=193, out_chw=ing[i]) for i in range(n)])
+        u8s.append(u8); ings.append(ing); masks.append(m.to(dev))
+    torch.cuda.synchronize()
+    out = []
+    for src in (ings, u8s):
+        ge = GroupEngine(model, B, 0, 5, lookahead=2)
+        gs = GroupSlot(ge, (160, 192), dev)
+        gs.start(src, masks, 2)
+        while not gs.done:
+            gs.step()
+        ge.synchronize()
+        out.append(gs.labels[:, :n].cpu().numpy().copy())
+    assert np.array_equal(out[0][:, 1:], out[1][:, 1:])
