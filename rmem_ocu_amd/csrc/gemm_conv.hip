@@ -47,6 +47,8 @@ struct ConvParams {
   int act_begin;         // first output channel the activation applies to (multiple of 8)
   int steps_per_split;   // k-steps (of 32) per gridDim.z slice
   int vec_ok;            // all leading dimensions / pointers allow 8-wide vector access
+  long x_elems;          // addressable span of x in elements (fast path: buffer descriptor range)
+  int fast_ok;           // 1: Cin % 64 == 0, <= 32 taps, x and w below 2 GB: scalar k-walk + hardware zero fill; 2: row-run form
 };
 
 // LDS tile rows are 128 B (BK = 64 bf16 = 8 chunks of 16 B).  Physical chunk = chunk ^ ((row >> 1) & 7): the 16 lanes of
@@ -307,28 +309,97 @@ __device__ uint4 g_zero16[1];
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-template <bool IS1X1, bool SPLITK, int ST = 1>
+// buffer-descriptor LDS-DMA (buffer_load_dwordx4 ... offen lds).  The descriptor type and these builtins exist only in the
+// device pass of hipcc; the host pass just needs the names to parse.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const void* base, int bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ void buf_load_lds16(rsrc_t r, lptr_t dst, int voff, int soff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, dst, 16, voff, soff, 0, 0);
+}
+#else
+struct rsrc_t {};
+__device__ inline rsrc_t make_rsrc(const void*, int) { return {}; }
+__device__ inline void buf_load_lds16(rsrc_t, lptr_t, int, int) {}
+#endif
+
+//
+// FAST (Cin % 64 == 0, which every 3x3 / 1x1 layer of the path satisfies): a k-step never leaves one filter tap, so the k-walk
+// (tap, ci) is wave-uniform and lives in SGPRs; each lane keeps ONE 32-bit byte offset per piece plus a bit mask of the taps
+// that fall inside the image.  Loads are buffer_load_dwordx4 ... lds through a buffer descriptor: the per-step uniform part
+// goes in soffset, and a lane whose tap is padding (or whose row is >= M) passes an out-of-range voffset, which the hardware
+// range check turns into a zero fill.  This removes ~90 of the ~110 instructions per k-step that the general form spends
+// on 64-bit address arithmetic and divergent tap bookkeeping (PMC: VALU busy 55 % vs MFMA busy 15 % on the 3x3 layers).
+template <bool IS1X1, bool SPLITK, int ST = 1, int BM = 64, int BN = 64, int MODE = 0>
 __device__ __forceinline__ void conv_gemm_dma_body(const ConvParams& p, const int zslice) {
-  constexpr int BM = 64, BN = 64, BK = 64, TM = 2, TN = 2;
+  constexpr bool FAST = MODE != 0;
+  constexpr bool ROWRUN = MODE == 2;      // Cin == 8, KW <= 8 (the ResNet stem): one k-step = the KW adjacent pixels of one filter row
+  constexpr int BK = 64, TM = BM / 32, TN = BN / 32;   // 2x2 waves, each (BM/2) x (BN/2) = TM x TN tiles of 16x16
+  constexpr int NA = BM / 32, NB = BN / 32;             // DMA wave-instructions (8 rows x 128 B each) per wave and k-step
   constexpr int CP = BN + 4;
   constexpr int STAGE_BYTES = (BM + BN) * BK * 2;
+  static_assert(32 * CP * 4 <= ST * STAGE_BYTES, "epilogue staging must fit the ring");
   __shared__ __attribute__((aligned(16))) char smem[ST * STAGE_BYTES];   // the ONLY shared object (epilogue staging aliases it)
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: LDS-DMA destinations stay in SGPRs
   const int wm = wave >> 1, wn = wave & 1;
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-  const int nk_total = (p.K + BK - 1) / BK;
+  const int nk_total = ROWRUN ? p.KH : (p.K + BK - 1) / BK;
   const int kt0 = SPLITK ? zslice * p.steps_per_split : 0;
   const int kt1 = SPLITK ? min(nk_total, kt0 + p.steps_per_split) : nk_total;
 
-  // this lane's two (row, chunk) pieces of the A tile and of the B tile: instruction i covers rows 16*wave + 8*i .. +7
-  int a_c[2], a_hi0[2], a_wi0[2], a_ci[2], a_kw[2], a_kh[2];
-  long a_base[2];
-  bool a_ok[2], b_ok[2];
-  long b_base[2];
+  // this lane's (row, chunk) pieces of the A tile and of the B tile: instruction i of a wave covers rows (BM/4)*wave + 8*i .. +7
+  int a_c[NA], a_hi0[NA], a_wi0[NA], a_ci[NA], a_kw[NA], a_kh[NA];
+  long a_base[NA];
+  bool a_ok[NA], b_ok[NB];
+  int b_c[NB];
+  long b_base[NB];
+  // FAST: per-lane byte offsets (31 bits) and tap masks; wave-uniform k-walk
+  constexpr int OOB = (int)0x80000000;
+  int f_aoff[NA], f_boff[NB];
+  unsigned f_amask[NA];
+  int s_ci = 0, s_kw = 0, s_tap = 0, s_aoff = 0;         // FAST is never split along K: the walk starts at tap 0, channel 0
+  if constexpr (FAST) {
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int r = 16 * wave + 8 * i + (lane >> 3);
+    for (int i = 0; i < NA; ++i) {
+      const int r = (BM / 4) * wave + 8 * i + (lane >> 3);
+      const int c = (lane & 7) ^ ((r >> 1) & 7);
+      const int m = m0 + r;
+      if (IS1X1) {
+        f_aoff[i] = m < p.M ? (m * p.ldx + c * 8) * 2 : OOB;
+        f_amask[i] = 1u;
+      } else {
+        const int img = m / p.HoWo, rem = m - img * p.HoWo;
+        const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+        const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
+        // offset relative to the (virtual) pixel (-pad, -pad) of image 0, so that it is never negative
+        f_aoff[i] = (((img * p.H + hi0 + p.pad) * p.W + wi0 + p.pad) * p.Cin + c * 8) * 2;
+        unsigned cm = 0, mask = 0;
+        if (ROWRUN) {           // chunk c of a k-step is pixel wi0 + c of filter row kh = step; bit kh of the mask = row inside the image
+          for (int kh = 0; kh < p.KH; ++kh) mask |= ((unsigned)(hi0 + kh) < (unsigned)p.H ? 1u : 0u) << kh;
+          if (c >= p.KW || (unsigned)(wi0 + c) >= (unsigned)p.W) mask = 0;
+        } else {
+          for (int kw = 0; kw < p.KW; ++kw) cm |= ((unsigned)(wi0 + kw) < (unsigned)p.W ? 1u : 0u) << kw;
+          for (int kh = 0; kh < p.KH; ++kh)
+            if ((unsigned)(hi0 + kh) < (unsigned)p.H) mask |= cm << (kh * p.KW);
+        }
+        f_amask[i] = m < p.M ? mask : 0u;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int r = (BN / 4) * wave + 8 * i + (lane >> 3);
+      const int c = (lane & 7) ^ ((r >> 1) & 7);
+      const int n = n0 + r;
+      f_boff[i] = (n < p.Cout && (!ROWRUN || c < p.KW)) ? (n * p.K + c * 8) * 2 : OOB;
+    }
+  } else {
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const int r = (BM / 4) * wave + 8 * i + (lane >> 3);
     a_c[i] = (lane & 7) ^ ((r >> 1) & 7);              // logical chunk that belongs in physical slot (lane & 7) of row r
     const int m = m0 + r;
     a_ok[i] = m < p.M;
@@ -347,17 +418,52 @@ __device__ __forceinline__ void conv_gemm_dma_body(const ConvParams& p, const in
       a_kh[i] = kk / p.KW;
       a_kw[i] = kk - a_kh[i] * p.KW;
     }
+  }
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    const int r = (BN / 4) * wave + 8 * i + (lane >> 3);
+    b_c[i] = (lane & 7) ^ ((r >> 1) & 7);
     const int n = n0 + r;
     b_ok[i] = n < p.Cout;
     b_base[i] = (long)n * p.K;
   }
+  }
   const char* zero = reinterpret_cast<const char*>(g_zero16);
+  // FAST: descriptors built from kernel arguments only (wave-uniform); A starts at the virtual pixel (-pad, -pad)
+  const long a_shift = (FAST && !IS1X1) ? ((long)p.pad * p.W + p.pad) * p.Cin : 0;
+  const rsrc_t rsrc_a = make_rsrc(p.x - a_shift, FAST ? (int)((p.x_elems + a_shift) * 2) : 0);
+  const rsrc_t rsrc_b = make_rsrc(p.w, FAST ? p.Cout * p.K * 2 : 0);
 
   auto issue = [&](int kt, int stage) {
     char* As = smem + stage * STAGE_BYTES;
     char* Bs = As + BM * BK * 2;
+    if constexpr (FAST) {
+      const int soff_a = IS1X1 ? kt * (BK * 2) : s_aoff;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+      for (int i = 0; i < NA; ++i) {
+        const int voff = IS1X1 ? f_aoff[i] : (((f_amask[i] >> s_tap) & 1u) ? f_aoff[i] : OOB);
+        buf_load_lds16(rsrc_a, (lptr_t)(As + ((BM / 4) * wave + 8 * i) * 128), voff, soff_a);
+      }
+#pragma unroll
+      for (int i = 0; i < NB; ++i)
+        buf_load_lds16(rsrc_b, (lptr_t)(Bs + ((BN / 4) * wave + 8 * i) * 128), f_boff[i], ROWRUN ? kt * p.KW * 16 : kt * (BK * 2));
+      if (ROWRUN) {             // next filter row
+        ++s_tap;
+        s_aoff += p.W * 16;
+      } else if (!IS1X1) {      // advance the uniform k-walk by one step (64 channels of one tap)
+        s_ci += BK;
+        s_aoff += BK * 2;
+        if (s_ci == p.Cin) {
+          s_ci = 0;
+          ++s_tap;
+          // the next tap of the same filter row is the next pixel: its + Cin channels are already in s_aoff
+          if (++s_kw == p.KW) { s_kw = 0; s_aoff += (p.W - p.KW) * p.Cin * 2; }
+        }
+      }
+      return;
+    }
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
       const char* src = zero;
       if (IS1X1) {
         const int kidx = kt * BK + a_c[i] * 8;
@@ -372,13 +478,13 @@ __device__ __forceinline__ void conv_gemm_dma_body(const ConvParams& p, const in
           if (++a_kw[i] == p.KW) { a_kw[i] = 0; ++a_kh[i]; }
         }
       }
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(As + (16 * wave + 8 * i) * 128), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(As + ((BM / 4) * wave + 8 * i) * 128), 16, 0, 0);
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int kidx = kt * BK + a_c[i] * 8;
+    for (int i = 0; i < NB; ++i) {
+      const int kidx = kt * BK + b_c[i] * 8;
       const char* src = (b_ok[i] && kidx < p.K) ? reinterpret_cast<const char*>(p.w + b_base[i] + kidx) : zero;
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Bs + (16 * wave + 8 * i) * 128), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Bs + ((BN / 4) * wave + 8 * i) * 128), 16, 0, 0);
     }
   };
 
@@ -400,11 +506,11 @@ __device__ __forceinline__ void conv_gemm_dma_body(const ConvParams& p, const in
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     } else {
-      // tile kt has landed once only the 4 DMA pieces per later tile (at most ST - 2 of them) are still outstanding for this wave
+      // tile kt has landed once only the NA + NB DMA pieces per later tile (at most ST - 2 of them) are still outstanding for this wave
       switch (min(ST - 2, kt1 - 1 - kt)) {
         case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-        case 1: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-        default: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA + NB) : "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (NA + NB)) : "memory"); break;
       }
       __builtin_amdgcn_s_barrier();                     // everyone's pieces of tile kt landed; everyone finished reading tile kt-1
       const int nxt = stage == 0 ? ST - 1 : stage - 1;  // slot of tile kt+ST-1 == slot of tile kt-1
@@ -416,9 +522,9 @@ __device__ __forceinline__ void conv_gemm_dma_body(const ConvParams& p, const in
     for (int ks = 0; ks < 2; ++ks) {
       bf16x8 af[TM], bfr[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(&As[swz(wm * 32 + i * 16 + fr, 4 * ks + fc)]);
+      for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(&As[swz(wm * (BM / 2) + i * 16 + fr, 4 * ks + fc)]);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(&Bs[swz(wn * 32 + j * 16 + fr, 4 * ks + fc)]);
+      for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(&Bs[swz(wn * (BN / 2) + j * 16 + fr, 4 * ks + fc)]);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -429,22 +535,25 @@ __device__ __forceinline__ void conv_gemm_dma_body(const ConvParams& p, const in
   }
   __syncthreads();                                     // all DMA drained (vmcnt(0) above) and all fragment reads done
 
+  // epilogue through LDS, 32 output rows per pass: pass -> wave row wm = pass / (TM/2), its tiles i = 2*(pass % (TM/2)), +1
   float* Cs = reinterpret_cast<float*>(smem);
   constexpr int VPR = BN / 8;
+  constexpr int PPW = TM / 2;                          // passes per wave row
 #pragma unroll
-  for (int pass = 0; pass < 2; ++pass) {
-    if (wm == pass) {
+  for (int pass = 0; pass < 2 * PPW; ++pass) {
+    if (wm == pass / PPW) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+      for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) Cs[(i * 16 + fc * 4 + r) * CP + wn * 32 + j * 16 + fr] = acc[i][j][r];
+          for (int r = 0; r < 4; ++r)
+            Cs[(ii * 16 + fc * 4 + r) * CP + wn * (BN / 2) + j * 16 + fr] = acc[2 * (pass % PPW) + ii][j][r];
     }
     __syncthreads();
-    for (int vi = tid; vi < (BM / 2) * VPR; vi += 256) {
+    for (int vi = tid; vi < 32 * VPR; vi += 256) {
       const int row = vi / VPR, cv = vi - row * VPR;
-      const int m = m0 + pass * (BM / 2) + row;
+      const int m = m0 + (pass / PPW) * (BM / 2) + (pass % PPW) * 32 + row;
       const int n = n0 + cv * 8;
       if (m >= p.M || n >= p.Cout) continue;
       const float* c = Cs + row * CP + cv * 8;
@@ -465,9 +574,16 @@ __device__ __forceinline__ void conv_gemm_dma_body(const ConvParams& p, const in
 }
 
 
-template <bool IS1X1, bool SPLITK, int ST = 1>
+template <bool IS1X1, bool SPLITK, int ST = 1, int MODE = 0>
 __global__ __launch_bounds__(256) void k_conv_gemm_dma(ConvParams p) {
-  conv_gemm_dma_body<IS1X1, SPLITK, ST>(p, blockIdx.z);
+  conv_gemm_dma_body<IS1X1, SPLITK, ST, 64, 64, MODE>(p, blockIdx.z);
+}
+
+// larger block tiles for the many-row problems (batched encoder / decoder convs): a 64x64 tile moves 16 KB global -> LDS per
+// 0.52 MFLOP, which caps a CU at its ~70 GB/s L2 -> LDS rate (MI355X_MICROARCH.md, 'Indexed rows: gather into LDS')
+template <bool IS1X1, int ST, int BM, int BN, bool FAST>
+__global__ __launch_bounds__(256) void k_conv_gemm_dma_big(ConvParams p) {
+  conv_gemm_dma_body<IS1X1, false, ST, BM, BN, FAST ? 1 : 0>(p, 0);
 }
 
 // up to 4 GEMMs of identical shape (different operands) as ONE launch: blockIdx.z selects the operand set.  The per-layer
@@ -476,11 +592,12 @@ __global__ __launch_bounds__(256) void k_conv_gemm_dma(ConvParams p) {
 struct GroupPtrs {
   const bf16* x[4]; const bf16* w[4]; const float* bias[4]; const void* res[4]; void* y[4]; bf16* y2[4];
 };
+template <bool FAST>
 __global__ __launch_bounds__(256) void k_gemm_dma_grouped(ConvParams p, GroupPtrs g) {
   const int z = blockIdx.z;
   ConvParams q = p;
   q.x = g.x[z]; q.w = g.w[z]; q.bias = g.bias[z]; q.res = g.res[z]; q.y = g.y[z]; q.y2 = g.y2[z];
-  conv_gemm_dma_body<true, false>(q, 0);
+  conv_gemm_dma_body<true, false, 1, 64, 64, FAST ? 1 : 0>(q, 0);
 }
 
 // sum the split-K slabs in slice order and apply the fused epilogue; thread = 8 channels of one row
@@ -522,6 +639,11 @@ void launch(const ConvParams& p, bool is1x1, int splits, hipStream_t s) {
       } else if (st == 3) {
         if (is1x1) hipLaunchKernelGGL((k_conv_gemm_dma<true, false, 3>), grid, dim3(256), 0, s, p);
         else hipLaunchKernelGGL((k_conv_gemm_dma<false, false, 3>), grid, dim3(256), 0, s, p);
+      } else if (p.fast_ok == 2) {
+        hipLaunchKernelGGL((k_conv_gemm_dma<false, false, 1, 2>), grid, dim3(256), 0, s, p);
+      } else if (p.fast_ok) {
+        if (is1x1) hipLaunchKernelGGL((k_conv_gemm_dma<true, false, 1, 1>), grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((k_conv_gemm_dma<false, false, 1, 1>), grid, dim3(256), 0, s, p);
       } else {
         if (is1x1) hipLaunchKernelGGL((k_conv_gemm_dma<true, false>), grid, dim3(256), 0, s, p);
         else hipLaunchKernelGGL((k_conv_gemm_dma<false, false>), grid, dim3(256), 0, s, p);
@@ -537,6 +659,18 @@ void launch(const ConvParams& p, bool is1x1, int splits, hipStream_t s) {
   } else {
     if (is1x1) hipLaunchKernelGGL((k_conv_gemm<BM, BN, PF, true, false>), grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL((k_conv_gemm<BM, BN, PF, false, false>), grid, dim3(256), 0, s, p);
+  }
+}
+
+template <int BM, int BN>
+void launch_big(const ConvParams& p, bool is1x1, int st, hipStream_t s) {
+  dim3 grid((p.M + BM - 1) / BM, (p.Cout + BN - 1) / BN, 1);
+  if (st == 2) {
+    if (is1x1) hipLaunchKernelGGL((k_conv_gemm_dma_big<true, 2, BM, BN, true>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((k_conv_gemm_dma_big<false, 2, BM, BN, true>), grid, dim3(256), 0, s, p);
+  } else {
+    if (is1x1) hipLaunchKernelGGL((k_conv_gemm_dma_big<true, 1, BM, BN, true>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((k_conv_gemm_dma_big<false, 1, BM, BN, true>), grid, dim3(256), 0, s, p);
   }
 }
 
@@ -599,6 +733,15 @@ static int conv_setup(const rmem_conv_desc* d, const void* x, const void* w, con
   p.act_begin = d->act_begin;
   p.steps_per_split = (p.K + 63) / 64;
   auto al = [](const void* q, int a) { return q == nullptr || ((uintptr_t)q % a) == 0; };
+  {
+    static const bool fast_on = !(getenv("RMEM_GEMM_FAST") && atoi(getenv("RMEM_GEMM_FAST")) == 0);   // kernel experiments only
+    p.x_elems = is1x1 ? (long)(p.M - 1) * p.ldx + p.Cin : (long)nb * p.H * p.W * p.Cin;
+    const long shift = is1x1 ? 0 : ((long)p.pad * p.W + p.pad) * p.Cin;
+    const long lim = (1L << 31) - (1L << 22);          // every in-range byte offset stays below 2^31 (masked lanes may wrap: unused)
+    const bool small = (p.x_elems + shift) * 2 < lim && (long)p.Cout * p.K * 2 < lim;
+    p.fast_ok = fast_on && small && p.Cin % 64 == 0 && p.KH * p.KW <= 32;
+    if (fast_on && small && !is1x1 && p.Cin == 8 && p.KW <= 8 && p.KH <= 32) p.fast_ok = 2;   // row-run form (the 7x7 stem)
+  }
   p.vec_ok = p.Cout % 8 == 0 && p.ldo % 8 == 0 && al(y, 16) && al(bias, 16) &&
              (!residual || (p.ldr % 8 == 0 && al(residual, 16))) && (!y2 || (p.ld2 % 8 == 0 && al(y2, 16)));
   return 0;
@@ -626,6 +769,17 @@ extern "C" int rmem_conv2d_nhwc(const rmem_conv_desc* d, const void* x, const vo
       splits = (nk + p.steps_per_split - 1) / p.steps_per_split;   // no empty slice
       p.slabs = (float*)workspace;
     }
+    // 128x128 tiles halve the global -> LDS bytes per flop; they pay only where the k-loop dominates (K >= 512) and there are
+    // enough tiles to balance 256 CUs.  Measured per layer with 8 images / 4 clips per launch: 121x213 3x3 128->128 563 -> 662
+    // TFLOP/s, 512->1024 stride 2 393 -> 470; shallow-K 1x1 layers (64->256, 128->512) lose 20-40 % and stay on 64x64.
+    static const int big_thr = getenv("RMEM_GEMM_BIG") ? atoi(getenv("RMEM_GEMM_BIG")) : 512;
+    static const int big_k = getenv("RMEM_GEMM_BIG_K") ? atoi(getenv("RMEM_GEMM_BIG_K")) : 512;
+    static const int big_st = getenv("RMEM_GEMM_BIG_ST") ? atoi(getenv("RMEM_GEMM_BIG_ST")) : 1;
+    if (splits == 1 && big_thr > 0 && p.fast_ok == 1 && p.Cout >= 128 && p.K >= big_k &&
+        (long)((p.M + 127) / 128) * ((p.Cout + 127) / 128) >= big_thr) {
+      launch_big<128, 128>(p, is1x1, big_st, s);
+      return rmem_check_launch("rmem_conv2d_nhwc");
+    }
     launch<64, 64, 4>(p, is1x1, splits, s);
   }
   return rmem_check_launch("rmem_conv2d_nhwc");
@@ -646,6 +800,7 @@ extern "C" int rmem_linear_grouped(const rmem_conv_desc* d, int n, const void* c
     g.x[i] = pi.x; g.w[i] = pi.w; g.bias[i] = pi.bias; g.res[i] = pi.res; g.y[i] = pi.y; g.y2[i] = nullptr;
   }
   dim3 grid((p.M + 63) / 64, (p.Cout + 63) / 64, n);
-  hipLaunchKernelGGL(k_gemm_dma_grouped, grid, dim3(256), 0, (hipStream_t)stream, p, g);
+  if (p.fast_ok == 1) hipLaunchKernelGGL(k_gemm_dma_grouped<true>, grid, dim3(256), 0, (hipStream_t)stream, p, g);
+  else hipLaunchKernelGGL(k_gemm_dma_grouped<false>, grid, dim3(256), 0, (hipStream_t)stream, p, g);
   return rmem_check_launch("rmem_linear_grouped");
 }
