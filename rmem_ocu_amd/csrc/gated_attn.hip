@@ -642,9 +642,9 @@ __global__ __launch_bounds__(256) void k_gp_combine_dwconv(GpCombine p) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = 0.f;
 #pragma unroll
-    for (int dy = 0; dy < 5; ++dy)
+    for (int dx = 0; dx < 5; ++dx)                   // dx outer, dy inner: the summation order of k_dwconv5 (bit-identical)
 #pragma unroll
-      for (int dx = 0; dx < 5; ++dx) {
+      for (int dy = 0; dy < 5; ++dy) {
         const bf16x8 d = *reinterpret_cast<const bf16x8*>(&tile[((oy + dy) * (CT_W + 4) + ox + dx) * CT_C + ch8 * 8]);
         const float* wt = &wl[(dy * 5 + dx) * CT_C + ch8 * 8];
         const f32x4 w0 = *reinterpret_cast<const f32x4*>(wt), w1 = *reinterpret_cast<const f32x4*>(wt + 4);

@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void k_add_bf16_grouped(AddGroup g, long n8) {
 }
 
 // ------------------------------------------------------------------ GroupNorm (NHWC)
-constexpr int GN_SPLITS = 32;
+constexpr int GN_SPLITS = 64;
 
 __device__ __forceinline__ void gn_load8(const bf16* p, float (&f)[8]) {
   const bf16x8 d = *reinterpret_cast<const bf16x8*>(p);
@@ -194,7 +194,83 @@ __global__ __launch_bounds__(256) void k_gn_stats(const TI* x, int M, int C, int
   }
 }
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+// (mean, rstd) of `groups` (<= 64) groups from the per-split partials, by 4 threads per group in a fixed summation order
+// (every consumer of a workspace gets bit-identical statistics).  Call with all 256 threads, then __syncthreads().
+__device__ __forceinline__ void gn_finalize(const float* ws, int groups, float n, float eps, float* s_mean, float* s_rstd) {
+  const int g = threadIdx.x >> 2, q = threadIdx.x & 3;
+  float s = 0.f, ss = 0.f;
+  if (g < groups) {
+    const float* w = ws + ((long)g * GN_SPLITS + q * (GN_SPLITS / 4)) * 2;
+#pragma unroll
+    for (int i = 0; i < GN_SPLITS / 4; ++i) { s += w[2 * i]; ss += w[2 * i + 1]; }
+  }
+  s += __shfl_xor(s, 1); ss += __shfl_xor(ss, 1);
+  s += __shfl_xor(s, 2); ss += __shfl_xor(ss, 2);
+  if (g < groups && q == 0) {
+    const float mean = s / n;
+    const float var = fmaxf(ss / n - mean * mean, 0.f);
+    s_mean[g] = mean;
+    s_rstd[g] = rsqrtf(var + eps);
+  }
+}
+
+// Row-coalesced statistics for C = 128 .. 2048 (256 % (C/8) == 0): thread = (fixed 8 channels, every RPI-th row), so a wave
+// reads whole contiguous rows; 4 loads in flight per thread; per-group sums through LDS in a fixed order.
+// grid (GN_SPLITS, 1, images)
+template <typename TI>
+__global__ __launch_bounds__(256) void k_gn_stats_rows(const TI* x, int M, int C, int cpg, float* ws) {
+  const int groups = C / cpg;
+  x += (long)blockIdx.z * M * C;
+  ws += (long)blockIdx.z * groups * GN_SPLITS * 2;
+  const int sp = blockIdx.x;
+  const int vpr = C / 8, rpi = 256 / vpr;
+  const int c = threadIdx.x % vpr, rl = threadIdx.x / vpr;
+  const int rows_per = (M + GN_SPLITS - 1) / GN_SPLITS;
+  const int r0 = sp * rows_per, r1 = min(M, r0 + rows_per);
+  float s = 0.f, ss = 0.f;
+  for (int r = r0 + rl; r < r1; r += 4 * rpi) {
+    float d[4][8];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int rr = r + u * rpi;
+      if (rr < r1) gn_load8(x + (long)rr * C + c * 8, d[u]);
+      else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) d[u][j] = 0.f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { s += d[u][j]; ss += d[u][j] * d[u][j]; }
+  }
+  __shared__ float sh[2][256];
+  sh[0][threadIdx.x] = s;
+  sh[1][threadIdx.x] = ss;
+  __syncthreads();
+  if (threadIdx.x < groups) {
+    const int g = threadIdx.x, cpv = cpg / 8;
+    float a = 0.f, b = 0.f;
+    for (int l = 0; l < rpi; ++l)
+      for (int v = 0; v < cpv; ++v) { a += sh[0][l * vpr + g * cpv + v]; b += sh[1][l * vpr + g * cpv + v]; }
+    ws[(g * GN_SPLITS + sp) * 2 + 0] = a;
+    ws[(g * GN_SPLITS + sp) * 2 + 1] = b;
+  }
+}
+
+// exact-form GELU 0.5 x (1 + erf(x / sqrt 2)) with erf from Abramowitz-Stegun 7.1.26 (|error| < 1.5e-7, far below the bf16 the
+// callers round to): 2 transcendentals + ~12 plain VALU ops instead of the ~40 of erff.  For x < 0 the factor 1 + erf is formed
+// directly as poly * exp(-z^2) (= erfc), without the cancellation of 1 - 0.9999...
+__device__ __forceinline__ float gelu_erf(float x) {
+  const float z = fabsf(x) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.f));
+  float q = fmaf(1.061405429f, t, -1.453152027f);
+  q = fmaf(q, t, 1.421413741f);
+  q = fmaf(q, t, -0.284496736f);
+  q = fmaf(q, t, 0.254829592f);
+  const float erfc_z = q * t * __builtin_amdgcn_exp2f(z * z * -1.4426950408889634f);
+  return 0.5f * x * (x < 0.f ? erfc_z : 2.f - erfc_z);
+}
 
 template <typename TI>
 __global__ __launch_bounds__(256) void k_gn_apply(const TI* x, int M, int C, int cpg, int groups, const float* ws,
@@ -203,18 +279,7 @@ __global__ __launch_bounds__(256) void k_gn_apply(const TI* x, int M, int C, int
   y += (long)blockIdx.y * M * C;
   ws += (long)blockIdx.y * groups * GN_SPLITS * 2;
   __shared__ float s_mean[64], s_rstd[64];
-  if (threadIdx.x < groups) {
-    float s = 0.f, ss = 0.f;
-    for (int i = 0; i < GN_SPLITS; ++i) {
-      s += ws[(threadIdx.x * GN_SPLITS + i) * 2];
-      ss += ws[(threadIdx.x * GN_SPLITS + i) * 2 + 1];
-    }
-    const float n = (float)M * (float)cpg;
-    const float mean = s / n;
-    const float var = fmaxf(ss / n - mean * mean, 0.f);
-    s_mean[threadIdx.x] = mean;
-    s_rstd[threadIdx.x] = rsqrtf(var + eps);
-  }
+  gn_finalize(ws, groups, (float)M * (float)cpg, eps, s_mean, s_rstd);
   __syncthreads();
   const int vpr = C / 8;
   const long total = (long)M * vpr;
@@ -236,6 +301,51 @@ __global__ __launch_bounds__(256) void k_gn_apply(const TI* x, int M, int C, int
   }
 }
 
+// Row-coalesced apply for C = 128 .. 2048: thread = (fixed 8 channels, 8 rows); gamma / beta / statistics in registers, all 8
+// loads issued before the first use.  grid (ceil(M / (8 * rpi)), images).  Same arithmetic as k_gn_apply (bit-identical).
+template <typename TI>
+__global__ __launch_bounds__(256) void k_gn_apply_rows(const TI* x, int M, int C, int cpg, int groups, const float* ws,
+                                                       const float* gamma, const float* beta, float eps, int act, bf16* y) {
+  x += (long)blockIdx.y * M * C;
+  y += (long)blockIdx.y * M * C;
+  ws += (long)blockIdx.y * groups * GN_SPLITS * 2;
+  __shared__ float s_mean[64], s_rstd[64];
+  gn_finalize(ws, groups, (float)M * (float)cpg, eps, s_mean, s_rstd);
+  __syncthreads();
+  constexpr int UN = 8;
+  const int vpr = C / 8, rpi = 256 / vpr;
+  const int c = threadIdx.x % vpr, rl = threadIdx.x / vpr, c0 = c * 8;
+  const float mean = s_mean[c0 / cpg], rstd = s_rstd[c0 / cpg];
+  float gm[8], bt[8];
+  {
+    const f32x4 g0v = *reinterpret_cast<const f32x4*>(gamma + c0), g1v = *reinterpret_cast<const f32x4*>(gamma + c0 + 4);
+    const f32x4 b0v = *reinterpret_cast<const f32x4*>(beta + c0), b1v = *reinterpret_cast<const f32x4*>(beta + c0 + 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { gm[j] = g0v[j]; gm[4 + j] = g1v[j]; bt[j] = b0v[j]; bt[4 + j] = b1v[j]; }
+  }
+  const int rb = blockIdx.x * (UN * rpi) + rl;
+  float d[UN][8];
+#pragma unroll
+  for (int u = 0; u < UN; ++u) {
+    const int r = rb + u * rpi;
+    if (r < M) gn_load8(x + (long)r * C + c0, d[u]);
+  }
+#pragma unroll
+  for (int u = 0; u < UN; ++u) {
+    const int r = rb + u * rpi;
+    if (r >= M) continue;
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float f = (d[u][j] - mean) * rstd * gm[j] + bt[j];
+      if (act == 1) f = fmaxf(f, 0.f);
+      else if (act == 2) f = gelu_erf(f);
+      o[j] = (bf16)f;
+    }
+    *reinterpret_cast<bf16x8*>(y + (long)r * C + c0) = o;
+  }
+}
+
 // ------------------------------------------------------------------ depth-wise 5x5 (NHWC, pad 2)
 // thread = (pixel, 8 channels); weights pre-transposed to [25][C] fp32
 __global__ __launch_bounds__(256) void k_dwconv5(const bf16* x, const float* w, bf16* y, int H, int W, int C) {
@@ -249,12 +359,12 @@ __global__ __launch_bounds__(256) void k_dwconv5(const bf16* x, const float* w, 
   float acc[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-  for (int dy = 0; dy < 5; ++dy) {
-    const int yy = py + dy - 2;
-    if ((unsigned)yy >= (unsigned)H) continue;
-    for (int dx = 0; dx < 5; ++dx) {
-      const int xx = px + dx - 2;
-      if ((unsigned)xx >= (unsigned)W) continue;
+  for (int dx = 0; dx < 5; ++dx) {             // dx outer, dy inner: the summation order of the fused k_gn_dwconv5 (bit-identical)
+    const int xx = px + dx - 2;
+    if ((unsigned)xx >= (unsigned)W) continue;
+    for (int dy = 0; dy < 5; ++dy) {
+      const int yy = py + dy - 2;
+      if ((unsigned)yy >= (unsigned)H) continue;
       const bf16x8 d = *reinterpret_cast<const bf16x8*>(x + ((long)yy * W + xx) * C + c0);
       const float* wt = w + (dy * 5 + dx) * C + c0;
       const f32x4 w0 = *reinterpret_cast<const f32x4*>(wt), w1 = *reinterpret_cast<const f32x4*>(wt + 4);
@@ -285,66 +395,97 @@ __global__ __launch_bounds__(256) void k_gn_dwconv5(const bf16* x, const float* 
   const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
   const int c0 = blockIdx.y * DT_C;
   const int ng = DT_C / cpg, g0 = c0 / cpg;
-  if (tid < ng) {
-    float s = 0.f, ss = 0.f;
-    for (int i = 0; i < GN_SPLITS; ++i) {
-      s += ws[((g0 + tid) * GN_SPLITS + i) * 2];
-      ss += ws[((g0 + tid) * GN_SPLITS + i) * 2 + 1];
-    }
-    const float n = (float)M * (float)cpg;
-    const float mean = s / n;
-    const float var = fmaxf(ss / n - mean * mean, 0.f);
-    s_mean[tid] = mean;
-    s_rstd[tid] = rsqrtf(var + eps);
-  }
+  gn_finalize(ws + (long)g0 * GN_SPLITS * 2, ng, (float)M * (float)cpg, eps, s_mean, s_rstd);
   for (int i = tid; i < 25 * DT_C; i += 256) wl[i] = w[(i / DT_C) * C + c0 + (i % DT_C)];
   __syncthreads();
-  for (int i = tid; i < DT_HW * (DT_C / 8); i += 256) {
-    const int pix = i >> 3, ch8 = i & 7;
-    const int hy = pix / (DT_W + 4), hx = pix - hy * (DT_W + 4);
-    const int gy = ty * DT_H + hy - 2, gx = tx * DT_W + hx - 2;
-    bf16x8 o = {0, 0, 0, 0, 0, 0, 0, 0};
-    if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) {
-      const int cc = c0 + ch8 * 8;
-      float d[8];
-      gn_load8(x + ((long)gy * W + gx) * C + cc, d);
-      const int g = (ch8 * 8) / cpg;
-      const float mean = s_mean[g], rstd = s_rstd[g];
+  {
+    // phase 1: thread = (8 channels, every 32nd halo pixel).  All global loads of a thread are issued before the first use
+    // (a loop with the LDS store inside serialises one memory latency per pixel), gamma / beta live in registers.
+    constexpr int NIT = (DT_HW * (DT_C / 8) + 255) / 256;
+    const int c8 = tid & 7, cc = c0 + c8 * 8;
+    float gm[8], bt[8];
+    {
+      const f32x4 g0v = *reinterpret_cast<const f32x4*>(gamma + cc), g1v = *reinterpret_cast<const f32x4*>(gamma + cc + 4);
+      const f32x4 b0v = *reinterpret_cast<const f32x4*>(beta + cc), b1v = *reinterpret_cast<const f32x4*>(beta + cc + 4);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        float f = (d[j] - mean) * rstd * gamma[cc + j] + beta[cc + j];
-        if (act == 1) f = fmaxf(f, 0.f);
-        else if (act == 2) f = gelu_erf(f);
-        o[j] = (bf16)f;
-      }
+      for (int j = 0; j < 4; ++j) { gm[j] = g0v[j]; gm[4 + j] = g1v[j]; bt[j] = b0v[j]; bt[4 + j] = b1v[j]; }
     }
-    *reinterpret_cast<bf16x8*>(&tile[pix * DT_C + ch8 * 8]) = o;
+    const float mean = s_mean[(c8 * 8) / cpg], rstd = s_rstd[(c8 * 8) / cpg];
+    bf16x8 raw[NIT];
+    bool ok[NIT];
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      const int pix = (tid >> 3) + 32 * k;
+      const int hy = pix / (DT_W + 4), hx = pix - hy * (DT_W + 4);
+      const int gy = ty * DT_H + hy - 2, gx = tx * DT_W + hx - 2;
+      ok[k] = pix < DT_HW && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+      raw[k] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+      if (ok[k]) raw[k] = *reinterpret_cast<const bf16x8*>(x + ((long)gy * W + gx) * C + cc);
+    }
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      const int pix = (tid >> 3) + 32 * k;
+      bf16x8 o = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (ok[k]) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float f = ((float)raw[k][j] - mean) * rstd * gm[j] + bt[j];
+          if (act == 1) f = fmaxf(f, 0.f);
+          else if (act == 2) f = gelu_erf(f);
+          o[j] = (bf16)f;
+        }
+      }
+      if (pix < DT_HW) *reinterpret_cast<bf16x8*>(&tile[pix * DT_C + c8 * 8]) = o;
+    }
   }
   __syncthreads();
+  // thread = (8 channels, one tile column, half of the tile rows): the 4 outputs of its column slide over 8 input rows, so each
+  // LDS pixel is read once per dx and feeds up to 4 outputs (40 data + 50 weight reads per thread instead of 100 + 200)
+  static_assert(DT_H == 8 && DT_W == 16 && DT_C == 64, "thread mapping below");
+  const int ch8 = tid & 7, ox = (tid >> 3) & 15, half = tid >> 7;
+  float acc[4][8];
 #pragma unroll
-  for (int k = 0; k < DT_H * DT_W * (DT_C / 8) / 256; ++k) {
-    const int item = tid + 256 * k;
-    const int ch8 = item & 7, pp = item >> 3;
-    const int oy = pp / DT_W, ox = pp - oy * DT_W;
-    const int gy = ty * DT_H + oy, gx = tx * DT_W + ox;
-    if (gy >= H || gx >= W) continue;
-    float acc[8];
+  for (int o = 0; o < 4; ++o)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    for (int j = 0; j < 8; ++j) acc[o][j] = 0.f;
+#pragma unroll 1
+  for (int dx = 0; dx < 5; ++dx) {
+    float wv[5][8];
 #pragma unroll
-    for (int dy = 0; dy < 5; ++dy)
+    for (int dy = 0; dy < 5; ++dy) {
+      const float* wt = &wl[(dy * 5 + dx) * DT_C + ch8 * 8];
+      const f32x4 w0 = *reinterpret_cast<const f32x4*>(wt), w1 = *reinterpret_cast<const f32x4*>(wt + 4);
 #pragma unroll
-      for (int dx = 0; dx < 5; ++dx) {
-        const bf16x8 d = *reinterpret_cast<const bf16x8*>(&tile[((oy + dy) * (DT_W + 4) + ox + dx) * DT_C + ch8 * 8]);
-        const float* wt = &wl[(dy * 5 + dx) * DT_C + ch8 * 8];
-        const f32x4 w0 = *reinterpret_cast<const f32x4*>(wt), w1 = *reinterpret_cast<const f32x4*>(wt + 4);
+      for (int j = 0; j < 4; ++j) { wv[dy][j] = w0[j]; wv[dy][4 + j] = w1[j]; }
+    }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { acc[j] += (float)d[j] * w0[j]; acc[4 + j] += (float)d[4 + j] * w1[j]; }
+    for (int r = 0; r < 8; ++r) {
+      const bf16x8 d = *reinterpret_cast<const bf16x8*>(&tile[((4 * half + r) * (DT_W + 4) + ox + dx) * DT_C + ch8 * 8]);
+      float df[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) df[j] = (float)d[j];
+#pragma unroll
+      for (int dy = 0; dy < 5; ++dy) {
+        const int o = r - dy;
+        if (o >= 0 && o < 4) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[o][j] += df[j] * wv[dy][j];
+        }
       }
-    bf16x8 o;
+    }
+  }
+  const int gx = tx * DT_W + ox;
+  if (gx < W) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = (bf16)acc[j];
-    *reinterpret_cast<bf16x8*>(y + ((long)gy * W + gx) * C + c0 + ch8 * 8) = o;
+    for (int o = 0; o < 4; ++o) {
+      const int gy = ty * DT_H + 4 * half + o;
+      if (gy < H) {
+        bf16x8 ov;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ov[j] = (bf16)acc[o][j];
+        *reinterpret_cast<bf16x8*>(y + ((long)gy * W + gx) * C + c0 + ch8 * 8) = ov;
+      }
+    }
   }
 }
 
@@ -420,6 +561,31 @@ extern "C" int rmem_add_bf16_grouped(int n, const void* const* a, const void* co
   return rmem_check_launch("rmem_add_bf16_grouped");
 }
 
+namespace {
+template <typename TI>
+void gn_launch_stats(const TI* x, int images, int M, int C, int cpg, float* ws, hipStream_t s) {
+  const int vpr = C / 8;
+  if (vpr <= 256 && 256 % vpr == 0)
+    hipLaunchKernelGGL(k_gn_stats_rows<TI>, dim3(GN_SPLITS, 1, images), dim3(256), 0, s, x, M, C, cpg, ws);
+  else
+    hipLaunchKernelGGL(k_gn_stats<TI>, dim3(C / cpg, GN_SPLITS, images), dim3(256), 0, s, x, M, C, cpg, ws);
+}
+template <typename TI>
+void gn_launch_apply(const TI* x, int images, int M, int C, int cpg, const float* ws, const float* gamma, const float* beta, float eps,
+                     int act, bf16* y, hipStream_t s) {
+  const int vpr = C / 8, groups = C / cpg;
+  if (vpr <= 256 && 256 % vpr == 0) {
+    const int rows_per_wg = 8 * (256 / vpr);
+    hipLaunchKernelGGL(k_gn_apply_rows<TI>, dim3((M + rows_per_wg - 1) / rows_per_wg, images), dim3(256), 0, s, x, M, C, cpg, groups, ws,
+                       gamma, beta, eps, act, y);
+  } else {
+    const long total = (long)M * vpr;
+    const int blocks = (int)min((long)2048, (total + 255) / 256);
+    hipLaunchKernelGGL(k_gn_apply<TI>, dim3(blocks, images), dim3(256), 0, s, x, M, C, cpg, groups, ws, gamma, beta, eps, act, y);
+  }
+}
+}  // namespace
+
 extern "C" size_t rmem_groupnorm_workspace_bytes(int groups) { return (size_t)groups * GN_SPLITS * 2 * sizeof(float); }
 
 static int gn_check(const void* x, const void* y, const float* gamma, const float* beta, const float* ws, int groups, int C, int act,
@@ -436,10 +602,8 @@ extern "C" int rmem_groupnorm_nhwc_images(const void* x, int images, int M, int 
   if (gn_check(x, y, gamma, beta, workspace, groups, C, act, M, images)) return -1;
   const int cpg = C / groups;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_gn_stats<bf16>, dim3(groups, GN_SPLITS, images), dim3(256), 0, s, (const bf16*)x, M, C, cpg, workspace);
-  const long total = (long)M * (C / 8);
-  const int blocks = (int)min((long)2048, (total + 255) / 256);
-  hipLaunchKernelGGL(k_gn_apply<bf16>, dim3(blocks, images), dim3(256), 0, s, (const bf16*)x, M, C, cpg, groups, workspace, gamma, beta, eps, act, (bf16*)y);
+  gn_launch_stats((const bf16*)x, images, M, C, cpg, workspace, s);
+  gn_launch_apply((const bf16*)x, images, M, C, cpg, workspace, gamma, beta, eps, act, (bf16*)y, s);
   return rmem_check_launch("rmem_groupnorm_nhwc_images");
 }
 
@@ -451,10 +615,8 @@ extern "C" int rmem_groupnorm_nhwc(const void* x, int M, int C, int groups, cons
   RMEM_REQUIRE(act >= 0 && act <= 2 && M > 0, "rmem_groupnorm_nhwc: bad act / M");
   const int cpg = C / groups;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_gn_stats<bf16>, dim3(groups, GN_SPLITS), dim3(256), 0, s, (const bf16*)x, M, C, cpg, workspace);
-  const long total = (long)M * (C / 8);
-  const int blocks = (int)min((long)2048, (total + 255) / 256);
-  hipLaunchKernelGGL(k_gn_apply<bf16>, dim3(blocks), dim3(256), 0, s, (const bf16*)x, M, C, cpg, groups, workspace, gamma, beta, eps, act, (bf16*)y);
+  gn_launch_stats((const bf16*)x, 1, M, C, cpg, workspace, s);
+  gn_launch_apply((const bf16*)x, 1, M, C, cpg, workspace, gamma, beta, eps, act, (bf16*)y, s);
   return rmem_check_launch("rmem_groupnorm_nhwc");
 }
 
@@ -466,10 +628,8 @@ extern "C" int rmem_groupnorm_f32_nhwc(const float* x, int M, int C, int groups,
   RMEM_REQUIRE(act >= 0 && act <= 2 && M > 0, "rmem_groupnorm_f32_nhwc: bad act / M");
   const int cpg = C / groups;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_gn_stats<float>, dim3(groups, GN_SPLITS), dim3(256), 0, s, x, M, C, cpg, workspace);
-  const long total = (long)M * (C / 8);
-  const int blocks = (int)min((long)2048, (total + 255) / 256);
-  hipLaunchKernelGGL(k_gn_apply<float>, dim3(blocks), dim3(256), 0, s, x, M, C, cpg, groups, workspace, gamma, beta, eps, act, (bf16*)y);
+  gn_launch_stats(x, 1, M, C, cpg, workspace, s);
+  gn_launch_apply(x, 1, M, C, cpg, workspace, gamma, beta, eps, act, (bf16*)y, s);
   return rmem_check_launch("rmem_groupnorm_f32_nhwc");
 }
 
@@ -492,7 +652,7 @@ extern "C" int rmem_gn_act_dwconv5x5_nhwc_images(const void* x, int images, int 
   RMEM_REQUIRE(act >= 0 && act <= 2, "rmem_gn_act_dwconv5x5_nhwc: bad act");
   const int M = H * W;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_gn_stats<bf16>, dim3(groups, GN_SPLITS, images), dim3(256), 0, s, (const bf16*)x, M, C, cpg, workspace);
+  gn_launch_stats((const bf16*)x, images, M, C, cpg, workspace, s);
   const dim3 grid(((W + DT_W - 1) / DT_W) * ((H + DT_H - 1) / DT_H), C / DT_C, images);
   hipLaunchKernelGGL(k_gn_dwconv5, grid, dim3(256), 0, s, (const bf16*)x, workspace, gamma, beta, eps, cpg, act, w_t, (bf16*)y, H, W, C, M);
   return rmem_check_launch("rmem_gn_act_dwconv5x5_nhwc");
