@@ -335,7 +335,8 @@ __device__ inline void buf_load_lds16(rsrc_t, lptr_t, int, int) {}
 template <bool IS1X1, bool SPLITK, int ST = 1, int BM = 64, int BN = 64, int MODE = 0>
 __device__ __forceinline__ void conv_gemm_dma_body(const ConvParams& p, const int zslice) {
   constexpr bool FAST = MODE != 0;
-  constexpr bool ROWRUN = MODE == 2;      // Cin == 8, KW <= 8 (the ResNet stem): one k-step = the KW adjacent pixels of one filter row
+  constexpr bool ROWRUN = MODE == 2;      // Cin % 64 != 0 (stem 7x7x8, id bank 17x17x16): the KW * Cin elements of one filter row are
+                                          // contiguous in NHWC, so a filter row is walked as spr = ceil(KW * Cin / 64) k-steps
   constexpr int BK = 64, TM = BM / 32, TN = BN / 32;   // 2x2 waves, each (BM/2) x (BN/2) = TM x TN tiles of 16x16
   constexpr int NA = BM / 32, NB = BN / 32;             // DMA wave-instructions (8 rows x 128 B each) per wave and k-step
   constexpr int CP = BN + 4;
@@ -347,7 +348,9 @@ __device__ __forceinline__ void conv_gemm_dma_body(const ConvParams& p, const in
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: LDS-DMA destinations stay in SGPRs
   const int wm = wave >> 1, wn = wave & 1;
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-  const int nk_total = ROWRUN ? p.KH : (p.K + BK - 1) / BK;
+  const int rr_len = p.KW * p.Cin;                        // ROWRUN: elements per filter row, k-steps per filter row
+  const int rr_spr = (rr_len + BK - 1) / BK;
+  const int nk_total = ROWRUN ? p.KH * rr_spr : (p.K + BK - 1) / BK;
   const int kt0 = SPLITK ? zslice * p.steps_per_split : 0;
   const int kt1 = SPLITK ? min(nk_total, kt0 + p.steps_per_split) : nk_total;
 
@@ -360,8 +363,9 @@ __device__ __forceinline__ void conv_gemm_dma_body(const ConvParams& p, const in
   // FAST: per-lane byte offsets (31 bits) and tap masks; wave-uniform k-walk
   constexpr int OOB = (int)0x80000000;
   int f_aoff[NA], f_boff[NB];
-  unsigned f_amask[NA];
+  unsigned f_amask[NA], f_cmask[NA];
   int s_ci = 0, s_kw = 0, s_tap = 0, s_aoff = 0;         // FAST is never split along K: the walk starts at tap 0, channel 0
+  int s_boff = 0;                                        // ROWRUN: s_tap = filter row, s_kw = step inside the row
   if constexpr (FAST) {
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
@@ -371,6 +375,7 @@ __device__ __forceinline__ void conv_gemm_dma_body(const ConvParams& p, const in
       if (IS1X1) {
         f_aoff[i] = m < p.M ? (m * p.ldx + c * 8) * 2 : OOB;
         f_amask[i] = 1u;
+        f_cmask[i] = 0u;
       } else {
         const int img = m / p.HoWo, rem = m - img * p.HoWo;
         const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
@@ -378,9 +383,13 @@ __device__ __forceinline__ void conv_gemm_dma_body(const ConvParams& p, const in
         // offset relative to the (virtual) pixel (-pad, -pad) of image 0, so that it is never negative
         f_aoff[i] = (((img * p.H + hi0 + p.pad) * p.W + wi0 + p.pad) * p.Cin + c * 8) * 2;
         unsigned cm = 0, mask = 0;
-        if (ROWRUN) {           // chunk c of a k-step is pixel wi0 + c of filter row kh = step; bit kh of the mask = row inside the image
+        if (ROWRUN) {           // bit kh of mask: filter row inside the image; bit j of cm: this chunk of step j is a real tap inside it
           for (int kh = 0; kh < p.KH; ++kh) mask |= ((unsigned)(hi0 + kh) < (unsigned)p.H ? 1u : 0u) << kh;
-          if (c >= p.KW || (unsigned)(wi0 + c) >= (unsigned)p.W) mask = 0;
+          for (int j = 0; j < rr_spr; ++j) {
+            const int e = j * BK + c * 8;
+            if (e < rr_len && (unsigned)(wi0 + e / p.Cin) < (unsigned)p.W) cm |= 1u << j;
+          }
+          f_cmask[i] = cm;
         } else {
           for (int kw = 0; kw < p.KW; ++kw) cm |= ((unsigned)(wi0 + kw) < (unsigned)p.W ? 1u : 0u) << kw;
           for (int kh = 0; kh < p.KH; ++kh)
@@ -394,7 +403,8 @@ __device__ __forceinline__ void conv_gemm_dma_body(const ConvParams& p, const in
       const int r = (BN / 4) * wave + 8 * i + (lane >> 3);
       const int c = (lane & 7) ^ ((r >> 1) & 7);
       const int n = n0 + r;
-      f_boff[i] = (n < p.Cout && (!ROWRUN || c < p.KW)) ? (n * p.K + c * 8) * 2 : OOB;
+      // ROWRUN: chunks past the end of a filter row read the next row's weights (or 0 past the buffer); A is zero there
+      f_boff[i] = n < p.Cout ? (n * p.K + c * 8) * 2 : OOB;
     }
   } else {
 #pragma unroll
@@ -441,15 +451,23 @@ __device__ __forceinline__ void conv_gemm_dma_body(const ConvParams& p, const in
       const int soff_a = IS1X1 ? kt * (BK * 2) : s_aoff;
 #pragma unroll
       for (int i = 0; i < NA; ++i) {
-        const int voff = IS1X1 ? f_aoff[i] : (((f_amask[i] >> s_tap) & 1u) ? f_aoff[i] : OOB);
+        const int voff = IS1X1 ? f_aoff[i]
+                         : ROWRUN ? ((((f_amask[i] >> s_tap) & (f_cmask[i] >> s_kw)) & 1u) ? f_aoff[i] : OOB)
+                                  : (((f_amask[i] >> s_tap) & 1u) ? f_aoff[i] : OOB);
         buf_load_lds16(rsrc_a, (lptr_t)(As + ((BM / 4) * wave + 8 * i) * 128), voff, soff_a);
       }
 #pragma unroll
       for (int i = 0; i < NB; ++i)
-        buf_load_lds16(rsrc_b, (lptr_t)(Bs + ((BN / 4) * wave + 8 * i) * 128), f_boff[i], ROWRUN ? kt * p.KW * 16 : kt * (BK * 2));
-      if (ROWRUN) {             // next filter row
-        ++s_tap;
-        s_aoff += p.W * 16;
+        buf_load_lds16(rsrc_b, (lptr_t)(Bs + ((BN / 4) * wave + 8 * i) * 128), f_boff[i], ROWRUN ? s_boff : kt * (BK * 2));
+      if (ROWRUN) {             // next 64 elements of this filter row, or the start of the next row
+        s_aoff += BK * 2;
+        s_boff += BK * 2;
+        if (++s_kw == rr_spr) {
+          s_kw = 0;
+          ++s_tap;
+          s_aoff += (p.W * p.Cin - rr_spr * BK) * 2;
+          s_boff += (rr_len - rr_spr * BK) * 2;
+        }
       } else if (!IS1X1) {      // advance the uniform k-walk by one step (64 channels of one tap)
         s_ci += BK;
         s_aoff += BK * 2;
@@ -592,12 +610,12 @@ __global__ __launch_bounds__(256) void k_conv_gemm_dma_big(ConvParams p) {
 struct GroupPtrs {
   const bf16* x[4]; const bf16* w[4]; const float* bias[4]; const void* res[4]; void* y[4]; bf16* y2[4];
 };
-template <bool FAST>
+template <bool FAST, int ST = 1>
 __global__ __launch_bounds__(256) void k_gemm_dma_grouped(ConvParams p, GroupPtrs g) {
   const int z = blockIdx.z;
   ConvParams q = p;
   q.x = g.x[z]; q.w = g.w[z]; q.bias = g.bias[z]; q.res = g.res[z]; q.y = g.y[z]; q.y2 = g.y2[z];
-  conv_gemm_dma_body<true, false, 1, 64, 64, FAST ? 1 : 0>(q, 0);
+  conv_gemm_dma_body<true, false, ST, 64, 64, FAST ? 1 : 0>(q, 0);
 }
 
 // sum the split-K slabs in slice order and apply the fused epilogue; thread = 8 channels of one row
@@ -639,11 +657,21 @@ void launch(const ConvParams& p, bool is1x1, int splits, hipStream_t s) {
       } else if (st == 3) {
         if (is1x1) hipLaunchKernelGGL((k_conv_gemm_dma<true, false, 3>), grid, dim3(256), 0, s, p);
         else hipLaunchKernelGGL((k_conv_gemm_dma<false, false, 3>), grid, dim3(256), 0, s, p);
-      } else if (p.fast_ok == 2) {
-        hipLaunchKernelGGL((k_conv_gemm_dma<false, false, 1, 2>), grid, dim3(256), 0, s, p);
       } else if (p.fast_ok) {
-        if (is1x1) hipLaunchKernelGGL((k_conv_gemm_dma<true, false, 1, 1>), grid, dim3(256), 0, s, p);
-        else hipLaunchKernelGGL((k_conv_gemm_dma<false, false, 1, 1>), grid, dim3(256), 0, s, p);
+        // few-workgroup problems (token GEMMs of the LSTT, id bank): too few resident workgroups to hide the DMA latency behind
+        // each other, so a 3-deep ring keeps two k-steps in flight inside the workgroup
+        static const int deep_wgs = getenv("RMEM_GEMM_DEEP_WGS") ? atoi(getenv("RMEM_GEMM_DEEP_WGS")) : 1024;
+        const bool deep = (long)grid.x * grid.y <= deep_wgs && p.steps_per_split >= 3;
+        if (p.fast_ok == 2) {
+          if (deep) hipLaunchKernelGGL((k_conv_gemm_dma<false, false, 3, 2>), grid, dim3(256), 0, s, p);
+          else hipLaunchKernelGGL((k_conv_gemm_dma<false, false, 1, 2>), grid, dim3(256), 0, s, p);
+        } else if (is1x1) {
+          if (deep) hipLaunchKernelGGL((k_conv_gemm_dma<true, false, 3, 1>), grid, dim3(256), 0, s, p);
+          else hipLaunchKernelGGL((k_conv_gemm_dma<true, false, 1, 1>), grid, dim3(256), 0, s, p);
+        } else {
+          if (deep) hipLaunchKernelGGL((k_conv_gemm_dma<false, false, 3, 1>), grid, dim3(256), 0, s, p);
+          else hipLaunchKernelGGL((k_conv_gemm_dma<false, false, 1, 1>), grid, dim3(256), 0, s, p);
+        }
       } else {
         if (is1x1) hipLaunchKernelGGL((k_conv_gemm_dma<true, false>), grid, dim3(256), 0, s, p);
         else hipLaunchKernelGGL((k_conv_gemm_dma<false, false>), grid, dim3(256), 0, s, p);
@@ -740,7 +768,8 @@ static int conv_setup(const rmem_conv_desc* d, const void* x, const void* w, con
     const long lim = (1L << 31) - (1L << 22);          // every in-range byte offset stays below 2^31 (masked lanes may wrap: unused)
     const bool small = (p.x_elems + shift) * 2 < lim && (long)p.Cout * p.K * 2 < lim;
     p.fast_ok = fast_on && small && p.Cin % 64 == 0 && p.KH * p.KW <= 32;
-    if (fast_on && small && !is1x1 && p.Cin == 8 && p.KW <= 8 && p.KH <= 32) p.fast_ok = 2;   // row-run form (the 7x7 stem)
+    if (!p.fast_ok && fast_on && small && !is1x1 && p.KH <= 32 && (p.KW * p.Cin + 63) / 64 <= 32 && p.KW * p.Cin >= 48)
+      p.fast_ok = 2;                                     // row-run form (7x7x8 stem, 17x17x16 id bank, 4x4x8 patch embedding)
   }
   p.vec_ok = p.Cout % 8 == 0 && p.ldo % 8 == 0 && al(y, 16) && al(bias, 16) &&
              (!residual || (p.ldr % 8 == 0 && al(residual, 16))) && (!y2 || (p.ld2 % 8 == 0 && al(y2, 16)));
@@ -800,7 +829,10 @@ extern "C" int rmem_linear_grouped(const rmem_conv_desc* d, int n, const void* c
     g.x[i] = pi.x; g.w[i] = pi.w; g.bias[i] = pi.bias; g.res[i] = pi.res; g.y[i] = pi.y; g.y2[i] = nullptr;
   }
   dim3 grid((p.M + 63) / 64, (p.Cout + 63) / 64, n);
-  if (p.fast_ok == 1) hipLaunchKernelGGL(k_gemm_dma_grouped<true>, grid, dim3(256), 0, (hipStream_t)stream, p, g);
+  static const int deep_wgs = getenv("RMEM_GEMM_DEEP_WGS") ? atoi(getenv("RMEM_GEMM_DEEP_WGS")) : 1024;
+  if (p.fast_ok == 1 && (long)grid.x * grid.y * n <= deep_wgs && p.steps_per_split >= 3)
+    hipLaunchKernelGGL((k_gemm_dma_grouped<true, 3>), grid, dim3(256), 0, (hipStream_t)stream, p, g);
+  else if (p.fast_ok == 1) hipLaunchKernelGGL(k_gemm_dma_grouped<true>, grid, dim3(256), 0, (hipStream_t)stream, p, g);
   else hipLaunchKernelGGL(k_gemm_dma_grouped<false>, grid, dim3(256), 0, (hipStream_t)stream, p, g);
   return rmem_check_launch("rmem_linear_grouped");
 }
