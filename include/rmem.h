@@ -69,6 +69,15 @@ int rmem_conv2d_nhwc(const rmem_conv_desc* desc, const void* x, const void* w, c
 int rmem_linear_grouped(const rmem_conv_desc* desc, int n, const void* const* x, const void* const* w,
                         const float* const* bias, const void* const* residual, void* const* y, void* stream);
 
+/* y = act([x | x2 sampled at stride2] * w_cat^T + bias): the closing 1x1 convolution of a ResNet bottleneck and its (strided) 1x1
+ * shortcut (encoders/resnet.py:48-68: `out = conv3(out); identity = downsample(x); out += identity; relu`) as ONE GEMM over
+ * K = desc->Cin + Cin2, so the shortcut tensor is neither written nor re-read.  desc describes the dense 1x1 problem on x
+ * (batch, H = Ho, W = Wo, Cin, Cout, relu, ldo; no residual); x2 is NHWC [batch][H2][W2][Cin2] with (H2 - 1) / stride2 + 1 == Ho;
+ * w_cat is [Cout][Cin + Cin2] bf16 (both BN-folded weights side by side), bias the sum of both folded biases.
+ * Cin and Cin2 must be multiples of 64. */
+int rmem_conv1x1_dual_nhwc(const rmem_conv_desc* desc, const void* x, const void* x2, int H2, int W2, int Cin2, int stride2,
+                           const void* w_cat, const float* bias, void* y, void* stream);
+
 /* ------------------------------------------------------------------ memory-read attention
  * out[q, 32h:32h+32] = softmax_k( (Q[q,h]+pe_cur[h]) . (K[k,h]+pe_mem[slot(k),h]) / sqrt(32) ) V[k,h]
  * over the keys named by the chunk table, plus (optionally) the per-memory-frame probability mass

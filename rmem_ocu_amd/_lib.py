@@ -46,6 +46,7 @@ SIGNATURES = {
     'rmem_add_bf16': (_i, [_vp, _vp, _vp, _ll, _vp]),
     'rmem_add_bf16_grouped': (_i, [_i, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), _ll, _vp]),
     'rmem_layernorm256_pair': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _vp]),
+    'rmem_conv1x1_dual_nhwc': (_i, [C.POINTER(ConvDesc), _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     'rmem_linear_grouped': (_i, [C.POINTER(ConvDesc), _i, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), _vp]),
     'rmem_groupnorm_workspace_bytes': (C.c_size_t, [_i]),
     'rmem_groupnorm_nhwc': (_i, [_vp, _i, _i, _i, _vp, _vp, _f, _i, _vp, _vp, _vp]),

@@ -48,6 +48,9 @@ struct ConvParams {
   int steps_per_split;   // k-steps (of 32) per gridDim.z slice
   int vec_ok;            // all leading dimensions / pointers allow 8-wide vector access
   long x_elems;          // addressable span of x in elements (fast path: buffer descriptor range)
+  const bf16* x2;        // dual form: second A source, NHWC [batch][H2][W2][Cin2] sampled at stride2; k >= Cin comes from it
+  int H2, W2, Cin2, stride2;
+  long x2_elems;
   int fast_ok;           // 1: Cin % 64 == 0, <= 32 taps, x and w below 2 GB: scalar k-walk + hardware zero fill; 2: row-run form
 };
 
@@ -335,6 +338,7 @@ __device__ inline void buf_load_lds16(rsrc_t, lptr_t, int, int) {}
 template <bool IS1X1, bool SPLITK, int ST = 1, int BM = 64, int BN = 64, int MODE = 0>
 __device__ __forceinline__ void conv_gemm_dma_body(const ConvParams& p, const int zslice) {
   constexpr bool FAST = MODE != 0;
+  constexpr bool DUAL = MODE == 3;        // Y = act([x | x2 sampled] * Wcat^T + b): a bottleneck's conv3 and its strided 1x1 shortcut as one GEMM
   constexpr bool ROWRUN = MODE == 2;      // Cin % 64 != 0 (stem 7x7x8, id bank 17x17x16): the KW * Cin elements of one filter row are
                                           // contiguous in NHWC, so a filter row is walked as spr = ceil(KW * Cin / 64) k-steps
   constexpr int BK = 64, TM = BM / 32, TN = BN / 32;   // 2x2 waves, each (BM/2) x (BN/2) = TM x TN tiles of 16x16
@@ -364,6 +368,8 @@ __device__ __forceinline__ void conv_gemm_dma_body(const ConvParams& p, const in
   constexpr int OOB = (int)0x80000000;
   int f_aoff[NA], f_boff[NB];
   unsigned f_amask[NA], f_cmask[NA];
+  int f_aoff2[NA];
+  const int nk1 = p.Cin / BK;                             // DUAL: k-steps served by x
   int s_ci = 0, s_kw = 0, s_tap = 0, s_aoff = 0;         // FAST is never split along K: the walk starts at tap 0, channel 0
   int s_boff = 0;                                        // ROWRUN: s_tap = filter row, s_kw = step inside the row
   if constexpr (FAST) {
@@ -376,6 +382,11 @@ __device__ __forceinline__ void conv_gemm_dma_body(const ConvParams& p, const in
         f_aoff[i] = m < p.M ? (m * p.ldx + c * 8) * 2 : OOB;
         f_amask[i] = 1u;
         f_cmask[i] = 0u;
+        if (DUAL) {
+          const int img = m / p.HoWo, rem = m - img * p.HoWo;
+          const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+          f_aoff2[i] = m < p.M ? (((img * p.H2 + ho * p.stride2) * p.W2 + wo * p.stride2) * p.Cin2 + c * 8) * 2 : OOB;
+        }
       } else {
         const int img = m / p.HoWo, rem = m - img * p.HoWo;
         const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
@@ -443,12 +454,18 @@ __device__ __forceinline__ void conv_gemm_dma_body(const ConvParams& p, const in
   const long a_shift = (FAST && !IS1X1) ? ((long)p.pad * p.W + p.pad) * p.Cin : 0;
   const rsrc_t rsrc_a = make_rsrc(p.x - a_shift, FAST ? (int)((p.x_elems + a_shift) * 2) : 0);
   const rsrc_t rsrc_b = make_rsrc(p.w, FAST ? p.Cout * p.K * 2 : 0);
+  const rsrc_t rsrc_a2 = make_rsrc(DUAL ? p.x2 : p.x, DUAL ? (int)(p.x2_elems * 2) : 0);
 
   auto issue = [&](int kt, int stage) {
     char* As = smem + stage * STAGE_BYTES;
     char* Bs = As + BM * BK * 2;
     if constexpr (FAST) {
       const int soff_a = IS1X1 ? kt * (BK * 2) : s_aoff;
+      if (DUAL && kt >= nk1) {  // wave-uniform: this k-step comes from the second source
+#pragma unroll
+        for (int i = 0; i < NA; ++i)
+          buf_load_lds16(rsrc_a2, (lptr_t)(As + ((BM / 4) * wave + 8 * i) * 128), f_aoff2[i], (kt - nk1) * (BK * 2));
+      } else
 #pragma unroll
       for (int i = 0; i < NA; ++i) {
         const int voff = IS1X1 ? f_aoff[i]
@@ -599,9 +616,9 @@ __global__ __launch_bounds__(256) void k_conv_gemm_dma(ConvParams p) {
 
 // larger block tiles for the many-row problems (batched encoder / decoder convs): a 64x64 tile moves 16 KB global -> LDS per
 // 0.52 MFLOP, which caps a CU at its ~70 GB/s L2 -> LDS rate (MI355X_MICROARCH.md, 'Indexed rows: gather into LDS')
-template <bool IS1X1, int ST, int BM, int BN, bool FAST>
+template <bool IS1X1, int ST, int BM, int BN, int MODE>
 __global__ __launch_bounds__(256) void k_conv_gemm_dma_big(ConvParams p) {
-  conv_gemm_dma_body<IS1X1, false, ST, BM, BN, FAST ? 1 : 0>(p, 0);
+  conv_gemm_dma_body<IS1X1, false, ST, BM, BN, MODE>(p, 0);
 }
 
 // up to 4 GEMMs of identical shape (different operands) as ONE launch: blockIdx.z selects the operand set.  The per-layer
@@ -694,11 +711,11 @@ template <int BM, int BN>
 void launch_big(const ConvParams& p, bool is1x1, int st, hipStream_t s) {
   dim3 grid((p.M + BM - 1) / BM, (p.Cout + BN - 1) / BN, 1);
   if (st == 2) {
-    if (is1x1) hipLaunchKernelGGL((k_conv_gemm_dma_big<true, 2, BM, BN, true>), grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((k_conv_gemm_dma_big<false, 2, BM, BN, true>), grid, dim3(256), 0, s, p);
+    if (is1x1) hipLaunchKernelGGL((k_conv_gemm_dma_big<true, 2, BM, BN, 1>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((k_conv_gemm_dma_big<false, 2, BM, BN, 1>), grid, dim3(256), 0, s, p);
   } else {
-    if (is1x1) hipLaunchKernelGGL((k_conv_gemm_dma_big<true, 1, BM, BN, true>), grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((k_conv_gemm_dma_big<false, 1, BM, BN, true>), grid, dim3(256), 0, s, p);
+    if (is1x1) hipLaunchKernelGGL((k_conv_gemm_dma_big<true, 1, BM, BN, 1>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((k_conv_gemm_dma_big<false, 1, BM, BN, 1>), grid, dim3(256), 0, s, p);
   }
 }
 
@@ -746,6 +763,7 @@ static int conv_setup(const rmem_conv_desc* d, const void* x, const void* w, con
   RMEM_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)w % 16) == 0, "rmem_conv2d_nhwc: x/w must be 16-byte aligned");
   p.x = (const bf16*)x; p.w = (const bf16*)w; p.bias = bias; p.res = residual; p.y = y; p.y2 = (bf16*)y2;
   p.slabs = nullptr;
+  p.x2 = nullptr; p.H2 = p.W2 = p.Cin2 = p.stride2 = 0; p.x2_elems = 0;
   p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Ho = Ho; p.Wo = Wo; p.Cout = d->Cout;
   p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad;
   const int nb = d->batch > 0 ? d->batch : 1;
@@ -812,6 +830,37 @@ extern "C" int rmem_conv2d_nhwc(const rmem_conv_desc* d, const void* x, const vo
     launch<64, 64, 4>(p, is1x1, splits, s);
   }
   return rmem_check_launch("rmem_conv2d_nhwc");
+}
+
+// Y = act([x | x2 sampled at stride2] * Wcat^T + bias): the last 1x1 conv of a ResNet bottleneck and its (strided) 1x1 shortcut
+// (encoders/resnet.py:48-68, downsample branch) as ONE GEMM over K = Cin + Cin2 -- the shortcut tensor is never written or re-read.
+extern "C" int rmem_conv1x1_dual_nhwc(const rmem_conv_desc* d, const void* x, const void* x2, int H2, int W2, int Cin2, int stride2,
+                                      const void* w_cat, const float* bias, void* y, void* stream) {
+  ConvParams p;
+  bool is1x1 = false;
+  RMEM_REQUIRE(d && x2 && H2 > 0 && W2 > 0 && stride2 >= 1, "rmem_conv1x1_dual_nhwc: bad second source");
+  if (conv_setup(d, x, w_cat, bias, nullptr, y, nullptr, p, is1x1)) return -1;
+  RMEM_REQUIRE(is1x1 && d->ldx == 0, "rmem_conv1x1_dual_nhwc: the main problem must be a dense 1x1 stride-1 convolution");
+  RMEM_REQUIRE(p.Cin % 64 == 0 && Cin2 % 64 == 0, "rmem_conv1x1_dual_nhwc: Cin and Cin2 must be multiples of 64");
+  RMEM_REQUIRE((H2 - 1) / stride2 + 1 == p.Ho && (W2 - 1) / stride2 + 1 == p.Wo, "rmem_conv1x1_dual_nhwc: x2 geometry does not match the output");
+  RMEM_REQUIRE(((uintptr_t)x2 % 16) == 0, "rmem_conv1x1_dual_nhwc: x2 must be 16-byte aligned");
+  const int nb = d->batch > 0 ? d->batch : 1;
+  p.x2 = (const bf16*)x2; p.H2 = H2; p.W2 = W2; p.Cin2 = Cin2; p.stride2 = stride2;
+  p.x2_elems = (long)nb * H2 * W2 * Cin2;
+  p.K = p.Cin + Cin2;                                   // Wcat is [Cout][Cin + Cin2]
+  p.steps_per_split = p.K / 64;
+  const long lim = (1L << 31) - (1L << 22);
+  RMEM_REQUIRE(p.x_elems * 2 < lim && p.x2_elems * 2 < lim && (long)p.Cout * p.K * 2 < lim, "rmem_conv1x1_dual_nhwc: operands must stay below 2 GB");
+  hipStream_t s = (hipStream_t)stream;
+  static const int big_thr = getenv("RMEM_GEMM_BIG") ? atoi(getenv("RMEM_GEMM_BIG")) : 512;
+  if (big_thr > 0 && p.Cout >= 128 && p.K >= 512 && (long)((p.M + 127) / 128) * ((p.Cout + 127) / 128) >= big_thr) {
+    dim3 grid((p.M + 127) / 128, (p.Cout + 127) / 128, 1);
+    hipLaunchKernelGGL((k_conv_gemm_dma_big<true, 1, 128, 128, 3>), grid, dim3(256), 0, s, p);
+  } else {
+    dim3 grid((p.M + 63) / 64, (p.Cout + 63) / 64, 1);
+    hipLaunchKernelGGL((k_conv_gemm_dma<true, false, 1, 3>), grid, dim3(256), 0, s, p);
+  }
+  return rmem_check_launch("rmem_conv1x1_dual_nhwc");
 }
 
 extern "C" int rmem_linear_grouped(const rmem_conv_desc* d, int n, const void* const* x, const void* const* w,

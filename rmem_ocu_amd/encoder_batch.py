@@ -41,7 +41,6 @@ class BatchEncoder:
         self.x16 = [e(B, L, 1024), e(B, L, 1024)]
         self.mid_a = e(B * M4 * 128)
         self.mid_b = e(B * M4 * 64)
-        self.ds = e(B * M4 * 256)
         self.conv_ws = torch.empty(16 * B * L * 256, dtype=F32, device=device)
         self._prog = None
         # stage outputs = the last block's buffer of every layer (block count - 1) % 2
@@ -74,13 +73,12 @@ class BatchEncoder:
                 o.append(self._conv(x, P[p + '.conv1.w'], P[p + '.conv1.b'], a, H=h, W=w, Cin=cin, Cout=planes, relu=True))
                 o.append(self._conv(a, P[p + '.conv2.w'], P[p + '.conv2.b'], bb, H=h, W=w, Cin=planes, Cout=planes, KH=3, KW=3,
                                     stride=s, pad=1, relu=True))
-                if (p + '.ds.w') in P:
-                    r = self.ds[: B * ho * wo * planes * 4]
-                    o.append(self._conv(x, P[p + '.ds.w'], P[p + '.ds.b'], r, H=h, W=w, Cin=cin, Cout=planes * 4, stride=s))
+                if (p + '.c3ds.w') in P:     # conv3 + strided 1x1 shortcut as one GEMM: the shortcut tensor never exists
+                    o.append(ops.conv1x1_dual(bb, x, P[p + '.c3ds.w'], P[p + '.c3ds.b'], y, H=ho, W=wo, Cin=planes, Cout=planes * 4,
+                                              H2=h, W2=w, Cin2=cin, stride2=s, relu=True, batch=B))
                 else:
-                    r = x
-                o.append(self._conv(bb, P[p + '.conv3.w'], P[p + '.conv3.b'], y, H=ho, W=wo, Cin=planes, Cout=planes * 4,
-                                    residual=r, relu=True))
+                    o.append(self._conv(bb, P[p + '.conv3.w'], P[p + '.conv3.b'], y, H=ho, W=wo, Cin=planes, Cout=planes * 4,
+                                        residual=x, relu=True))
                 x, (h, w), cin = y, (ho, wo), planes * 4
         self._prog = o
         return o

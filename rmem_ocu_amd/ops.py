@@ -79,6 +79,18 @@ def conv2d(x, w, bias, y, *, H, W, Cin, Cout, KH=1, KW=1, stride=1, pad=0, resid
     return Op(_lib.lib().rmem_conv2d_nhwc, args, 'rmem_conv2d_nhwc', (d, x, w, bias, residual, y, y2, ws))
 
 
+def conv1x1_dual(x, x2, w_cat, bias, y, *, H, W, Cin, Cout, H2, W2, Cin2, stride2, relu=False, batch=1) -> Op:
+    """y = act([x | x2 sampled at stride2] @ w_cat^T + bias): bottleneck conv3 + its 1x1 shortcut as one GEMM.
+    x [batch*H*W, Cin] bf16, x2 NHWC [batch, H2, W2, Cin2] bf16, w_cat [Cout, Cin + Cin2] bf16."""
+    _dev(x, x2, w_cat, bias, y)
+    assert x.dtype == BF16 and x2.dtype == BF16 and w_cat.dtype == BF16 and w_cat.is_contiguous() and y.dtype == BF16
+    assert w_cat.numel() == Cout * (Cin + Cin2) and bias.dtype == F32 and bias.numel() == Cout
+    assert x.numel() >= batch * H * W * Cin and x2.numel() >= batch * H2 * W2 * Cin2 and y.numel() >= batch * H * W * Cout
+    d = ConvDesc(H, W, Cin, H, W, Cout, 1, 1, 1, 0, Cout, Cout, Cout, int(relu), 0, 0, 0, batch, 0)
+    args = (C.byref(d), _ptr(x), _ptr(x2), H2, W2, Cin2, stride2, _ptr(w_cat), _ptr(bias), _ptr(y))
+    return Op(_lib.lib().rmem_conv1x1_dual_nhwc, args, 'rmem_conv1x1_dual_nhwc', (d, x, x2, w_cat, bias, y))
+
+
 def linear(x, w, bias, y, *, M, K, N, residual=None, y2=None, relu=False, ldo=None, ldr=None, ld2=None, ws=None, ldx=0,
            act_begin=0) -> Op:
     """y[M, N] = x[M, K] @ w[N, K]^T + bias: the 1x1 case of conv2d (x rows of stride ldx, default K)."""

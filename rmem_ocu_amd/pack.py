@@ -130,6 +130,10 @@ def pack_state_dict(sd: Dict[str, torch.Tensor], device, num_lstt: int = 3) -> D
             if f'{p}.downsample.0.weight' in sd:
                 w, b = _fold_bn(sd, f'{p}.downsample.0.weight', f'{p}.downsample.1')
                 put(f'{p}.ds.w', w); put(f'{p}.ds.b', b)
+                # conv3 and the shortcut as one GEMM over [conv2 output | block input] (ops.conv1x1_dual)
+                w3, b3 = P[f'{p}.conv3.w'], P[f'{p}.conv3.b']
+                put(f'{p}.c3ds.w', torch.cat([w3.reshape(w3.shape[0], -1), P[f'{p}.ds.w'].reshape(w3.shape[0], -1)], 1))
+                put(f'{p}.c3ds.b', b3 + P[f'{p}.ds.b'])
     put('proj.w', _conv_w(sd['encoder_projector.weight'].float())); put('proj.b', sd['encoder_projector.bias'].float())
 
     def lin(dst, src):

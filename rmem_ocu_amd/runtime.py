@@ -118,7 +118,6 @@ class ClipRuntime:
             self.x16 = [e(L, 1024), e(L, 1024)]
             self.mid_a = e(M4, 128)                     # bottleneck conv1 out (<= M4*64, M4*128 for layer2.0, ...)
             self.mid_b = e(M4, 64)                      # bottleneck conv2 out
-            self.ds = e(M4, 256)                        # downsample branch
         self._alloc_lstt(L, num_lstt)
         self.onehot = e(H * W, 16)
         self.gn_ws = ops.groupnorm_workspace(32, device)
@@ -299,13 +298,12 @@ class ClipRuntime:
                 o.append(self._conv(x, P[p + '.conv1.w'], P[p + '.conv1.b'], a, H=h, W=w, Cin=cin, Cout=planes, relu=True))
                 o.append(self._conv(a, P[p + '.conv2.w'], P[p + '.conv2.b'], b, H=h, W=w, Cin=planes, Cout=planes, KH=3, KW=3,
                                     stride=s, pad=1, relu=True))
-                if (p + '.ds.w') in P:
-                    r = self.ds.view(-1)[: ho * wo * planes * 4]
-                    o.append(self._conv(x, P[p + '.ds.w'], P[p + '.ds.b'], r, H=h, W=w, Cin=cin, Cout=planes * 4, stride=s))
+                if (p + '.c3ds.w') in P:     # conv3 + strided 1x1 shortcut as one GEMM: the shortcut tensor never exists
+                    o.append(ops.conv1x1_dual(b, x, P[p + '.c3ds.w'], P[p + '.c3ds.b'], y, H=ho, W=wo, Cin=planes, Cout=planes * 4,
+                                              H2=h, W2=w, Cin2=cin, stride2=s, relu=True))
                 else:
-                    r = x
-                o.append(self._conv(b, P[p + '.conv3.w'], P[p + '.conv3.b'], y, H=ho, W=wo, Cin=planes, Cout=planes * 4,
-                                    residual=r, relu=True))
+                    o.append(self._conv(b, P[p + '.conv3.w'], P[p + '.conv3.b'], y, H=ho, W=wo, Cin=planes, Cout=planes * 4,
+                                        residual=x, relu=True))
                 x, (h, w), cin = y, (ho, wo), planes * 4
             setattr(self, f'enc{li}', x)
         # encoder_projector: fp32 residual stream + bf16 copy into the decoder's concat buffer

@@ -430,6 +430,28 @@ def test_conv2d_batch_of_images(dev):
     assert_close(y, ref.permute(0, 2, 3, 1).reshape(B, Ho * Wo, Cout), 1e-2, 'batched conv')
 
 
+@pytest.mark.parametrize('B,H2,W2,K1,K2,Cout,stride', [(2, 23, 31, 64, 128, 192, 2), (1, 9, 14, 64, 64, 256, 1), (3, 61, 43, 256, 512, 1024, 2)])
+def test_conv1x1_dual_bottleneck_tail(dev, B, H2, W2, K1, K2, Cout, stride):
+    """relu(conv3(h) + b3 + downsample(x) + bd) of a ResNet bottleneck (encoders/resnet.py:48-68) as one GEMM over [h | x sampled];
+    fp32 reference on the bf16-rounded operands.  The 3rd case takes the 128x128 tile, the others the 64x64 one."""
+    from rmem_ocu_amd import ops
+    Ho, Wo = (H2 - 1) // stride + 1, (W2 - 1) // stride + 1
+    h = rb(seeded(51, (B, K1, Ho, Wo)))
+    x = rb(seeded(52, (B, K2, H2, W2)))
+    w3 = rb(seeded(53, (Cout, K1, 1, 1), 1.0 / K1 ** 0.5))
+    wd = rb(seeded(54, (Cout, K2, 1, 1), 1.0 / K2 ** 0.5))
+    b3, bd = seeded(55, (Cout,), 0.1), seeded(56, (Cout,), 0.1)
+    ref = F.relu(F.conv2d(h, w3, b3) + F.conv2d(x, wd, bd, stride=stride))
+    hd = h.permute(0, 2, 3, 1).reshape(B * Ho * Wo, K1).contiguous().to(BF16).to(dev)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(BF16).to(dev)
+    wcat = torch.cat([w3.reshape(Cout, K1), wd.reshape(Cout, K2)], 1).contiguous().to(BF16).to(dev)
+    y = torch.zeros(B * Ho * Wo, Cout, dtype=BF16, device=dev)
+    ops.run(ops.conv1x1_dual(hd, xd, wcat, (b3 + bd).to(dev), y, H=Ho, W=Wo, Cin=K1, Cout=Cout, H2=H2, W2=W2, Cin2=K2, stride2=stride,
+                             relu=True, batch=B))
+    torch.cuda.synchronize()
+    assert_close(y, ref.permute(0, 2, 3, 1).reshape(B * Ho * Wo, Cout), 1e-2, 'conv3 + shortcut')
+
+
 def test_grouped_launches(dev):
     """rmem_linear_grouped / rmem_add_bf16_grouped / rmem_layernorm256_pair are bit-identical to the single launches."""
     from rmem_ocu_amd import ops
