@@ -242,12 +242,16 @@ int rmem_gn_act_dwconv5x5_nhwc(const void* x, int H, int W, int C, int groups, c
 /* ------------------------------------------------------------------ layout / resampling */
 /* fp32 [3][H][W] image -> bf16 [H][W][8] (channels 3..7 zero): input of encoders/resnet.py:179. */
 int rmem_image_to_nhwc8(const float* img_chw, void* out, int H, int W, void* stream);
+/* the `_images` forms of this section take `images` equally sized problems stored back to back (clip groups, encoder
+ * look-ahead) as ONE launch; each image's result equals the single-image call. */
+int rmem_image_to_nhwc8_images(const float* img_chw, void* out, int images, int H, int W, void* stream);
 /* Frame ingest: decoded uint8 RGB [Hs][Ws][3] -> bicubic resize to the network size (OpenCV INTER_CUBIC semantics) ->
  * ImageNet normalise -> fp32 [3][Hd][Wd] (the engine API's input) and/or bf16 [Hd][Wd][8] (the encoder's input).
  * Replaces dataloaders/video_transforms.py:648-652 (cv2.resize) + 676-680 (normalise) on the host. */
 int rmem_ingest_rgb8(const unsigned char* rgb_hwc, int Hs, int Ws, int Hd, int Wd, float* out_chw, void* out_nhwc8, void* stream);
 /* 3x3 stride-2 pad-1 max-pool (encoders/resnet.py:105, 182). */
 int rmem_maxpool3x3s2_nhwc(const void* x, void* y, int H, int W, int C, void* stream);
+int rmem_maxpool3x3s2_nhwc_images(const void* x, void* y, int images, int H, int W, int C, void* stream);
 /* bilinear resize, NHWC bf16 (decoders/fpn.py:49-52, 57-60). */
 int rmem_bilinear_nhwc(const void* x, void* y, int Hi, int Wi, int Ho, int Wo, int C, int align_corners, void* stream);
 /* logits fp32 NHWC [Hi][Wi][ldl]: ids > keep_max_id forced to -1e10, bilinear to (Ho, Wo); writes any of
@@ -256,10 +260,16 @@ int rmem_bilinear_nhwc(const void* x, void* y, int Hi, int Wi, int Ho, int Wo, i
 int rmem_logits_post(const float* logits_nhwc, int ldl, int num_classes, int keep_max_id, int Hi, int Wi,
                      int Ho, int Wo, int align_corners, float* out_nchw, unsigned char* label_u8,
                      float* label_f32, void* stream);
+/* images > 1: labels only (out_nchw must be NULL) */
+int rmem_logits_post_images(const float* logits_nhwc, int images, int ldl, int num_classes, int keep_max_id, int Hi, int Wi,
+                            int Ho, int Wo, int align_corners, float* out_nchw, unsigned char* label_u8,
+                            float* label_f32, void* stream);
 /* label map (uint8 or fp32) -> nearest resize -> one-hot + ignore channel, bf16 [Hd][Wd][16]
  * (utils/image.py:69-74; engines/aot_engine.py:208-224; managers/evaluator.py:518-522). */
 int rmem_label_to_onehot16(const void* label, int label_is_f32, int Hs, int Ws, int Hd, int Wd,
                            int num_classes, void* out, void* stream);
+int rmem_label_to_onehot16_images(const void* label, int label_is_f32, int images, int Hs, int Ws, int Hd, int Wd,
+                                  int num_classes, void* out, void* stream);
 /* scores[t] = sum_q mass[q][t] * (1 - softmax(bilinear_ac(logits -> He x We))[0])
  * (engines/aot_engine.py:355-362 + layers/transformer.py:341-351, the device half of the eviction policy).
  * `scores` must hold 32 + 64 * 32 floats: the first T are the result, the rest is reduction scratch. */

@@ -58,11 +58,15 @@ SIGNATURES = {
     'rmem_gn_act_dwconv5x5_nhwc': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _f, _i, _vp, _vp, _vp, _vp]),
     'rmem_dwconv5x5_nhwc': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     'rmem_image_to_nhwc8': (_i, [_vp, _vp, _i, _i, _vp]),
+    'rmem_image_to_nhwc8_images': (_i, [_vp, _vp, _i, _i, _i, _vp]),
     'rmem_ingest_rgb8': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     'rmem_maxpool3x3s2_nhwc': (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    'rmem_maxpool3x3s2_nhwc_images': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     'rmem_bilinear_nhwc': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     'rmem_logits_post': (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    'rmem_logits_post_images': (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     'rmem_label_to_onehot16': (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    'rmem_label_to_onehot16_images': (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     'rmem_evict_scores': (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp]),
     'rmem_tta_merge': (_i, [C.POINTER(_vp), C.POINTER(_i), _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     'rmem_mask_iou_counts': (_i, [_vp, _vp, _ll, _i, _i, _vp, _vp]),

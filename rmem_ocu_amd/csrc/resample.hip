@@ -18,6 +18,8 @@ __global__ __launch_bounds__(256) void k_image_to_nhwc8(const float* img, bf16* 
   const long n = (long)H * W;
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
+  img += (long)blockIdx.y * 3 * n;            // blockIdx.y = image of a batch
+  out += (long)blockIdx.y * 8 * n;
   bf16x8 o = {0, 0, 0, 0, 0, 0, 0, 0};
   o[0] = (bf16)img[i];
   o[1] = (bf16)img[n + i];
@@ -33,6 +35,8 @@ __global__ __launch_bounds__(256) void k_maxpool3s2(const bf16* x, bf16* y, int 
   const int c0 = (int)(i % vpr) * 8;
   const int pix = (int)(i / vpr);
   const int oy = pix / Wo, ox = pix - oy * Wo;
+  x += (long)blockIdx.y * H * W * C;          // blockIdx.y = image of a batch
+  y += (long)blockIdx.y * total * 8;
   float m[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) m[j] = -3.0e38f;
@@ -96,6 +100,9 @@ __global__ __launch_bounds__(256) void k_logits_post(const float* lg, int ldl, i
   const long total = (long)Ho * Wo;
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
+  lg += (long)blockIdx.y * Hi * Wi * ldl;     // blockIdx.y = image of a batch (labels only: out is per image)
+  if (label) label += (long)blockIdx.y * total;
+  if (label_f32) label_f32 += (long)blockIdx.y * total;
   const int oy = (int)(i / Wo), ox = (int)(i - (long)oy * Wo);
   int y0, y1, x0, x1; float wy, wx;
   src_coord(oy, Hi, Ho, align, y0, y1, wy);
@@ -153,6 +160,8 @@ __global__ __launch_bounds__(256) void k_label_onehot(const void* lab, int lab_f
   const long total = (long)Hd * Wd;
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
+  lab = reinterpret_cast<const char*>(lab) + (long)blockIdx.y * Hs * Ws * (lab_f32 ? 4 : 1);   // blockIdx.y = image of a batch
+  out += (long)blockIdx.y * total * 16;
   const int y = (int)(i / Wd), x = (int)(i - (long)y * Wd);
   const int sy = min((int)floorf((float)y * ((float)Hs / (float)Hd)), Hs - 1);   // F.interpolate(mode='nearest')
   const int sx = min((int)floorf((float)x * ((float)Ws / (float)Wd)), Ws - 1);
@@ -355,17 +364,25 @@ extern "C" int rmem_scatter_blocks(const void* src, void* dst, const int* slots_
   return rmem_check_launch("rmem_scatter_blocks");
 }
 
-extern "C" int rmem_image_to_nhwc8(const float* img_chw, void* out, int H, int W, void* stream) {
-  RMEM_REQUIRE(img_chw && out && H > 0 && W > 0, "rmem_image_to_nhwc8: bad argument");
-  hipLaunchKernelGGL(k_image_to_nhwc8, dim3(nblk((long)H * W)), dim3(256), 0, (hipStream_t)stream, img_chw, (bf16*)out, H, W);
+extern "C" int rmem_image_to_nhwc8_images(const float* img_chw, void* out, int images, int H, int W, void* stream) {
+  RMEM_REQUIRE(img_chw && out && images >= 1 && H > 0 && W > 0, "rmem_image_to_nhwc8: bad argument");
+  hipLaunchKernelGGL(k_image_to_nhwc8, dim3(nblk((long)H * W), images), dim3(256), 0, (hipStream_t)stream, img_chw, (bf16*)out, H, W);
   return rmem_check_launch("rmem_image_to_nhwc8");
 }
 
-extern "C" int rmem_maxpool3x3s2_nhwc(const void* x, void* y, int H, int W, int C, void* stream) {
-  RMEM_REQUIRE(x && y && H > 0 && W > 0 && C % 8 == 0, "rmem_maxpool3x3s2_nhwc: bad argument");
+extern "C" int rmem_image_to_nhwc8(const float* img_chw, void* out, int H, int W, void* stream) {
+  return rmem_image_to_nhwc8_images(img_chw, out, 1, H, W, stream);
+}
+
+extern "C" int rmem_maxpool3x3s2_nhwc_images(const void* x, void* y, int images, int H, int W, int C, void* stream) {
+  RMEM_REQUIRE(x && y && images >= 1 && H > 0 && W > 0 && C % 8 == 0, "rmem_maxpool3x3s2_nhwc: bad argument");
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-  hipLaunchKernelGGL(k_maxpool3s2, dim3(nblk((long)Ho * Wo * (C / 8))), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, (bf16*)y, H, W, C, Ho, Wo);
+  hipLaunchKernelGGL(k_maxpool3s2, dim3(nblk((long)Ho * Wo * (C / 8)), images), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, (bf16*)y, H, W, C, Ho, Wo);
   return rmem_check_launch("rmem_maxpool3x3s2_nhwc");
+}
+
+extern "C" int rmem_maxpool3x3s2_nhwc(const void* x, void* y, int H, int W, int C, void* stream) {
+  return rmem_maxpool3x3s2_nhwc_images(x, y, 1, H, W, C, stream);
 }
 
 extern "C" int rmem_bilinear_nhwc_images(const void* x, void* y, int images, int Hi, int Wi, int Ho, int Wo, int C, int align_corners,
@@ -380,19 +397,34 @@ extern "C" int rmem_bilinear_nhwc(const void* x, void* y, int Hi, int Wi, int Ho
   return rmem_bilinear_nhwc_images(x, y, 1, Hi, Wi, Ho, Wo, C, align_corners, stream);
 }
 
-extern "C" int rmem_logits_post(const float* logits_nhwc, int ldl, int num_classes, int keep_max_id, int Hi, int Wi, int Ho, int Wo,
-                                int align_corners, float* out_nchw, unsigned char* label_u8, float* label_f32, void* stream) {
-  RMEM_REQUIRE(logits_nhwc && num_classes >= 1 && num_classes <= 16 && ldl >= num_classes, "rmem_logits_post: bad argument");
+extern "C" int rmem_logits_post_images(const float* logits_nhwc, int images, int ldl, int num_classes, int keep_max_id, int Hi, int Wi,
+                                       int Ho, int Wo, int align_corners, float* out_nchw, unsigned char* label_u8, float* label_f32,
+                                       void* stream) {
+  RMEM_REQUIRE(logits_nhwc && images >= 1 && num_classes >= 1 && num_classes <= 16 && ldl >= num_classes, "rmem_logits_post: bad argument");
   RMEM_REQUIRE(out_nchw || label_u8 || label_f32, "rmem_logits_post: no output requested");
-  hipLaunchKernelGGL(k_logits_post, dim3(nblk((long)Ho * Wo)), dim3(256), 0, (hipStream_t)stream, logits_nhwc, ldl, num_classes, keep_max_id,
-                     Hi, Wi, Ho, Wo, align_corners, out_nchw, label_u8, label_f32);
+  RMEM_REQUIRE(images == 1 || !out_nchw, "rmem_logits_post: a batch of images produces labels only");
+  hipLaunchKernelGGL(k_logits_post, dim3(nblk((long)Ho * Wo), images), dim3(256), 0, (hipStream_t)stream, logits_nhwc, ldl, num_classes,
+                     keep_max_id, Hi, Wi, Ho, Wo, align_corners, out_nchw, label_u8, label_f32);
   return rmem_check_launch("rmem_logits_post");
 }
 
-extern "C" int rmem_label_to_onehot16(const void* label, int label_is_f32, int Hs, int Ws, int Hd, int Wd, int num_classes, void* out, void* stream) {
-  RMEM_REQUIRE(label && out && Hs > 0 && Ws > 0 && Hd > 0 && Wd > 0 && num_classes >= 1 && num_classes <= 15, "rmem_label_to_onehot16: bad argument");
-  hipLaunchKernelGGL(k_label_onehot, dim3(nblk((long)Hd * Wd)), dim3(256), 0, (hipStream_t)stream, label, label_is_f32, Hs, Ws, Hd, Wd, num_classes, (bf16*)out);
+extern "C" int rmem_logits_post(const float* logits_nhwc, int ldl, int num_classes, int keep_max_id, int Hi, int Wi, int Ho, int Wo,
+                                int align_corners, float* out_nchw, unsigned char* label_u8, float* label_f32, void* stream) {
+  return rmem_logits_post_images(logits_nhwc, 1, ldl, num_classes, keep_max_id, Hi, Wi, Ho, Wo, align_corners, out_nchw, label_u8, label_f32,
+                                 stream);
+}
+
+extern "C" int rmem_label_to_onehot16_images(const void* label, int label_is_f32, int images, int Hs, int Ws, int Hd, int Wd, int num_classes,
+                                             void* out, void* stream) {
+  RMEM_REQUIRE(label && out && images >= 1 && Hs > 0 && Ws > 0 && Hd > 0 && Wd > 0 && num_classes >= 1 && num_classes <= 15,
+               "rmem_label_to_onehot16: bad argument");
+  hipLaunchKernelGGL(k_label_onehot, dim3(nblk((long)Hd * Wd), images), dim3(256), 0, (hipStream_t)stream, label, label_is_f32, Hs, Ws, Hd, Wd,
+                     num_classes, (bf16*)out);
   return rmem_check_launch("rmem_label_to_onehot16");
+}
+
+extern "C" int rmem_label_to_onehot16(const void* label, int label_is_f32, int Hs, int Ws, int Hd, int Wd, int num_classes, void* out, void* stream) {
+  return rmem_label_to_onehot16_images(label, label_is_f32, 1, Hs, Ws, Hd, Wd, num_classes, out, stream);
 }
 
 extern "C" int rmem_evict_scores(const float* logits_nhwc, int ldl, int num_classes, int keep_max_id, int Hi, int Wi, int He, int We,

@@ -53,12 +53,10 @@ class BatchEncoder:
         if self._prog is not None:
             return self._prog
         P, B, o = self.P, self.B, []
-        for b in range(B):
-            o.append(ops.image_to_nhwc8(self.img_in[b], self.img8[b], H=self.H, W=self.W))
+        o.append(ops.image_to_nhwc8(self.img_in, self.img8, H=self.H, W=self.W, images=B))
         o.append(self._conv(self.img8, P['stem.w'], P['stem.b'], self.stem, H=self.H, W=self.W, Cin=8, Cout=64, KH=7, KW=7, stride=2,
                             pad=3, relu=True))
-        for b in range(B):
-            o.append(ops.maxpool3x3s2(self.stem[b], self.pool[b], H=self.H2, W=self.W2, C=64))
+        o.append(ops.maxpool3x3s2(self.stem, self.pool, H=self.H2, W=self.W2, C=64, images=B))
         x, (h, w), cin = self.pool, (self.H4, self.W4), 64
         outs = [self.x4, self.x8, self.x16]
         for li, (nblk, stride) in enumerate(zip(R50_BLOCKS, R50_STRIDES), start=1):

@@ -273,8 +273,7 @@ class GroupRuntime:
             return self._prog[key]
         P, B = self.P, self.B
         k, s, p = (17, 16, 8) if self.align else (16, 16, 0)
-        o = [ops.label_to_onehot16(labels[c], self.onehot[c * self.H * self.W:(c + 1) * self.H * self.W], Hs=hs, Ws=ws, Hd=self.H,
-                                   Wd=self.W, ncls=self.nc) for c in range(B)]
+        o = [ops.label_to_onehot16(labels, self.onehot, Hs=hs, Ws=ws, Hd=self.H, Wd=self.W, ncls=self.nc, images=B)]
         o.append(self._conv(self.onehot, P['idbank.w'], P['idbank.b'], self.id_emb, H=self.H, W=self.W, Cin=16, Cout=D_MODEL,
                             KH=k, KW=k, stride=s, pad=p))
         self._prog[key] = o

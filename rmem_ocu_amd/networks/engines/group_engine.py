@@ -140,8 +140,8 @@ class GroupEngine:
             wm = self._mass_needed(T)
             pk = f'post_{labels_u8.data_ptr()}_{Ho}_{Wo}'
             if pk not in rt._prog:
-                rt._prog[pk] = [ops.logits_post(rt.logits[c * rt.M4:(c + 1) * rt.M4], ldl=16, nc=rt.nc, keep=keep, Hi=rt.H4, Wi=rt.W4,
-                                                Ho=Ho, Wo=Wo, align_corners=self.align_corners, label_u8=labels_u8[c]) for c in range(B)]
+                rt._prog[pk] = [ops.logits_post(rt.logits, ldl=16, nc=rt.nc, keep=keep, Hi=rt.H4, Wi=rt.W4, Ho=Ho, Wo=Wo,
+                                                align_corners=self.align_corners, label_u8=labels_u8, images=B)]
             if enc_slot is None:
                 ops.copy_async(rt.enc_now.img_in, imgs.contiguous(), B * 3 * rt.H * rt.W * 4)(self._s())
                 prog = rt.prog_encode() + rt.prog_project(None) + rt.prog_lstt(False, T, wm) + rt.prog_decode(None) + rt._prog[pk]

@@ -236,10 +236,12 @@ def dwconv5x5(x, w_t, y, *, H, W, C) -> Op:
     return Op(_lib.lib().rmem_dwconv5x5_nhwc, (_ptr(x), _ptr(w_t), _ptr(y), H, W, C), 'rmem_dwconv5x5_nhwc', (x, w_t, y))
 
 
-def image_to_nhwc8(img, out, *, H, W) -> Op:
+def image_to_nhwc8(img, out, *, H, W, images=1) -> Op:
+    """fp32 [images, 3, H, W] -> bf16 [images, H*W, 8]"""
     _dev(img, out)
-    assert img.dtype == F32 and img.is_contiguous() and img.numel() == 3 * H * W and out.dtype == BF16
-    return Op(_lib.lib().rmem_image_to_nhwc8, (_ptr(img), _ptr(out), H, W), 'rmem_image_to_nhwc8', (img, out))
+    assert img.dtype == F32 and img.is_contiguous() and img.numel() == images * 3 * H * W and out.dtype == BF16
+    assert out.is_contiguous() and out.numel() >= images * H * W * 8
+    return Op(_lib.lib().rmem_image_to_nhwc8_images, (_ptr(img), _ptr(out), images, H, W), 'rmem_image_to_nhwc8', (img, out))
 
 
 def ingest_rgb8(rgb, *, Hs, Ws, Hd, Wd, out_chw=None, out_nhwc8=None) -> Op:
@@ -250,9 +252,11 @@ def ingest_rgb8(rgb, *, Hs, Ws, Hd, Wd, out_chw=None, out_nhwc8=None) -> Op:
     return Op(_lib.lib().rmem_ingest_rgb8, (_ptr(rgb), Hs, Ws, Hd, Wd, _ptr(out_chw), _ptr(out_nhwc8)), 'rmem_ingest_rgb8', (rgb, out_chw, out_nhwc8))
 
 
-def maxpool3x3s2(x, y, *, H, W, C) -> Op:
+def maxpool3x3s2(x, y, *, H, W, C, images=1) -> Op:
     _dev(x, y)
-    return Op(_lib.lib().rmem_maxpool3x3s2_nhwc, (_ptr(x), _ptr(y), H, W, C), 'rmem_maxpool3x3s2_nhwc', (x, y))
+    assert x.is_contiguous() and y.is_contiguous() and x.numel() >= images * H * W * C
+    assert y.numel() >= images * ((H - 1) // 2 + 1) * ((W - 1) // 2 + 1) * C
+    return Op(_lib.lib().rmem_maxpool3x3s2_nhwc_images, (_ptr(x), _ptr(y), images, H, W, C), 'rmem_maxpool3x3s2_nhwc', (x, y))
 
 
 def bilinear(x, y, *, Hi, Wi, Ho, Wo, C, align_corners=True, images=1) -> Op:
@@ -262,18 +266,24 @@ def bilinear(x, y, *, Hi, Wi, Ho, Wo, C, align_corners=True, images=1) -> Op:
               'rmem_bilinear_nhwc', (x, y))
 
 
-def logits_post(logits, *, ldl, nc, keep, Hi, Wi, Ho, Wo, align_corners=True, out=None, label_u8=None, label_f32=None) -> Op:
+def logits_post(logits, *, ldl, nc, keep, Hi, Wi, Ho, Wo, align_corners=True, out=None, label_u8=None, label_f32=None, images=1) -> Op:
+    """images > 1: logits [images, Hi*Wi, ldl] -> labels [images, Ho, Wo] (labels only)."""
     _dev(logits, out, label_u8, label_f32)
     assert logits.dtype == F32 and (out is None or out.dtype == F32) and (label_u8 is None or label_u8.dtype == torch.uint8)
-    args = (_ptr(logits), ldl, nc, keep, Hi, Wi, Ho, Wo, int(align_corners), _ptr(out), _ptr(label_u8), _ptr(label_f32))
-    return Op(_lib.lib().rmem_logits_post, args, 'rmem_logits_post', (logits, out, label_u8, label_f32))
+    assert logits.numel() >= images * Hi * Wi * ldl and (images == 1 or out is None)
+    for lab in (label_u8, label_f32):
+        assert lab is None or (lab.is_contiguous() and lab.numel() >= images * Ho * Wo)
+    args = (_ptr(logits), images, ldl, nc, keep, Hi, Wi, Ho, Wo, int(align_corners), _ptr(out), _ptr(label_u8), _ptr(label_f32))
+    return Op(_lib.lib().rmem_logits_post_images, args, 'rmem_logits_post', (logits, out, label_u8, label_f32))
 
 
-def label_to_onehot16(label, out, *, Hs, Ws, Hd, Wd, ncls=11) -> Op:
+def label_to_onehot16(label, out, *, Hs, Ws, Hd, Wd, ncls=11, images=1) -> Op:
+    """label [images, Hs, Ws] uint8 / fp32 -> bf16 [images, Hd*Wd, 16]"""
     _dev(label, out)
     assert label.dtype in (torch.uint8, F32) and label.is_contiguous() and out.dtype == BF16
-    args = (_ptr(label), int(label.dtype == F32), Hs, Ws, Hd, Wd, ncls, _ptr(out))
-    return Op(_lib.lib().rmem_label_to_onehot16, args, 'rmem_label_to_onehot16', (label, out))
+    assert label.numel() >= images * Hs * Ws and out.numel() >= images * Hd * Wd * 16
+    args = (_ptr(label), int(label.dtype == F32), images, Hs, Ws, Hd, Wd, ncls, _ptr(out))
+    return Op(_lib.lib().rmem_label_to_onehot16_images, args, 'rmem_label_to_onehot16', (label, out))
 
 
 def evict_scores(logits, mass, scores, *, ldl, nc, keep, Hi, Wi, He, We, T) -> Op:

@@ -524,6 +524,25 @@ def test_batched_forms_match_single_launches(dev):
     ops.run([ops.bilinear(x[i], u1[i], Hi=H, Wi=W, Ho=17, Wo=27, C=C) for i in range(B)])
     torch.cuda.synchronize()
     assert torch.equal(ub, u1)
+    # layout / resampling forms: image conversion, max-pool, label one-hot, logits -> labels
+    img = seeded(90, (B, 3, 21, 30), 1.0).to(dev)
+    nb, n1 = torch.zeros(B, 21 * 30, 8, dtype=BF16, device=dev), torch.zeros(B, 21 * 30, 8, dtype=BF16, device=dev)
+    ops.run(ops.image_to_nhwc8(img, nb, H=21, W=30, images=B))
+    ops.run([ops.image_to_nhwc8(img[i], n1[i], H=21, W=30) for i in range(B)])
+    pb, p1 = torch.zeros(B, 5 * 7, C, dtype=BF16, device=dev), torch.zeros(B, 5 * 7, C, dtype=BF16, device=dev)
+    ops.run(ops.maxpool3x3s2(x, pb, H=H, W=W, C=C, images=B))
+    ops.run([ops.maxpool3x3s2(x[i], p1[i], H=H, W=W, C=C) for i in range(B)])
+    lab = (seeded(91, (B, 13, 19), 1.0).abs() * 3).clamp(max=4).to(torch.uint8).to(dev)
+    hb, h1 = torch.zeros(B, 21 * 30, 16, dtype=BF16, device=dev), torch.zeros(B, 21 * 30, 16, dtype=BF16, device=dev)
+    ops.run(ops.label_to_onehot16(lab, hb, Hs=13, Ws=19, Hd=21, Wd=30, ncls=11, images=B))
+    ops.run([ops.label_to_onehot16(lab[i], h1[i], Hs=13, Ws=19, Hd=21, Wd=30, ncls=11) for i in range(B)])
+    lg = seeded(92, (B, M, 16), 2.0).to(dev)
+    lb, l1 = torch.zeros(B, 33, 51, dtype=torch.uint8, device=dev), torch.zeros(B, 33, 51, dtype=torch.uint8, device=dev)
+    ops.run(ops.logits_post(lg, ldl=16, nc=11, keep=4, Hi=H, Wi=W, Ho=33, Wo=51, label_u8=lb, images=B))
+    ops.run([ops.logits_post(lg[i], ldl=16, nc=11, keep=4, Hi=H, Wi=W, Ho=33, Wo=51, label_u8=l1[i]) for i in range(B)])
+    torch.cuda.synchronize()
+    assert torch.equal(nb, n1) and torch.equal(pb, p1) and torch.equal(hb, h1) and torch.equal(lb, l1)
+    assert n1.float().abs().sum() > 0 and p1.float().abs().sum() > 0 and h1.float().sum() > 0 and l1.sum() > 0
     # attention: one-frame flavour (direct output) and memory read over per-clip banks with different slot orders
     L, T, S = 150, 3, 4
     q = rb(seeded(85, (B, L, 768))).to(BF16).to(dev)
