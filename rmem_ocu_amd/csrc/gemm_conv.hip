@@ -819,8 +819,8 @@ extern "C" int rmem_conv2d_nhwc(const rmem_conv_desc* d, const void* x, const vo
     // 128x128 tiles halve the global -> LDS bytes per flop; they pay only where the k-loop dominates (K >= 512) and there are
     // enough tiles to balance 256 CUs.  Measured per layer with 8 images / 4 clips per launch: 121x213 3x3 128->128 563 -> 662
     // TFLOP/s, 512->1024 stride 2 393 -> 470; shallow-K 1x1 layers (64->256, 128->512) lose 20-40 % and stay on 64x64.
-    static const int big_thr = getenv("RMEM_GEMM_BIG") ? atoi(getenv("RMEM_GEMM_BIG")) : 512;
-    static const int big_k = getenv("RMEM_GEMM_BIG_K") ? atoi(getenv("RMEM_GEMM_BIG_K")) : 512;
+    static const int big_thr = getenv("RMEM_GEMM_BIG") ? atoi(getenv("RMEM_GEMM_BIG")) : 128;
+    static const int big_k = getenv("RMEM_GEMM_BIG_K") ? atoi(getenv("RMEM_GEMM_BIG_K")) : 256;
     static const int big_st = getenv("RMEM_GEMM_BIG_ST") ? atoi(getenv("RMEM_GEMM_BIG_ST")) : 1;
     if (splits == 1 && big_thr > 0 && p.fast_ok == 1 && p.Cout >= 128 && p.K >= big_k &&
         (long)((p.M + 127) / 128) * ((p.Cout + 127) / 128) >= big_thr) {
@@ -852,8 +852,8 @@ extern "C" int rmem_conv1x1_dual_nhwc(const rmem_conv_desc* d, const void* x, co
   const long lim = (1L << 31) - (1L << 22);
   RMEM_REQUIRE(p.x_elems * 2 < lim && p.x2_elems * 2 < lim && (long)p.Cout * p.K * 2 < lim, "rmem_conv1x1_dual_nhwc: operands must stay below 2 GB");
   hipStream_t s = (hipStream_t)stream;
-  static const int big_thr = getenv("RMEM_GEMM_BIG") ? atoi(getenv("RMEM_GEMM_BIG")) : 512;
-  if (big_thr > 0 && p.Cout >= 128 && p.K >= 512 && (long)((p.M + 127) / 128) * ((p.Cout + 127) / 128) >= big_thr) {
+  static const int big_thr = getenv("RMEM_GEMM_BIG") ? atoi(getenv("RMEM_GEMM_BIG")) : 128;
+  if (big_thr > 0 && p.Cout >= 128 && p.K >= 256 && (long)((p.M + 127) / 128) * ((p.Cout + 127) / 128) >= big_thr) {
     dim3 grid((p.M + 127) / 128, (p.Cout + 127) / 128, 1);
     hipLaunchKernelGGL((k_conv_gemm_dma_big<true, 1, 128, 128, 3>), grid, dim3(256), 0, s, p);
   } else {
