@@ -214,7 +214,7 @@ class GroupSlot:
                     imgs = torch.cat([f[i:i + 1] for f in self.frames], 0)
             eng.propagate_to_labels(self.cur_label, imgs=imgs)
         eng.update_from_labels(self.cur_label)
-        for c in range(B):
-            ops.copy_async(self.labels[c, i], self.cur_label[c], self.cur_label[c].numel())(s)
+        nb = self.cur_label[0].numel()                # frame i of every clip's label stack: one pitched copy
+        ops.copy2d_async(self.labels.view(-1)[i * nb:], self.labels.shape[1] * nb, self.cur_label, nb, nb, B)(s)
         self.cursor += 1
         self.done = self.cursor >= self.frames[0].shape[0]
