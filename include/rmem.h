@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define RMEM_ABI_VERSION 3
+#define RMEM_ABI_VERSION 4
 
 int rmem_abi_version(void);
 const char* rmem_last_error_string(void);

@@ -11,7 +11,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('RMEM_LIB_PATH') or os.path.join(_HERE, 'librmem_hip.so')   # override: kernel experiments only
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class RmemError(RuntimeError):
