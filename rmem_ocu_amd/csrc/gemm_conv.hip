@@ -827,6 +827,11 @@ extern "C" int rmem_conv2d_nhwc(const rmem_conv_desc* d, const void* x, const vo
       launch_big<128, 128>(p, is1x1, big_st, s);
       return rmem_check_launch("rmem_conv2d_nhwc");
     }
+    static const int big64 = getenv("RMEM_GEMM_BIG64") ? atoi(getenv("RMEM_GEMM_BIG64")) : 0;
+    if (splits == 1 && big64 > 0 && p.fast_ok == 1 && p.Cout <= 64 && p.K >= big_k && (p.M + 127) / 128 >= big64) {
+      launch_big<128, 64>(p, is1x1, big_st, s);
+      return rmem_check_launch("rmem_conv2d_nhwc");
+    }
     launch<64, 64, 4>(p, is1x1, splits, s);
   }
   return rmem_check_launch("rmem_conv2d_nhwc");
