@@ -710,7 +710,10 @@ void launch(const ConvParams& p, bool is1x1, int splits, hipStream_t s) {
 template <int BM, int BN>
 void launch_big(const ConvParams& p, bool is1x1, int st, hipStream_t s) {
   dim3 grid((p.M + BM - 1) / BM, (p.Cout + BN - 1) / BN, 1);
-  if (st == 2) {
+  if (st == 3) {
+    if (is1x1) hipLaunchKernelGGL((k_conv_gemm_dma_big<true, 3, BM, BN, 1>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((k_conv_gemm_dma_big<false, 3, BM, BN, 1>), grid, dim3(256), 0, s, p);
+  } else if (st == 2) {
     if (is1x1) hipLaunchKernelGGL((k_conv_gemm_dma_big<true, 2, BM, BN, 1>), grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL((k_conv_gemm_dma_big<false, 2, BM, BN, 1>), grid, dim3(256), 0, s, p);
   } else {
@@ -824,7 +827,10 @@ extern "C" int rmem_conv2d_nhwc(const rmem_conv_desc* d, const void* x, const vo
     static const int big_st = getenv("RMEM_GEMM_BIG_ST") ? atoi(getenv("RMEM_GEMM_BIG_ST")) : 1;
     if (splits == 1 && big_thr > 0 && p.fast_ok == 1 && p.Cout >= 128 && p.K >= big_k &&
         (long)((p.M + 127) / 128) * ((p.Cout + 127) / 128) >= big_thr) {
-      launch_big<128, 128>(p, is1x1, big_st, s);
+      // at most ~1 workgroup per CU and a deep k-loop: nothing else hides the DMA latency, so keep two k-steps in flight
+      static const int big_deep = getenv("RMEM_GEMM_BIG_DEEP") ? atoi(getenv("RMEM_GEMM_BIG_DEEP")) : 256;
+      const long t128 = (long)((p.M + 127) / 128) * ((p.Cout + 127) / 128);
+      launch_big<128, 128>(p, is1x1, (t128 <= big_deep && p.K >= 512) ? 3 : big_st, s);
       return rmem_check_launch("rmem_conv2d_nhwc");
     }
     static const int big64 = getenv("RMEM_GEMM_BIG64") ? atoi(getenv("RMEM_GEMM_BIG64")) : 0;
