@@ -149,6 +149,73 @@ def test_mem_read_attn_vs_oracle(dev, T, L, synth_weights):
     assert abs(mass.sum(1).mean().item() - 1.0) < 1e-3
 
 
+def test_mem_read_full_size_properties(dev, synth_weights):
+    """BASELINE configuration of the memory read (HW = 1674 tokens, T = 8 bank frames, 4 clips per launch) through the
+    size-independent properties of the operation, no oracle needed: (1) the per-frame probability mass of every query sums
+    to 1; (2) the result does not depend on which physical bank slots hold the frames nor on how frames are cut into key
+    ranges; (3) the read is linear in V; (4) a second launch is bit-identical; (5) the 4-clip launch equals 4 launches."""
+    from rmem_ocu_amd import ops
+    from rmem_ocu_amd.runtime import temporal_slots
+    L, T, C, B, S = 1674, 8, 256, 4, 9
+    slots = temporal_slots(T)
+    q = rb(seeded(301, (B, L, C))).to(BF16).to(dev)
+    kb = rb(seeded(302, (B * S, L, C))).to(BF16).to(dev)
+    vb = rb(seeded(303, (B * S, L, C))).to(BF16).to(dev)
+    pe_cur = synth_weights['cur_pos_emb'].view(-1).to(dev)
+    pe_mem = synth_weights['mem_pos_emb'].to(dev).contiguous()
+    order = [list(np.random.RandomState(c).permutation(S)[:T]) for c in range(B)]      # frame t of clip c lives in slot order[c][t]
+
+    def read(kbank, vbank, order, splits, clips=range(B), grouped=True):
+        per = (L + splits - 1) // splits
+        out = torch.zeros(B, L, C, dtype=BF16, device=dev)
+        mass = torch.zeros(B, L, T, dtype=F32, device=dev)
+        rows = {c: [(c * S + int(order[c][t]), j * per, min(per, L - j * per), slots[t], t) for t in range(T) for j in range(splits)]
+                for c in clips}
+        n = T * splits
+        ws = ops.attn_workspace(L, 8, n, dev, nclips=B)
+        if grouped:
+            tab = ops.make_chunk_table([r for c in clips for r in rows[c]]).to(dev)
+            ops.run(ops.mem_read_attn(q, kbank, vbank, out, ws, Lq=L, ldq=C, ldkv=C, ldo=C, slot_stride=L * C, chunks=tab, nchunks=n,
+                                      pe_cur=pe_cur, pe_mem=pe_mem, mass=mass, T=T, nclips=B, q_cs=L * C, out_cs=L * C))
+        else:
+            for c in clips:
+                tab = ops.make_chunk_table(rows[c]).to(dev)
+                ops.run(ops.mem_read_attn(q[c], kbank, vbank, out[c], ws, Lq=L, ldq=C, ldkv=C, ldo=C, slot_stride=L * C, chunks=tab,
+                                          nchunks=n, pe_cur=pe_cur, pe_mem=pe_mem, mass=mass[c], T=T))
+        torch.cuda.synchronize()
+        return out, mass
+
+    out, mass = read(kb, vb, order, 1)
+    assert out.float().abs().mean().item() > 1e-3
+    assert (mass.sum(2) - 1.0).abs().max().item() < 1e-4, 'probability mass over the bank frames must sum to 1'      # (1)
+    assert mass.min().item() >= 0.0
+    out2, mass2 = read(kb, vb, order, 1)
+    assert torch.equal(out, out2) and torch.equal(mass, mass2), 'two launches differ'                                   # (4)
+    outc, massc = read(kb, vb, order, 1, grouped=False)
+    assert torch.equal(out, outc) and torch.equal(mass, massc), 'clip group differs from per-clip launches'             # (5)
+    # (2) move every frame to another physical slot, and cut frames into 3 key ranges
+    order2 = [list(np.random.RandomState(100 + c).permutation(S)[:T]) for c in range(B)]
+    kb2, vb2 = torch.zeros_like(kb), torch.zeros_like(vb)
+    for c in range(B):
+        for t in range(T):
+            kb2[c * S + int(order2[c][t])] = kb[c * S + int(order[c][t])]
+            vb2[c * S + int(order2[c][t])] = vb[c * S + int(order[c][t])]
+    outp, massp = read(kb2, vb2, order2, 1)
+    assert torch.equal(out, outp) and torch.equal(mass, massp), 'result depends on the physical bank slots'
+    outs, masss = read(kb, vb, order, 3)
+    assert_close(outs, out.float().cpu(), 1e-2, 'frames cut into 3 key ranges')
+    assert (masss - mass).abs().max().item() < 1e-4
+    # (3) linearity in V (K fixed): read(V1 + V2) = read(V1) + read(V2) up to the bf16 rounding of the three outputs
+    v2 = rb(seeded(304, (B * S, L, C))).to(BF16).to(dev)
+    vsum = (vb.float() + v2.float())
+    o1, _ = read(kb, vb, order, 1)
+    o2, _ = read(kb, v2, order, 1)
+    o12, _ = read(kb, vsum.to(BF16), order, 1)
+    # the bf16 rounding of V1 + V2 is itself a perturbation of 2^-9 relative: compare against the read of the ROUNDED sum
+    lin = o1.float() + o2.float()
+    assert_close(o12, lin.cpu(), 2e-2, 'linearity in V')
+
+
 def test_plain_attn_split_keys(dev):
     """a4 / a5 core: one key frame split into 4 key ranges, no temporal PE, strided q/k/v views."""
     from rmem_ocu_amd import ops
