@@ -71,6 +71,17 @@ def test_state_dict_contract_and_packing():
     w = P[p + '.conv1.w'].float().permute(0, 3, 1, 2)
     y = torch.nn.functional.conv2d(x, w, P[p + '.conv1.b'])
     assert (y - y_ref).abs().max() < 0.05 * y_ref.abs().max()
+    # conv3 + strided 1x1 shortcut packed side by side (rmem_conv1x1_dual_nhwc): [h | x sampled] @ Wcat^T + b == bn3(conv3(h)) + bn_d(conv_d(x))
+    for p, stride in (('encoder.layer1.0', 1), ('encoder.layer2.0', 2)):
+        k1, k2 = ref[p + '.conv3.weight'].shape[1], ref[p + '.downsample.0.weight'].shape[1]
+        h, xin = torch.randn(1, k1, 5, 6), torch.randn(1, k2, 5 * stride - (stride - 1), 6 * stride - (stride - 1))
+        y_ref = O.frozen_bn(torch.nn.functional.conv2d(h, ref[p + '.conv3.weight']), ref, p + '.bn3') + \
+            O.frozen_bn(torch.nn.functional.conv2d(xin, ref[p + '.downsample.0.weight'], stride=stride), ref, p + '.downsample.1')
+        wcat = P[p + '.c3ds.w'].float()
+        assert wcat.shape == (ref[p + '.conv3.weight'].shape[0], k1 + k2)
+        a = torch.cat([h, xin[:, :, ::stride, ::stride]], 1).permute(0, 2, 3, 1).reshape(-1, k1 + k2)
+        y = (a @ wcat.t() + P[p + '.c3ds.b']).reshape(1, 5, 6, -1).permute(0, 3, 1, 2)
+        assert (y - y_ref).abs().max() < 0.02 * y_ref.abs().max()
 
 
 def test_network_size_rule():
