@@ -173,10 +173,20 @@ __global__ __launch_bounds__(256) void k_attn_partial(AttnParams pin) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) cinit[r] = bias;
 
+  // HW = 1674 = 13 * 128 + 10: in the last query tile only wave 0 owns real rows.  The other waves still stage K/V and meet
+  // the barriers, but skip the softmax / MFMA work (the kernel is VALU-bound: 3 of 56 wave-tiles per (head, chunk) saved).
+  const bool wave_active = qt * 128 + wave * 32 < p.Lq;
   const int ntiles = (kn + KT - 1) / KT;
   load_tile(0);
   store_tile(0);
   __syncthreads();
+  if (!wave_active) {            // staging-only twin of the main loop: same loads, stores and barriers, no arithmetic
+    for (int t = 0; t < ntiles; ++t) {
+      if (t + 1 < ntiles) { load_tile(t + 1); store_tile((t & 1) ^ 1); }
+      __syncthreads();
+    }
+    return;
+  }
 
   for (int t = 0; t < ntiles; ++t) {
     const int cur = t & 1;
