@@ -54,6 +54,11 @@ typedef struct rmem_conv_desc {
                          clips' frames go through the encoder as one launch per layer */
   int act_begin;      /* the activation applies to output channels >= act_begin (multiple of 8; 0 = all): one GEMM for
                          linear_QV, whose Q half is raw and whose V half goes through SiLU (transformer.py:1104-1110) */
+  int res_up_h, res_up_w, res_up_align;
+                      /* res_up_h > 0: `residual` is a LOWER-resolution bf16 map [batch][res_up_h][res_up_w] rows of ldr and is
+                         bilinearly resized to (Ho, Wo) on the fly (rounded to bf16 like rmem_bilinear_nhwc, so both routes
+                         are bit-identical): `F.interpolate(x, size) + adapter(shortcut)` of decoders/fpn.py:49-52, 57-60
+                         without materialising the resized map.  Needs Cout % 8 == 0 and 16-byte aligned operands. */
 } rmem_conv_desc;
 
 /* Problems with few output tiles are cut along K (split-K) when a workspace of at least

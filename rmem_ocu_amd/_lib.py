@@ -20,7 +20,8 @@ class RmemError(RuntimeError):
 
 class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int) for n in ('H', 'W', 'Cin', 'Ho', 'Wo', 'Cout', 'KH', 'KW', 'stride', 'pad',
-                                       'ldo', 'ldr', 'ld2', 'relu', 'out_f32', 'res_f32', 'ldx', 'batch', 'act_begin')]
+                                       'ldo', 'ldr', 'ld2', 'relu', 'out_f32', 'res_f32', 'ldx', 'batch', 'act_begin',
+                                       'res_up_h', 'res_up_w', 'res_up_align')]
 
 
 class AttnChunk(C.Structure):

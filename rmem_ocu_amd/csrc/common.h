@@ -24,6 +24,24 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// source coordinate of destination index d of a bilinear resize (PyTorch upsample_bilinear2d semantics)
+// (explicit fmaf: every caller must get the same coordinates and blend whatever -ffp-contract chooses around the call)
+__device__ __forceinline__ void rmem_src_coord(int d, int in, int out, int align, int& i0, int& i1, float& w1) {
+  float s;
+  if (align) s = out > 1 ? (float)d * ((float)(in - 1) / (float)(out - 1)) : 0.f;
+  else s = fmaxf(__builtin_fmaf((float)d + 0.5f, (float)in / (float)out, -0.5f), 0.f);
+  i0 = min((int)s, in - 1);
+  i1 = min(i0 + 1, in - 1);
+  w1 = s - (float)i0;
+}
+// bilinear blend of the four taps, one fixed operation sequence (rmem_bilinear_nhwc and the GEMM's resized residual)
+__device__ __forceinline__ float rmem_bilerp(float a, float b, float c, float d, float wx, float wy) {
+  const float ux = 1.f - wx, uy = 1.f - wy;
+  const float top = __builtin_fmaf(b, wx, a * ux);
+  const float bot = __builtin_fmaf(d, wx, c * ux);
+  return __builtin_fmaf(bot, wy, top * uy);
+}
+
 // error plumbing shared by the C-ABI translation units (api.cpp owns the storage)
 extern "C" void rmem_set_error(const char* msg);
 int rmem_check_launch(const char* what);

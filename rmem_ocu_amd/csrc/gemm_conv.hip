@@ -45,6 +45,7 @@ struct ConvParams {
   int relu, out_f32, res_f32;
   int ldx;               // input row stride of the 1x1 (GEMM) case
   int act_begin;         // first output channel the activation applies to (multiple of 8)
+  int up_h, up_w, up_align;   // > 0: the (bf16) residual is a [batch][up_h][up_w] map, bilinearly resized to (Ho, Wo) on the fly
   int steps_per_split;   // k-steps (of 32) per gridDim.z slice
   int vec_ok;            // all leading dimensions / pointers allow 8-wide vector access
   long x_elems;          // addressable span of x in elements (fast path: buffer descriptor range)
@@ -72,7 +73,21 @@ __device__ __forceinline__ void finish8(const ConvParams& p, int m, int n, float
     for (int j = 0; j < 8; ++j) o[j] = (bf16)v[j];
     *reinterpret_cast<bf16x8*>(p.y2 + (long)m * p.ld2 + n) = o;
   }
-  if (p.res) {
+  if (p.res && p.up_h > 0) {
+    // same arithmetic and the same bf16 rounding as k_bilinear_nhwc followed by a plain residual add
+    const int img = m / p.HoWo, rem = m - img * p.HoWo;
+    const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+    int y0, y1, x0, x1; float wy, wx;
+    rmem_src_coord(oy, p.up_h, p.Ho, p.up_align, y0, y1, wy);
+    rmem_src_coord(ox, p.up_w, p.Wo, p.up_align, x0, x1, wx);
+    const bf16* rb = reinterpret_cast<const bf16*>(p.res) + (long)img * p.up_h * p.up_w * p.ldr + n;
+    const bf16x8 a = *reinterpret_cast<const bf16x8*>(rb + ((long)y0 * p.up_w + x0) * p.ldr);
+    const bf16x8 b = *reinterpret_cast<const bf16x8*>(rb + ((long)y0 * p.up_w + x1) * p.ldr);
+    const bf16x8 c = *reinterpret_cast<const bf16x8*>(rb + ((long)y1 * p.up_w + x0) * p.ldr);
+    const bf16x8 d = *reinterpret_cast<const bf16x8*>(rb + ((long)y1 * p.up_w + x1) * p.ldr);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] += (float)(bf16)rmem_bilerp((float)a[j], (float)b[j], (float)c[j], (float)d[j], wx, wy);
+  } else if (p.res) {
     if (p.res_f32) {
       const float* r = reinterpret_cast<const float*>(p.res) + (long)m * p.ldr + n;
       const f32x4 r0 = *reinterpret_cast<const f32x4*>(r), r1 = *reinterpret_cast<const f32x4*>(r + 4);
@@ -780,6 +795,10 @@ static int conv_setup(const rmem_conv_desc* d, const void* x, const void* w, con
                "rmem_conv2d_nhwc: ldx needs a 1x1 stride-1 problem, ldx >= Cin, ldx % 8 == 0");
   p.ldx = d->ldx ? d->ldx : d->Cin;
   p.act_begin = d->act_begin;
+  p.up_h = d->res_up_h; p.up_w = d->res_up_w; p.up_align = d->res_up_align;
+  RMEM_REQUIRE(p.up_h >= 0 && p.up_w >= 0 && (p.up_h > 0) == (p.up_w > 0), "rmem_conv2d_nhwc: res_up_h / res_up_w must both be set or both be 0");
+  RMEM_REQUIRE(p.up_h == 0 || (residual && !d->res_f32 && p.Cout % 8 == 0 && p.ldr % 8 == 0 && ((uintptr_t)residual % 16) == 0 && p.ldo % 8 == 0),
+               "rmem_conv2d_nhwc: the resized residual must be bf16, 16-byte aligned, with Cout, ldr, ldo multiples of 8");
   p.steps_per_split = (p.K + 63) / 64;
   auto al = [](const void* q, int a) { return q == nullptr || ((uintptr_t)q % a) == 0; };
   {

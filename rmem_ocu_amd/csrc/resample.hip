@@ -57,14 +57,8 @@ __global__ __launch_bounds__(256) void k_maxpool3s2(const bf16* x, bf16* y, int 
   reinterpret_cast<bf16x8*>(y)[i] = o;
 }
 
-// source coordinate of destination index d (PyTorch upsample_bilinear2d semantics)
 __device__ __forceinline__ void src_coord(int d, int in, int out, int align, int& i0, int& i1, float& w1) {
-  float s;
-  if (align) s = out > 1 ? (float)d * ((float)(in - 1) / (float)(out - 1)) : 0.f;
-  else s = fmaxf(((float)d + 0.5f) * ((float)in / (float)out) - 0.5f, 0.f);
-  i0 = min((int)s, in - 1);
-  i1 = min(i0 + 1, in - 1);
-  w1 = s - (float)i0;
+  rmem_src_coord(d, in, out, align, i0, i1, w1);
 }
 
 __global__ __launch_bounds__(256) void k_bilinear_nhwc(const bf16* x, bf16* y, int Hi, int Wi, int Ho, int Wo, int C, int align) {
@@ -86,11 +80,7 @@ __global__ __launch_bounds__(256) void k_bilinear_nhwc(const bf16* x, bf16* y, i
   const bf16x8 d = *reinterpret_cast<const bf16x8*>(x + ((long)y1 * Wi + x1) * C + c0);
   bf16x8 o;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const float top = (float)a[j] * (1.f - wx) + (float)b[j] * wx;
-    const float bot = (float)c[j] * (1.f - wx) + (float)d[j] * wx;
-    o[j] = (bf16)(top * (1.f - wy) + bot * wy);
-  }
+  for (int j = 0; j < 8; ++j) o[j] = (bf16)rmem_bilerp((float)a[j], (float)b[j], (float)c[j], (float)d[j], wx, wy);
   reinterpret_cast<bf16x8*>(y)[i] = o;
 }
 

@@ -249,16 +249,27 @@ class GroupRuntime:
         o.append(self._conv(self.d16a, P['dec.conv_16x.w'], P['dec.conv_16x.b'], self.d16b, H=self.H16, W=self.W16, Cin=256, Cout=256,
                             KH=3, KW=3, pad=1))
         o.append(gn(self.d16b, 'dec.conv_16x', self.d16a, L, 256))
-        o.append(ops.bilinear(self.d16a, self.d8a, Hi=self.H16, Wi=self.W16, Ho=self.H8, Wo=self.W8, C=256, align_corners=self.align,
-                              images=B))
-        o.append(lin(enc2, 'dec.adapter_8x', self.d8b, M8, 512, 256, residual=self.d8a))
+        import os
+        fuse_up = not os.environ.get('RMEM_NO_UPFUSE')      # timing experiments only
+        # F.interpolate(x, size) + adapter(shortcut) (decoders/fpn.py:49-52): the resize happens in the GEMM's residual read
+        if fuse_up:
+            o.append(ops.conv2d(enc2, P['dec.adapter_8x.w'], P['dec.adapter_8x.b'], self.d8b, H=self.H8, W=self.W8, Cin=512, Cout=256,
+                                batch=B, residual=self.d16a, res_up=(self.H16, self.W16, self.align)))
+        else:
+            o.append(ops.bilinear(self.d16a, self.d8a, Hi=self.H16, Wi=self.W16, Ho=self.H8, Wo=self.W8, C=256, align_corners=self.align,
+                                  images=B))
+            o.append(lin(enc2, 'dec.adapter_8x', self.d8b, M8, 512, 256, residual=self.d8a))
         d8c = self.d8a.view(-1)[: B * M8 * 128]
         o.append(self._conv(self.d8b, P['dec.conv_8x.w'], P['dec.conv_8x.b'], d8c, H=self.H8, W=self.W8, Cin=256, Cout=128, KH=3, KW=3,
                             pad=1))
         d8d = self.d8b.view(-1)[: B * M8 * 128]
         o.append(gn(d8c, 'dec.conv_8x', d8d, M8, 128))
-        o.append(ops.bilinear(d8d, self.d4a, Hi=self.H8, Wi=self.W8, Ho=self.H4, Wo=self.W4, C=128, align_corners=self.align, images=B))
-        o.append(lin(enc1, 'dec.adapter_4x', self.d4b, M4, 256, 128, residual=self.d4a))
+        if fuse_up:
+            o.append(ops.conv2d(enc1, P['dec.adapter_4x.w'], P['dec.adapter_4x.b'], self.d4b, H=self.H4, W=self.W4, Cin=256, Cout=128,
+                                batch=B, residual=d8d, res_up=(self.H8, self.W8, self.align)))
+        else:
+            o.append(ops.bilinear(d8d, self.d4a, Hi=self.H8, Wi=self.W8, Ho=self.H4, Wo=self.W4, C=128, align_corners=self.align, images=B))
+            o.append(lin(enc1, 'dec.adapter_4x', self.d4b, M4, 256, 128, residual=self.d4a))
         o.append(self._conv(self.d4b, P['dec.conv_4x.w'], P['dec.conv_4x.b'], self.d4a, H=self.H4, W=self.W4, Cin=128, Cout=128, KH=3,
                             KW=3, pad=1))
         o.append(gn(self.d4a, 'dec.conv_4x', self.d4b, M4, 128))

@@ -54,9 +54,10 @@ def _dev(*ts):
 
 
 def conv2d(x, w, bias, y, *, H, W, Cin, Cout, KH=1, KW=1, stride=1, pad=0, residual=None, y2=None, relu=False,
-           ldo=None, ldr=None, ld2=None, ws=None, ldx=0, act_begin=0, batch=1) -> Op:
+           ldo=None, ldr=None, ld2=None, ws=None, ldx=0, act_begin=0, batch=1, res_up=None) -> Op:
     """y = act(conv(x, w) + bias (+ residual)); w is [Cout, KH, KW, Cin] bf16, x NHWC bf16.
-    relu: False/0 none, True/1 ReLU, 2 exact GELU, 3 SiLU (channels >= act_begin); ldx: input row stride of a 1x1 problem."""
+    relu: False/0 none, True/1 ReLU, 2 exact GELU, 3 SiLU (channels >= act_begin); ldx: input row stride of a 1x1 problem.
+    res_up=(h, w, align_corners): residual is a bf16 [batch, h, w, ldr] map, bilinearly resized to the output size on the fly."""
     _dev(x, w, bias, y, residual, y2)
     assert x.dtype == BF16 and w.dtype == BF16 and w.is_contiguous()
     assert w.numel() == Cout * KH * KW * Cin, (w.shape, Cout, KH, KW, Cin)
@@ -69,8 +70,11 @@ def conv2d(x, w, bias, y, *, H, W, Cin, Cout, KH=1, KW=1, stride=1, pad=0, resid
     ld2 = Cout if ld2 is None else ld2
     assert x.numel() >= (batch * H * W - 1) * (ldx or Cin) + Cin and y.numel() >= (batch * Ho * Wo - 1) * ldo + Cout
     assert batch == 1 or not ldx
+    ru = (0, 0, 0) if res_up is None else (int(res_up[0]), int(res_up[1]), int(bool(res_up[2])))
+    if res_up is not None:
+        assert residual is not None and residual.dtype == BF16 and residual.numel() >= (batch * ru[0] * ru[1] - 1) * ldr + Cout
     d = ConvDesc(H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, ldo, ldr, ld2, int(relu), int(y.dtype == F32),
-                 int(residual is not None and residual.dtype == F32), ldx, batch, act_begin)
+                 int(residual is not None and residual.dtype == F32), ldx, batch, act_begin, *ru)
     if ws is not None:   # split-K workspace: use it only if it is big enough for this problem
         _dev(ws)
         if ws.numel() * ws.element_size() < _lib.lib().rmem_conv_workspace_bytes(C.byref(d)):
@@ -86,7 +90,7 @@ def conv1x1_dual(x, x2, w_cat, bias, y, *, H, W, Cin, Cout, H2, W2, Cin2, stride
     assert x.dtype == BF16 and x2.dtype == BF16 and w_cat.dtype == BF16 and w_cat.is_contiguous() and y.dtype == BF16
     assert w_cat.numel() == Cout * (Cin + Cin2) and bias.dtype == F32 and bias.numel() == Cout
     assert x.numel() >= batch * H * W * Cin and x2.numel() >= batch * H2 * W2 * Cin2 and y.numel() >= batch * H * W * Cout
-    d = ConvDesc(H, W, Cin, H, W, Cout, 1, 1, 1, 0, Cout, Cout, Cout, int(relu), 0, 0, 0, batch, 0)
+    d = ConvDesc(H, W, Cin, H, W, Cout, 1, 1, 1, 0, Cout, Cout, Cout, int(relu), 0, 0, 0, batch, 0, 0, 0, 0)
     args = (C.byref(d), _ptr(x), _ptr(x2), H2, W2, Cin2, stride2, _ptr(w_cat), _ptr(bias), _ptr(y))
     return Op(_lib.lib().rmem_conv1x1_dual_nhwc, args, 'rmem_conv1x1_dual_nhwc', (d, x, x2, w_cat, bias, y))
 

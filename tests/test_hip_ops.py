@@ -522,6 +522,32 @@ def test_conv1x1_dual_bottleneck_tail(dev, B, H2, W2, K1, K2, Cout, stride):
     assert_close(y, ref.permute(0, 2, 3, 1).reshape(B * Ho * Wo, Cout), 1e-2, 'conv3 + shortcut')
 
 
+@pytest.mark.parametrize('align', [True, False])
+def test_conv_resized_residual_is_bit_identical(dev, align):
+    """rmem_conv_desc.res_up_*: the residual is a lower-resolution map resized on the fly in the GEMM epilogue
+    (decoders/fpn.py:49-52: F.interpolate + adapter) -- bit-identical to rmem_bilinear_nhwc followed by a plain residual add,
+    and close to the fp32 torch reference; a batch of 2 images, 128x128 and 64x64 tile routes."""
+    from rmem_ocu_amd import ops
+    for (B, Hi, Wi, Ho, Wo, Cin, Cout) in [(2, 31, 54, 61, 107, 512, 256), (2, 9, 11, 17, 21, 64, 128)]:
+        x = rb(seeded(61, (B, Cin, Ho, Wo)))
+        lo = rb(seeded(62, (B, Cout, Hi, Wi)))
+        w = rb(seeded(63, (Cout, Cin, 1, 1), 1.0 / Cin ** 0.5))
+        b = seeded(64, (Cout,), 0.1)
+        ref = F.conv2d(x, w, b) + F.interpolate(lo, size=(Ho, Wo), mode='bilinear', align_corners=align)
+        xd = x.permute(0, 2, 3, 1).reshape(B * Ho * Wo, Cin).contiguous().to(BF16).to(dev)
+        lod = lo.permute(0, 2, 3, 1).reshape(B * Hi * Wi, Cout).contiguous().to(BF16).to(dev)
+        wd, bd = pack_w(w).to(dev), b.to(dev)
+        up = torch.zeros(B * Ho * Wo, Cout, dtype=BF16, device=dev)
+        y1 = torch.zeros(B * Ho * Wo, Cout, dtype=BF16, device=dev)
+        y2 = torch.zeros(B * Ho * Wo, Cout, dtype=BF16, device=dev)
+        ops.run([ops.bilinear(lod, up, Hi=Hi, Wi=Wi, Ho=Ho, Wo=Wo, C=Cout, align_corners=align, images=B),
+                 ops.conv2d(xd, wd, bd, y1, H=Ho, W=Wo, Cin=Cin, Cout=Cout, batch=B, residual=up)])
+        ops.run(ops.conv2d(xd, wd, bd, y2, H=Ho, W=Wo, Cin=Cin, Cout=Cout, batch=B, residual=lod, res_up=(Hi, Wi, align)))
+        torch.cuda.synchronize()
+        assert torch.equal(y1, y2), 'fused resize differs from bilinear + residual'
+        assert_close(y2, ref.permute(0, 2, 3, 1).reshape(B * Ho * Wo, Cout), 1e-2, 'adapter + resized residual')
+
+
 def test_grouped_launches(dev):
     """rmem_linear_grouped / rmem_add_bf16_grouped / rmem_layernorm256_pair are bit-identical to the single launches."""
     from rmem_ocu_amd import ops
