@@ -425,16 +425,28 @@ class ClipRuntime:
         o.append(self._conv(self.d16a, P['dec.conv_16x.w'], P['dec.conv_16x.b'], self.d16b, H=self.H16, W=self.W16, Cin=256, Cout=256,
                             KH=3, KW=3, pad=1))
         o.append(gn(self.d16b, 'dec.conv_16x', self.d16a, L, 256))
+        import os
+        fuse_up = not os.environ.get('RMEM_NO_UPFUSE')      # timing experiments only
         # F.interpolate(x, size) + adapter(shortcut) (decoders/fpn.py:49-52): the resize happens in the GEMM's residual read
-        o.append(self._conv(enc2, P['dec.adapter_8x.w'], P['dec.adapter_8x.b'], self.d8b, H=self.H8, W=self.W8, Cin=c8, Cout=256,
-                            residual=self.d16a, res_up=(self.H16, self.W16, self.align)))
+        if fuse_up:
+            o.append(self._conv(enc2, P['dec.adapter_8x.w'], P['dec.adapter_8x.b'], self.d8b, H=self.H8, W=self.W8, Cin=c8, Cout=256,
+                                residual=self.d16a, res_up=(self.H16, self.W16, self.align)))
+        else:
+            o.append(ops.bilinear(self.d16a, self.d8a, Hi=self.H16, Wi=self.W16, Ho=self.H8, Wo=self.W8, C=256, align_corners=self.align))
+            o.append(self._conv(enc2, P['dec.adapter_8x.w'], P['dec.adapter_8x.b'], self.d8b, H=M8, W=1, Cin=c8, Cout=256,
+                                residual=self.d8a))
         d8c = self.d8a.view(-1)[: M8 * 128]
         o.append(self._conv(self.d8b, P['dec.conv_8x.w'], P['dec.conv_8x.b'], d8c, H=self.H8, W=self.W8, Cin=256, Cout=128,
                             KH=3, KW=3, pad=1))
         d8d = self.d8b.view(-1)[: M8 * 128]
         o.append(gn(d8c, 'dec.conv_8x', d8d, M8, 128))
-        o.append(self._conv(enc1, P['dec.adapter_4x.w'], P['dec.adapter_4x.b'], self.d4b, H=self.H4, W=self.W4, Cin=c4, Cout=128,
-                            residual=d8d, res_up=(self.H8, self.W8, self.align)))
+        if fuse_up:
+            o.append(self._conv(enc1, P['dec.adapter_4x.w'], P['dec.adapter_4x.b'], self.d4b, H=self.H4, W=self.W4, Cin=c4, Cout=128,
+                                residual=d8d, res_up=(self.H8, self.W8, self.align)))
+        else:
+            o.append(ops.bilinear(d8d, self.d4a, Hi=self.H8, Wi=self.W8, Ho=self.H4, Wo=self.W4, C=128, align_corners=self.align))
+            o.append(self._conv(enc1, P['dec.adapter_4x.w'], P['dec.adapter_4x.b'], self.d4b, H=M4, W=1, Cin=c4, Cout=128,
+                                residual=self.d4a))
         o.append(self._conv(self.d4b, P['dec.conv_4x.w'], P['dec.conv_4x.b'], self.d4a, H=self.H4, W=self.W4, Cin=128, Cout=128,
                             KH=3, KW=3, pad=1))
         o.append(gn(self.d4a, 'dec.conv_4x', self.d4b, M4, 128))
