@@ -190,6 +190,12 @@ int rmem_groupnorm_f32_nhwc(const float* x, int M, int C, int groups, const floa
  * rmem_groupnorm_workspace_bytes(groups). */
 int rmem_groupnorm_nhwc_images(const void* x, int images, int M, int C, int groups, const float* gamma, const float* beta,
                                float eps, int act, void* y, float* workspace, void* stream);
+/* y[m][n] = bias[n] + sum_c w[n][c] * act(GroupNorm(x))[m][c], n < N <= 16, fp32 rows of ldy: the segmentation head's
+ * `conv_out(relu(gn(x)))` (decoders/fpn.py:62-66) in one pass over x (the normalised 128-channel map is never written;
+ * it is rounded to bf16 on chip exactly as rmem_groupnorm_nhwc would store it).  C must be 128; w is [N][128] bf16. */
+int rmem_groupnorm_head_nhwc_images(const void* x, int images, int M, int C, int groups, const float* gamma, const float* beta,
+                                    float eps, int act, const void* w, const float* bias, int N, float* y, int ldy,
+                                    float* workspace, void* stream);
 int rmem_gn_act_dwconv5x5_nhwc_images(const void* x, int images, int H, int W, int C, int groups, const float* gamma,
                                       const float* beta, float eps, int act, const float* w_t, void* y, float* workspace, void* stream);
 int rmem_bilinear_nhwc_images(const void* x, void* y, int images, int Hi, int Wi, int Ho, int Wo, int C, int align_corners, void* stream);

@@ -53,6 +53,7 @@ SIGNATURES = {
     'rmem_groupnorm_nhwc': (_i, [_vp, _i, _i, _i, _vp, _vp, _f, _i, _vp, _vp, _vp]),
     'rmem_groupnorm_f32_nhwc': (_i, [_vp, _i, _i, _i, _vp, _vp, _f, _i, _vp, _vp, _vp]),
     'rmem_groupnorm_nhwc_images': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _f, _i, _vp, _vp, _vp]),
+    'rmem_groupnorm_head_nhwc_images': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _f, _i, _vp, _vp, _i, _vp, _i, _vp, _vp]),
     'rmem_gn_act_dwconv5x5_nhwc_images': (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _f, _i, _vp, _vp, _vp, _vp]),
     'rmem_bilinear_nhwc_images': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     'rmem_mem_read_attn_clips': (_i, [_vp, _i, _vp, _vp, _ll, _i, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _i, _ll, _ll, _ll, _vp, _vp]),

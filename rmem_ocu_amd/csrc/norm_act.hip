@@ -346,6 +346,79 @@ __global__ __launch_bounds__(256) void k_gn_apply_rows(const TI* x, int M, int C
   }
 }
 
+// GroupNorm apply + activation + a narrow 1x1 convolution (N <= 16 outputs) in one pass: the segmentation head's last
+// `conv_out(relu(gn(x)))` (decoders/fpn.py:62-66) without writing the normalised 128-channel map.  A workgroup takes 64 pixels:
+// phase 1 normalises them into LDS (bf16, the rounding the two-kernel route stores), phase 2 gives thread (pixel, 4 outputs)
+// a 128-long dot product against fp32 weights in LDS.  C = 128 only (the path's head); y is fp32 [M][ldy].
+constexpr int HC = 128, HPIX = 64, HROW = HC + 8;
+__global__ __launch_bounds__(256) void k_gn_apply_head(const bf16* x, int M, int cpg, int groups, const float* ws, const float* gamma,
+                                                       const float* beta, float eps, int act, const bf16* w, const float* bias, int N,
+                                                       float* y, int ldy) {
+  x += (long)blockIdx.y * M * HC;
+  y += (long)blockIdx.y * M * ldy;
+  ws += (long)blockIdx.y * groups * GN_SPLITS * 2;
+  __shared__ float s_mean[64], s_rstd[64];
+  __shared__ __attribute__((aligned(16))) bf16 tile[HPIX * HROW];
+  __shared__ __attribute__((aligned(16))) float wl[16 * HC];
+  gn_finalize(ws, groups, (float)M * (float)cpg, eps, s_mean, s_rstd);
+  const int tid = threadIdx.x;
+  for (int i = tid; i < 16 * HC; i += 256) wl[i] = (i / HC) < N ? (float)w[i] : 0.f;     // w is [N][128] bf16
+  __syncthreads();
+  const int m0 = blockIdx.x * HPIX;
+  {
+    const int c = tid & 15, rl = tid >> 4, c0 = c * 8;          // 16 chunks of 8 channels per pixel, 16 pixels per pass
+    const float mean = s_mean[c0 / cpg], rstd = s_rstd[c0 / cpg];
+    float gm[8], bt[8];
+    const f32x4 g0v = *reinterpret_cast<const f32x4*>(gamma + c0), g1v = *reinterpret_cast<const f32x4*>(gamma + c0 + 4);
+    const f32x4 b0v = *reinterpret_cast<const f32x4*>(beta + c0), b1v = *reinterpret_cast<const f32x4*>(beta + c0 + 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { gm[j] = g0v[j]; gm[4 + j] = g1v[j]; bt[j] = b0v[j]; bt[4 + j] = b1v[j]; }
+    float d[4][8];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int r = m0 + rl + 16 * u;
+      if (r < M) gn_load8(x + (long)r * HC + c0, d[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int r = m0 + rl + 16 * u;
+      bf16x8 o = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (r < M) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float f = (d[u][j] - mean) * rstd * gm[j] + bt[j];
+          if (act == 1) f = fmaxf(f, 0.f);
+          else if (act == 2) f = gelu_erf(f);
+          o[j] = (bf16)f;
+        }
+      }
+      *reinterpret_cast<bf16x8*>(&tile[(rl + 16 * u) * HROW + c0]) = o;
+    }
+  }
+  __syncthreads();
+  const int px = tid & 63, og = tid >> 6;                       // og is wave-uniform: weight reads are LDS broadcasts
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+  for (int c8 = 0; c8 < HC / 8; ++c8) {
+    const bf16x8 a = *reinterpret_cast<const bf16x8*>(&tile[px * HROW + c8 * 8]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float* wq = &wl[(og * 4 + q) * HC + c8 * 8];
+      const f32x4 w0 = *reinterpret_cast<const f32x4*>(wq), w1 = *reinterpret_cast<const f32x4*>(wq + 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { acc[q] += (float)a[j] * w0[j]; acc[q] += (float)a[4 + j] * w1[j]; }
+    }
+  }
+  const int m = m0 + px;
+  if (m < M) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int n = og * 4 + q;
+      if (n < N) y[(long)m * ldy + n] = acc[q] + (bias ? bias[n] : 0.f);
+    }
+  }
+}
+
 // ------------------------------------------------------------------ depth-wise 5x5 (NHWC, pad 2)
 // thread = (pixel, 8 channels); weights pre-transposed to [25][C] fp32
 __global__ __launch_bounds__(256) void k_dwconv5(const bf16* x, const float* w, bf16* y, int H, int W, int C) {
@@ -605,6 +678,19 @@ extern "C" int rmem_groupnorm_nhwc_images(const void* x, int images, int M, int 
   gn_launch_stats((const bf16*)x, images, M, C, cpg, workspace, s);
   gn_launch_apply((const bf16*)x, images, M, C, cpg, workspace, gamma, beta, eps, act, (bf16*)y, s);
   return rmem_check_launch("rmem_groupnorm_nhwc_images");
+}
+
+extern "C" int rmem_groupnorm_head_nhwc_images(const void* x, int images, int M, int C, int groups, const float* gamma, const float* beta,
+                                               float eps, int act, const void* w, const float* bias, int N, float* y, int ldy,
+                                               float* workspace, void* stream) {
+  if (gn_check(x, y, gamma, beta, workspace, groups, C, act, M, images)) return -1;
+  RMEM_REQUIRE(C == 128 && w && N >= 1 && N <= 16 && ldy >= N, "rmem_groupnorm_head_nhwc: C must be 128, 1 <= N <= 16 <= ... ldy >= N");
+  const int cpg = C / groups;
+  hipStream_t s = (hipStream_t)stream;
+  gn_launch_stats((const bf16*)x, images, M, C, cpg, workspace, s);
+  hipLaunchKernelGGL(k_gn_apply_head, dim3((M + HPIX - 1) / HPIX, images), dim3(256), 0, s, (const bf16*)x, M, cpg, groups, workspace, gamma,
+                     beta, eps, act, (const bf16*)w, bias, N, y, ldy);
+  return rmem_check_launch("rmem_groupnorm_head_nhwc_images");
 }
 
 extern "C" int rmem_groupnorm_nhwc(const void* x, int M, int C, int groups, const float* gamma, const float* beta, float eps,

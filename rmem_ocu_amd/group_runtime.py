@@ -272,8 +272,12 @@ class GroupRuntime:
             o.append(lin(enc1, 'dec.adapter_4x', self.d4b, M4, 256, 128, residual=self.d4a))
         o.append(self._conv(self.d4b, P['dec.conv_4x.w'], P['dec.conv_4x.b'], self.d4a, H=self.H4, W=self.W4, Cin=128, Cout=128, KH=3,
                             KW=3, pad=1))
-        o.append(gn(self.d4a, 'dec.conv_4x', self.d4b, M4, 128))
-        o.append(lin(self.d4b, 'dec.conv_out', self.logits, M4, 128, self.nc, ldo=16))
+        if os.environ.get('RMEM_NO_HEADFUSE'):               # timing experiments only
+            o.append(gn(self.d4a, 'dec.conv_4x', self.d4b, M4, 128))
+            o.append(lin(self.d4b, 'dec.conv_out', self.logits, M4, 128, self.nc, ldo=16))
+        else:                                                # conv_out(relu(gn(x))) in one pass over x (decoders/fpn.py:62-66)
+            o.append(ops.groupnorm_head(self.d4a, P['dec.conv_4x.gn.g'], P['dec.conv_4x.gn.b'], P['dec.conv_out.w'], P['dec.conv_out.b'],
+                                        self.logits, self.gn_ws, M=M4, C=128, groups=8, N=self.nc, ldy=16, act=1, images=B))
         self._prog[key] = o
         return o
 

@@ -225,6 +225,17 @@ def groupnorm(x, gamma, beta, y, ws, *, M, C, groups, act=0, eps=1e-5, images=1)
     return Op(_lib.lib().rmem_groupnorm_nhwc, args, 'rmem_groupnorm_nhwc', (x, gamma, beta, y, ws))
 
 
+def groupnorm_head(x, gamma, beta, w, bias, y, ws, *, M, C, groups, N, ldy, act=1, eps=1e-5, images=1) -> Op:
+    """y[images*M, ldy] fp32: y[:, :N] = act(GroupNorm(x)) @ w^T + bias with w [N, C] bf16 (N <= 16, C == 128), one pass over x."""
+    _dev(x, gamma, beta, w, bias, y, ws)
+    assert x.dtype == BF16 and w.dtype == BF16 and y.dtype == F32 and gamma.dtype == F32 and gamma.numel() == C
+    assert w.numel() == N * C and w.is_contiguous() and (bias is None or (bias.dtype == F32 and bias.numel() == N))
+    assert x.numel() >= images * M * C and y.numel() >= (images * M - 1) * ldy + N
+    assert ws.numel() * 4 >= images * _lib.lib().rmem_groupnorm_workspace_bytes(groups)
+    args = (_ptr(x), images, M, C, groups, _ptr(gamma), _ptr(beta), eps, act, _ptr(w), _ptr(bias), N, _ptr(y), ldy, _ptr(ws))
+    return Op(_lib.lib().rmem_groupnorm_head_nhwc_images, args, 'rmem_groupnorm_head_nhwc', (x, gamma, beta, w, bias, y, ws))
+
+
 def gn_act_dwconv5x5(x, gamma, beta, w_t, y, ws, *, H, W, C, groups, act=2, eps=1e-5, images=1) -> Op:
     """y = dwconv5x5(act(GroupNorm(x))): statistics launch + one fused normalise / activate / convolve launch."""
     _dev(x, gamma, beta, w_t, y, ws)

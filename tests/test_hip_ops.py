@@ -548,6 +548,31 @@ def test_conv_resized_residual_is_bit_identical(dev, align):
         assert_close(y2, ref.permute(0, 2, 3, 1).reshape(B * Ho * Wo, Cout), 1e-2, 'adapter + resized residual')
 
 
+@pytest.mark.parametrize('B,M', [(1, 500), (3, 1674 + 37)])
+def test_groupnorm_head_fused(dev, B, M):
+    """conv_out(relu(gn(x))) (decoders/fpn.py:62-66) as one pass: against the two-launch route (GroupNorm + 1x1 GEMM; same
+    bf16 operands, fp32 summation order differs) and against the fp32 torch reference."""
+    from rmem_ocu_amd import ops
+    C, N = 128, 11
+    x = rb(seeded(71, (B, C, M, 1), 2.0))
+    g, b = 1 + seeded(72, (C,), 0.1), seeded(73, (C,), 0.1)
+    w, wb = rb(seeded(74, (N, C, 1, 1), 1.0 / C ** 0.5)), seeded(75, (N,), 0.1)
+    ref = F.conv2d(rb(F.relu(F.group_norm(x, 8, g, b, 1e-5))), w, wb)[:, :, :, 0].permute(0, 2, 1)      # [B, M, N]
+    xd = x[:, :, :, 0].permute(0, 2, 1).contiguous().to(BF16).to(dev)
+    ws = ops.groupnorm_workspace(8, dev, images=B)
+    wd = w.reshape(N, C).contiguous().to(BF16).to(dev)
+    y1 = torch.zeros(B * M, 16, dtype=F32, device=dev)
+    y2 = torch.zeros(B * M, 16, dtype=F32, device=dev)
+    tmp = torch.zeros(B, M, C, dtype=BF16, device=dev)
+    ops.run([ops.groupnorm(xd, g.to(dev), b.to(dev), tmp, ws, M=M, C=C, groups=8, act=1, images=B),
+             ops.conv2d(tmp, wd, wb.to(dev), y1, H=B * M, W=1, Cin=C, Cout=N, ldo=16)])
+    ops.run(ops.groupnorm_head(xd, g.to(dev), b.to(dev), wd, wb.to(dev), y2, ws, M=M, C=C, groups=8, N=N, ldy=16, act=1, images=B))
+    torch.cuda.synchronize()
+    assert y2[:, N:].abs().max().item() == 0
+    assert_close(y2[:, :N], y1[:, :N], 1e-5, 'fused head vs two launches')
+    assert_close(y2[:, :N], ref.reshape(B * M, N), 1e-2, 'fused head vs torch')
+
+
 def test_grouped_launches(dev):
     """rmem_linear_grouped / rmem_add_bf16_grouped / rmem_layernorm256_pair are bit-identical to the single launches."""
     from rmem_ocu_amd import ops
