@@ -2,30 +2,41 @@
 """bench.py -- frames/s of the MI355X memory-reading VOS engine on BASELINE.json's cfg 2.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
 
-Workload (config.workload = "davis17_480p_r50_N8"): synthetic 480x854 clips of 80 frames at network
-size 481x849 (HW = 1674 tokens), ResNet-50 + 3-layer LSTT + FPN, memory bank N = 8 (1 + 7),
-per-clip gap = max(round(80/30), 5) = 5, 3 objects, bf16 operands / fp32 accumulation.
-A *step* is one propagated frame of one clip: match-propagate + argmax + memory update -- the
-reference's own FPS unit (managers/evaluator.py:399-404, 525-535).  Clips are independent; a GPU is filled by keeping 24 of
-them in flight, as 6 groups of 4 clips that advance in lockstep on one GroupEngine each (one launch per layer for the 4
-clips: rmem_ocu_amd/networks/engines/group_engine.py; --clips-per-group 1 selects the per-clip engines of the drop-in API),
-every group on its own HIP stream with its own hipGraphs.  Ranks never exchange data on the hot path (weak scaling: per-GPU
-work is fixed); the only collectives are the barriers around the timed region and one final gather of (frames, seconds,
-checksum) to rank 0.  Reference frames that fall inside the timed region are executed but not counted as steps.  Inside a
-clip the ResNet-50 encoder runs 2 frames ahead of the LSTT (frames do not depend on each other before the memory read): one
-launch per encoder layer covers 2 frames x 4 clips, every frame is still encoded exactly once (config.encoder_lookahead).
-A group step propagates 4 frames, so the timed region executes ceil(K / 4) * 4 frames while `value` = K / elapsed (never
-over-reports; config.frames_executed_in_timed_region).  Inputs are resident in HBM when the timed region starts.
+N > 1 without WORLD_SIZE in the environment: this process starts N fresh ranks itself (``python -m torch.distributed.run
+--nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...`` as a child, before anything here touches the GPU -- the way the
+reference's tools/eval.py:137-143 spawns one worker per GPU), relays rank 0's JSON line and exits with the child's code.
+Launched by torch.distributed.run (WORLD_SIZE set) it is one rank.
+
+Workload (config.workload = "davis17_480p_r50_N8"): a job of 64 synthetic 480x854 clips per GPU, 80 frames each, at network
+size 481x849 (HW = 1674 tokens), ResNet-50 + 3-layer LSTT + FPN, memory bank N = 8 (1 + 7), per-clip
+gap = max(round(80/30), 5) = 5, 3 objects, bf16 operands / fp32 accumulation.
+A *step* is one propagated frame of one clip: match-propagate + argmax + memory update -- the reference's own FPS unit
+(managers/evaluator.py:399-404, 525-535).  Clips are independent; the job's clip list is handed to the ranks by
+rmem_ocu_amd.clip_runner.ClipFeeder -- a job-wide ticket queue on the process group's TCPStore (the reference's shared
+sequence queue, managers/evaluator.py:276-295) or, with --feeder static, a longest-first split -- and every rank keeps 24
+clips in flight as 6 groups of 4 clips that advance in lockstep on one GroupEngine each (one launch per layer for the 4
+clips; --clips-per-group 1 selects the per-clip engines of the drop-in API), every group on its own HIP stream with its own
+hipGraphs.  Ranks never exchange data on the hot path (weak scaling: per-GPU work is fixed); the only collectives are the
+barriers around the timed region and one final gather of (frames, seconds, checksum) to rank 0.  The timed region is a
+window of K steps per rank out of that job (the list is cyclic, a window never runs dry).  Reference frames that fall
+inside the timed region are executed but not counted as steps.  Inside a clip the ResNet-50 encoder runs 2 frames ahead of
+the LSTT (frames do not depend on each other before the memory read): one launch per encoder layer covers 2 frames x 4
+clips, every frame is still encoded exactly once (config.encoder_lookahead).  A group step propagates 4 frames, so the timed
+region executes ceil(K / 4) * 4 frames while `value` = K / elapsed (never over-reports;
+config.frames_executed_in_timed_region).  Inputs are resident in HBM when the timed region starts.
 
 The single JSON line also carries
-  roofline     -- the dominant kernel (k_attn_partial, the long-term memory read): algorithmic FLOPs
-                  4*HW*(T*HW)*256 per launch / launch duration measured with HIP events on the launch
-                  stream for a 1-in-100 sample of the timed frames.  A sampled frame runs alone on the GPU
-                  as direct launches (events cannot sit inside a replayed graph) and its kernels use the
-                  symbol k_attn_partial<true, true>, so `rocprofv3 --kernel-trace --stats` of the same command
-                  reports exactly these launches under that name; peak = 2.5 PFLOP/s dense bf16.
+  roofline     -- the dominant kernel (the long-term memory read, rmem_mem_read_attn_clips): AFTER the timed region (so
+                  it cannot perturb `value`, and independent of --steps) the layer-0 memory read of one group is
+                  launched --roofline-launches times (default 32) at bank size T = 8 (the steady state of the
+                  clip) alone on the GPU, directly (events cannot sit inside a replayed graph), each launch bracketed by
+                  HIP events on the launch stream.  achieved = algorithmic FLOPs 4*HW*(T*HW)*256 per clip-launch /
+                  mean launch duration; these launches use the symbol k_attn_partial<true, true>, so `rocprofv3
+                  --kernel-trace --stats` of the same command reports exactly them under that name; peak = 2.5 PFLOP/s
+                  dense bf16.  `t_mix` says which bank sizes were timed.  `traffic` (HBM bytes per launch from separate
+                  rocprofv3 --pmc passes) is only reported while the committed PMC summary was measured on the attention.hip that is
+                  built now (sha256 match), else null.
   cpu_baseline -- oracle/ref_cpu.py (fp32 port of the reference path) timed on this host's cores on a
                   bounded sample of the same workload (rank 0, N = 1 only).
 """
@@ -33,8 +44,11 @@ from __future__ import annotations
 
 import argparse
 import ctypes
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -43,21 +57,20 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-CLIP_LEN = 80
-VIDEO_HW = (480, 854)
-NUM_OBJS = 3
 PEAK_BF16_TFLOPS = 2500.0
 # --workload: the default is BASELINE.json's cfg 2 (the line the driver records); the others are extra measurements
 WORKLOADS = {
-    'davis17_480p_r50_N8': dict(model='r50_aotl', video=(480, 854), clip=80, objs=3, former=1, latter=7, net=None),
-    # cfg 5 geometry: 720p, Swin-B, bank N = 12 (1 + 11), align_corners False -> network size = video size (multiple of 16)
+    'davis17_480p_r50_N8': dict(model='r50_aotl', video=(480, 854), lengths=(80,), clips_per_gpu=64, objs=3, former=1, latter=7, net=None),
     # the model the reference's shipped eval_vost.sh runs: R50-DeAOTL, bank 1 + 8 (configs/models/r50_deaotl.py:8-9), cfg-2 geometry
-    'davis17_480p_r50deaot_N9': dict(model='r50_deaotl', video=(480, 854), clip=80, objs=3, former=1, latter=8, net=None),
-    'lvos_720p_swinb_N12': dict(model='swinb_aotl', video=(720, 1280), clip=150, objs=2, former=1, latter=11, net=(720, 1280)),
+    'davis17_480p_r50deaot_N9': dict(model='r50_deaotl', video=(480, 854), lengths=(80,), clips_per_gpu=64, objs=3, former=1, latter=8, net=None),
+    # cfg 5 geometry: 720p, Swin-B, bank N = 12 (1 + 11), align_corners False -> network size = video size (multiple of 16)
+    'lvos_720p_swinb_N12': dict(model='swinb_aotl', video=(720, 1280), lengths=(150,), clips_per_gpu=4, objs=2, former=1, latter=11, net=(720, 1280)),
+    # cfg 2 geometry with a skewed clip list (mixed lengths): exercises the feeder's length buckets and queue
+    'davis17_480p_r50_N8_mixed': dict(model='r50_aotl', video=(480, 854), lengths=(100, 80, 60, 40), clips_per_gpu=64, objs=3, former=1, latter=7, net=None),
 }
 
 
-def cpu_baseline(frames, mask, n_timed=8):
+def cpu_baseline(frames, mask, video_hw, n_timed=8):
     """Oracle (CPU port of the reference path) on a bounded sample: bank filled to N = 8 with gap 1 over 8
     untimed frames, then n_timed propagated frames at T = 8 are timed (propagate + update)."""
     from oracle import ref_cpu as O
@@ -72,7 +85,7 @@ def cpu_baseline(frames, mask, n_timed=8):
         for i in range(1, 9 + n_timed):
             if i == 9:
                 t0 = time.time()
-            logit = eng.match_propogate_one_frame(frames[i:i + 1], VIDEO_HW)
+            logit = eng.match_propogate_one_frame(frames[i:i + 1], video_hw)
             label = torch.argmax(torch.softmax(logit, 1), 1, keepdim=True).float()
             eng.update_memory(F.interpolate(label, size=eng.input_size_2d, mode='nearest'))
         dt = time.time() - t0
@@ -80,21 +93,46 @@ def cpu_baseline(frames, mask, n_timed=8):
             'sample': f'{n_timed} propagated frames at 481x849, bank T=8 (steady state of the 80-frame clip), fp32, after 9 untimed frames'}
 
 
+def attention_source_sha256() -> str:
+    with open(os.path.join(ROOT, 'rmem_ocu_amd', 'csrc', 'attention.hip'), 'rb') as f:
+        return hashlib.sha256(f.read()).hexdigest()
+
+
 def pmc_traffic(clips_per_launch=1):
-    """HBM bytes per T = 8 launch of the memory-read kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
-    WRITE_SIZE in separate runs, gfx950 FETCH correction applied): profiles/r01/attn_pmc.json (one clip per launch) or
-    attn_pmc_group4.json (4 clips per launch).  bench.py cannot collect counters itself; the figure is per launch like `achieved`."""
+    """HBM bytes per T = 8 launch of the memory-read kernel from the newest committed PMC summary (rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE in separate passes, gfx950 FETCH correction applied; bench.py cannot collect counters itself).  A summary is
+    only valid for the kernel source it was measured on: it names attention.hip's sha256, and anything else gives None."""
     name = {1: 'attn_pmc.json', 4: 'attn_pmc_group4.json'}.get(clips_per_launch)
     if name is None:
-        return None
-    try:
-        with open(os.path.join(ROOT, 'profiles', 'r01', name)) as f:
-            return json.load(f)['hbm_bytes_per_launch']
-    except Exception:
-        return None
+        return None, None
+    sha = attention_source_sha256()
+    for rnd in sorted((d for d in os.listdir(os.path.join(ROOT, 'profiles')) if d.startswith('r')), reverse=True):
+        try:
+            with open(os.path.join(ROOT, 'profiles', rnd, name)) as f:
+                j = json.load(f)
+        except Exception:
+            continue
+        if j.get('attention_hip_sha256') == sha:
+            return j['hbm_bytes_per_launch'], f'profiles/{rnd}/{name}'
+        return None, f'profiles/{rnd}/{name} was measured on another attention.hip (stale)'
+    return None, None
 
 
-def main():
+def self_launch(n: int) -> int:
+    """--gpus N > 1 from a plain `python bench.py`: N fresh ranks as children of THIS process, which has not touched the GPU
+    (never exec from a process that has).  stdout / stderr are inherited, so rank 0's JSON line is this command's output."""
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=790)
@@ -109,14 +147,22 @@ def main():
                     help='PCIe-inclusive variant (not the contract line): frames start as decoded uint8 RGB in pinned host memory')
     ap.add_argument('--encoder-lookahead', type=int, default=int(os.environ.get('RMEM_ENC_LOOKAHEAD', 0)),
                     help='frames the ResNet-50 encoder runs ahead inside a clip (one launch per layer for all of them)')
-    ap.add_argument('--sample-every', type=int, default=100, help='time the memory-read kernel on 1 in N timed frames (run in isolation)')
-    args = ap.parse_args()
+    ap.add_argument('--feeder', default=None, choices=['queue', 'static'],
+                    help='how the clip list reaches the ranks: job-wide ticket queue (default for N > 1) or static longest-first split')
+    ap.add_argument('--roofline-launches', type=int, default=32, help='isolated T = 8 memory-read launches timed after the timed region')
+    return ap.parse_args(argv)
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        raise SystemExit(self_launch(args.gpus))
 
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     if world != args.gpus:
-        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}')
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: there is no CPU execution path for the product')
     ndev = torch.cuda.device_count()
@@ -135,13 +181,12 @@ def main():
             dist.init_process_group(backend)
 
     from rmem_ocu_amd import _lib, build_engine, build_vos_model, get_config
-    from rmem_ocu_amd.clip_runner import ClipSlot
+    from rmem_ocu_amd.clip_runner import ClipFeeder, ClipSlot, pump
     from rmem_ocu_amd.synth import make_clip, network_size
     from rmem_ocu_amd.weights import synth_state_dict
 
-    global CLIP_LEN, VIDEO_HW, NUM_OBJS
     wl = WORKLOADS[args.workload]
-    CLIP_LEN, VIDEO_HW, NUM_OBJS = wl['clip'], wl['video'], wl['objs']
+    VIDEO_HW, NUM_OBJS = wl['video'], wl['objs']
     cfg = get_config('pre_vost', 'bench', wl['model'])
     cfg.FORMER_MEM_LEN, cfg.LATTER_MEM_LEN = wl['former'], wl['latter']
     model = build_vos_model(cfg.MODEL_VOS, cfg).cuda(local_rank)
@@ -149,8 +194,17 @@ def main():
     model.load_state_dict(synth_state_dict(0, encoder=cfg.MODEL_ENCODER, model='deaot' if deaot else 'aot'))
     net_hw = wl['net'] or network_size(*VIDEO_HW)
 
-    # two distinct synthetic clips per rank, reused round-robin by the clip slots
-    clips_host = [make_clip(1000 * rank + j, CLIP_LEN, net_hw[0], net_hw[1], NUM_OBJS) for j in range(2)]
+    C = max(1, args.clips_in_flight)
+    G = args.clips_per_group if wl['model'] == 'r50_aotl' else 1
+    # ---- the job: clips_per_gpu * world clips, lengths cycling through wl['lengths'] (whole groups per length) ----
+    per_len = max(G, (wl['clips_per_gpu'] * world // len(wl['lengths'])) // G * G)
+    lengths = [n for n in wl['lengths'] for _ in range(per_len)]
+    feeder = ClipFeeder(lengths, rank, world, group=G, mode=args.feeder, cyclic=True)
+    max_len = max(lengths)
+
+    # clip CONTENT: two distinct synthetic clips per rank at the longest length (a clip id maps to one of them, truncated to
+    # its own length): an 80-frame fp32 clip is 392 MB on the device, the clip list itself is only ids and lengths
+    clips_host = [make_clip(1000 * rank + j, max_len, net_hw[0], net_hw[1], NUM_OBJS) for j in range(2)]
     if args.host_frames:
         # decoded video frames as a loader would hand them over: uint8 RGB [n, Hs, Ws, 3] at the VIDEO size in pinned memory;
         # every frame crosses PCIe (1.2 MB) and is resized + normalised on the device (rmem_ingest_rgb8)
@@ -163,8 +217,10 @@ def main():
     else:
         clips = [(f.to(dev), m.to(dev)) for f, m in clips_host]
 
-    C = max(1, args.clips_in_flight)
-    G = args.clips_per_group if wl['model'] == 'r50_aotl' else 1
+    def clip_data(cid):
+        f, m = clips[cid % 2]
+        return f[:lengths[cid]], m
+
     # frames the encoder runs ahead (0 = default: 2 with clip groups -- 8 images per launch --, 4 for single clips)
     lookahead = (args.encoder_lookahead or (2 if G > 1 else 4)) if cfg.MODEL_ENCODER == 'resnet50' else 1
     slots = []
@@ -177,108 +233,127 @@ def main():
             eng.use_graphs = not args.no_graphs
             slots.append(GroupSlot(eng, VIDEO_HW, dev))
         inner_of = lambda s: s.engine                                            # noqa: E731
-        start = lambda s, k: s.start([clips[(k + c) % 2][0] for c in range(G)], [clips[(k + c) % 2][1] for c in range(G)], NUM_OBJS)  # noqa: E731
+
+        def start(s):
+            ids = feeder.next_unit()
+            data = [clip_data(i) for i in ids]
+            s.start([d[0] for d in data], [d[1] for d in data], NUM_OBJS)
     else:
         for j in range(C):
             eng = build_engine(cfg.MODEL_ENGINE, phase='eval', aot_model=model, gpu_id=local_rank, long_term_mem_gap=5)
             eng.set_async(use_graphs=not args.no_graphs)
             slots.append(ClipSlot(eng, VIDEO_HW, dev, lookahead=lookahead))
         inner_of = lambda s: s.engine.aot_engines[0]                             # noqa: E731
-        start = lambda s, k: s.start(*clips[k % 2], NUM_OBJS)                    # noqa: E731
+
+        def start(s):
+            s.start(*clip_data(feeder.next_unit()[0]), NUM_OBJS)
 
     # ---- priming (untimed setup): every slot runs one whole clip, interleaved exactly like the timed region, which builds
     # every launch list / hipGraph (T = 1..8); then the slots are staggered so they sit at different clip positions ----
-    for j, s in enumerate(slots):
-        start(s, j)
+    for s in slots:
+        start(s)
     while not all(s.done for s in slots):
         for s in slots:
             if not s.done:
                 s.step()
-    for j, s in enumerate(slots):
-        start(s, j)
-    for k in range(CLIP_LEN - 1):
+    for s in slots:
+        start(s)
+    n0 = min(lengths)
+    for k in range(n0 - 1):
         for j, s in enumerate(slots):
-            if k < (j * (CLIP_LEN - 1)) // C:
+            if k < (j * (n0 - 1)) // C and not s.done:
                 s.step()
     torch.cuda.synchronize()
 
-    next_clip = [0]
-
-    def run_steps(n, sample_every=0):
-        """n propagated frames in total (a group step propagates G frames)."""
-        done = 0
-        j = 0
-        while done < n:
-            s = slots[j % C]
-            j += 1
-            if s.done:
-                next_clip[0] += 1
-                start(s, next_clip[0])      # reference frame(s): executed, not counted
-            inner = inner_of(s)
-            eager = sample_every and (done % sample_every) < G and done >= sample_every // 2
-            if eager:
-                # roofline sample: this frame runs alone on the GPU as direct launches, its memory-read kernels bracketed by
-                # HIP events (symbol k_attn_partial<true, true>), so the event time is the kernel's own duration
-                torch.cuda.synchronize()
-                inner.use_graphs = False
-            s.step()
-            if eager:
-                inner.use_graphs = not args.no_graphs
-                inner.stream.synchronize()
-            done += G
+    def run_steps(n):
+        """n propagated frames in total (a group step propagates G frames); a finished slot takes the job's next unit."""
+        pump(slots, start, n, G)
 
     run_steps(args.warmup)
     torch.cuda.synchronize()
 
-    L = _lib.lib()
-    _lib.check(L.rmem_profile_start(4 * (args.steps // max(1, args.sample_every) + 4)), 'rmem_profile_start')
-    if deaot:
-        _lib.check(L.rmem_gated_profile_start(), 'rmem_gated_profile_start')
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    run_steps(args.steps, args.sample_every)
+    run_steps(args.steps)
     host_enqueue = time.perf_counter() - t0
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    ms, fl, nl = ctypes.c_double(), ctypes.c_double(), ctypes.c_int()
-    _lib.check(L.rmem_profile_stop(ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(nl)), 'rmem_profile_stop')
-    if deaot:       # the dominant kernel of this workload is the value-side GEMM of the long-term gated attention
-        _lib.check(L.rmem_gated_profile_stop(ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(nl)), 'rmem_gated_profile_stop')
 
     checksum = float(sum(int(s.labels.sum().item()) for s in slots))
     from rmem_ocu_amd.clip_runner import gather_stats
     gdev = dev if (dist is None or dist.get_backend() == 'nccl') else torch.device('cpu')
     agg = gather_stats(float(args.steps), elapsed, checksum, dist, rank, world, gdev)   # the one data exchange: 24 bytes per rank
-    if rank == 0:
-        total_steps, elapsed, _ = agg
+
+    # ---- roofline leg, after (and outside) the timed region: isolated launches of the dominant kernel under HIP events ----
+    L = _lib.lib()
+    roof = {'achieved': None, 'frac': None, 'launches_timed': 0, 'avg_launch_us': None, 't_mix': {}}
+    if rank == 0 and args.roofline_launches > 0:
+        inner = inner_of(slots[0])
+        inner.stream.synchronize()
+        torch.cuda.synchronize()
+        s_int = inner.stream.cuda_stream
+        ms, fl, nl = ctypes.c_double(), ctypes.c_double(), ctypes.c_int()
+        if deaot:       # the dominant kernel of this workload is the value-side GEMM of the long-term gated attention
+            T = wl['former'] + wl['latter']
+            op, _ = inner.rt.mem_read_probe(T)
+            for _ in range(3):
+                op(s_int)
+            inner.stream.synchronize()
+            _lib.check(L.rmem_gated_profile_start(), 'rmem_gated_profile_start')
+            for _ in range(args.roofline_launches):
+                op(s_int)
+                inner.stream.synchronize()
+            _lib.check(L.rmem_gated_profile_stop(ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(nl)), 'rmem_gated_profile_stop')
+        else:
+            T = wl['former'] + wl['latter']
+            op, _ = inner.rt.mem_read_probe(T)
+            for _ in range(3):              # untimed: instruction cache, TLB
+                op(s_int)
+            inner.stream.synchronize()
+            _lib.check(L.rmem_profile_start(args.roofline_launches + 4), 'rmem_profile_start')
+            for _ in range(args.roofline_launches):
+                op(s_int)
+                inner.stream.synchronize()      # alone on the GPU: the event bracket is the kernel's own duration
+            _lib.check(L.rmem_profile_stop(ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(nl)), 'rmem_profile_stop')
+        if nl.value and ms.value > 0:
+            ach = (fl.value / (ms.value * 1e-3)) / 1e12
+            roof = {'achieved': round(ach, 2), 'frac': round(ach / PEAK_BF16_TFLOPS, 4), 'launches_timed': nl.value,
+                    'avg_launch_us': round(1e3 * ms.value / nl.value, 2), 't_mix': {str(T): nl.value}}
 
     if rank == 0:
-        achieved = (fl.value / (ms.value * 1e-3)) / 1e12 if nl.value and ms.value > 0 else None
+        total_steps, elapsed, _ = agg
+        traffic, traffic_src = pmc_traffic(G) if args.workload.startswith('davis17_480p_r50_N8') else (None, None)
+        L16 = (net_hw[0] // 16 if wl['net'] else (net_hw[0] - 1) // 16 + 1) * (net_hw[1] // 16 if wl['net'] else (net_hw[1] - 1) // 16 + 1)
         out = {
             'metric': 'frames/sec (whole node) 480p VOS, N=8 memory bank' if args.workload == 'davis17_480p_r50_N8'
             else f'frames/sec (whole node) {args.workload}', 'value': round(total_steps / elapsed, 2), 'unit': 'frames/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * elapsed / args.steps, 4),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
-            'config': {'workload': args.workload, 'clip_frames': CLIP_LEN, 'video_hw': list(VIDEO_HW), 'network_hw': list(net_hw),
-                       'tokens': (net_hw[0] // 16 if wl['net'] else 31) * (net_hw[1] // 16 if wl['net'] else 54), 'objects': NUM_OBJS,
-                       'memory_bank': f"{wl['former']}+{wl['latter']}", 'gap': max(int(round(CLIP_LEN / 30)), 5), 'clips_in_flight_per_gpu': C * G, 'clips_per_group': G, 'frames_executed_in_timed_region': -(-args.steps // G) * G,
+            'config': {'workload': args.workload, 'clip_frames': list(wl['lengths']) if len(wl['lengths']) > 1 else wl['lengths'][0],
+                       'job_clips': len(lengths), 'clip_feeder': feeder.mode, 'video_hw': list(VIDEO_HW), 'network_hw': list(net_hw),
+                       'tokens': L16, 'objects': NUM_OBJS,
+                       'memory_bank': f"{wl['former']}+{wl['latter']}", 'gap': [max(int(round(n / 30)), 5) for n in wl['lengths']][0],
+                       'clips_in_flight_per_gpu': C * G, 'clips_per_group': G, 'frames_executed_in_timed_region': -(-args.steps // G) * G,
                        'parallelism': f'clip-parallel x{world}', 'weights': 'synthetic (no checkpoint offline)',
-                       'hipgraphs': not args.no_graphs, 'frames_from': 'pinned host uint8 (PCIe-inclusive)' if args.host_frames else 'HBM', 'encoder_lookahead': lookahead, 'host_enqueue_ms_per_step': round(1e3 * host_enqueue / args.steps, 4)},
-            'roofline': {'bound': 'mfma', 'kernel': 'k_gp_pv<1, true>' if deaot else 'k_attn_partial<true, true>', 'achieved': None if achieved is None else round(achieved, 2),
-                         'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': None if achieved is None else round(achieved / PEAK_BF16_TFLOPS, 4),
-                         'traffic': pmc_traffic(G) if args.workload == 'davis17_480p_r50_N8' else None, 'launches_timed': nl.value,
-                         'avg_launch_us': None if not nl.value else round(1e3 * ms.value / nl.value, 2)},
+                       'hipgraphs': not args.no_graphs, 'frames_from': 'pinned host uint8 (PCIe-inclusive)' if args.host_frames else 'HBM',
+                       'encoder_lookahead': lookahead, 'host_enqueue_ms_per_step': round(1e3 * host_enqueue / args.steps, 4)},
+            'roofline': {'bound': 'mfma', 'kernel': 'k_gp_pv<1, true>' if deaot else 'k_attn_partial<true, true>',
+                         'achieved': roof['achieved'], 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': roof['frac'],
+                         'traffic': traffic, 'traffic_source': traffic_src, 'launches_timed': roof['launches_timed'],
+                         'avg_launch_us': roof['avg_launch_us'], 't_mix': roof['t_mix'],
+                         'clips_per_launch': G, 'sampled': 'after the timed region, isolated direct launches'},
         }
         if world == 1 and not args.no_cpu_baseline and args.workload == 'davis17_480p_r50_N8':
-            out['cpu_baseline'] = cpu_baseline(*clips_host[0])
+            out['cpu_baseline'] = cpu_baseline(*clips_host[0], VIDEO_HW)
         else:
             out['cpu_baseline'] = None
         print(json.dumps(out), flush=True)
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -10,8 +10,9 @@
  *   - `stream` is a hipStream_t passed as void*; calls only enqueue work and never
  *     synchronise, so a caller may wrap any sequence of them in a hipGraph capture;
  *   - return value: 0 on success, negative on error (rmem_last_error_string() says why);
- *     no exception crosses the boundary; no global mutable state except the
- *     thread-local error string;
+ *     no exception crosses the boundary; the only global mutable state is the
+ *     thread-local error string and the opt-in launch timers (rmem_profile_* /
+ *     rmem_gated_profile_*: process-wide, mutex-protected, off unless started);
  *   - "bf16" = IEEE bfloat16 stored as uint16; feature maps are NHWC with N = 1, which
  *     for the LSTT is the same memory as the reference's [L, B=1, C] token layout;
  *   - leading dimensions (ld*) are in elements.

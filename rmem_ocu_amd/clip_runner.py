@@ -33,6 +33,91 @@ def shard_clips(num_clips: int, rank: int, world: int, lengths: Optional[Sequenc
     return mine
 
 
+def group_units(lengths: Sequence[int], group: int) -> List[List[int]]:
+    """Work units of a clip list for engines that advance ``group`` clips in lockstep: clips of EQUAL length (equal length
+    => equal gap, managers/evaluator.py:330-335) are bundled ``group`` at a time, longest first; a length whose clip count is
+    not a multiple of ``group`` leaves one shorter unit (run by a smaller group or the per-clip engine)."""
+    by_len = {}
+    for i, n in enumerate(lengths):
+        by_len.setdefault(int(n), []).append(i)
+    units = []
+    for n in sorted(by_len, reverse=True):
+        ids = by_len[n]
+        units += [ids[k:k + group] for k in range(0, len(ids), group)]
+    return units
+
+
+class ClipFeeder:
+    """Hands the work units of a job's clip list to this rank -- the counterpart of the reference's sequence queue
+    (tools/eval.py:137-143 spawns one worker per GPU; managers/evaluator.py:276-295 has every worker pop sequences from one
+    shared mp.Queue until it is empty).  No data-path collective is involved in either mode:
+
+      'queue'  (default for world > 1) a job-wide ticket counter on the process group's TCPStore (``store.add``): whichever
+               rank has a free slot takes the next unit, longest first, so a slow rank or a skewed list costs at most one unit
+               of tail (host-side work stealing; one ~50 us store round trip per CLIP, never per frame);
+      'static' the longest-first greedy split of ``shard_clips`` computed identically on every rank (no store traffic).
+
+    ``cyclic``: after the last unit the list starts over (bench.py measures a fixed-length window of a long job)."""
+
+    def __init__(self, lengths: Sequence[int], rank: int = 0, world: int = 1, group: int = 1, mode: Optional[str] = None,
+                 store=None, cyclic: bool = False, key: str = 'rmem_clip_queue'):
+        self.lengths = [int(n) for n in lengths]
+        self.units = group_units(self.lengths, group)
+        self.rank, self.world, self.cyclic, self.key = rank, world, cyclic, key
+        self.mode = mode or ('queue' if world > 1 else 'static')
+        if self.mode not in ('queue', 'static'):
+            raise ValueError(f'ClipFeeder mode {self.mode!r}: expected "queue" or "static"')
+        if self.mode == 'queue' and world > 1:
+            if store is None:
+                import torch.distributed as dist
+                store = dist.distributed_c10d._get_default_store()
+            self.store = store
+        else:
+            self.store = None
+        unit_len = [self.lengths[u[0]] * len(u) for u in self.units]
+        self._mine = shard_clips(len(self.units), rank, world, unit_len)      # static order (also the world == 1 order)
+        self._taken = 0
+        self.history: List[int] = []         # unit indexes this rank ran, in order
+
+    def next_unit(self) -> Optional[List[int]]:
+        """Clip ids of the next unit for this rank, or None when the list is drained."""
+        n = len(self.units)
+        if self.store is not None:
+            t = int(self.store.add(self.key, 1)) - 1                  # job-wide ticket
+            if t >= n and not self.cyclic:
+                return None
+            u = t % n
+        else:
+            if not self._mine or (self._taken >= len(self._mine) and not self.cyclic):
+                return None
+            u = self._mine[self._taken % len(self._mine)]
+            self._taken += 1
+        self.history.append(u)
+        return self.units[u]
+
+
+def pump(slots: Sequence, start_fn, steps: int, frames_per_step: int = 1) -> int:
+    """Advance the slots round-robin until ``steps`` propagated frames have been enqueued (one slot step = ``frames_per_step``
+    frames: the clips of a group move together).  A slot whose clip has ended takes the next unit of the job through
+    ``start_fn(slot)`` (reference frames: executed, not counted); start_fn returns False when the list is drained, the slot then
+    idles.  Returns the frames actually enqueued (< steps only if every slot ran dry).  Host-side only: nothing here waits for
+    the GPU."""
+    done, j, idle = 0, 0, 0
+    n = len(slots)
+    while done < steps and idle < n:
+        s = slots[j % n]
+        j += 1
+        if s.done and start_fn(s) is False:
+            idle += 1
+            continue
+        if s.done:                      # a unit of single-frame clips: nothing to propagate
+            continue
+        idle = 0
+        s.step()
+        done += frames_per_step
+    return done
+
+
 def gather_stats(frames: float, seconds: float, checksum: float, dist, rank: int, world: int, device):
     """The one exchange of the clip-parallel design (reference: info_queue, managers/evaluator.py:589-613):
     every rank sends (frames, seconds, checksum) to rank 0, which returns (sum frames, max seconds, sum checksum)."""
@@ -82,6 +167,10 @@ class ClipSlot:
                 self._first = torch.empty(1, 3, H, W, dtype=torch.float32, device=self.device)
             self._net_hw = (H, W)
             cur = torch.cuda.current_stream(self.device)
+            # the engine's own stream may still be running the previous clip's last frames, which read _stage / _first:
+            # order this clip's first-frame copy + ingest behind them (a device-side wait, no host stall)
+            for e in eng.aot_engines + getattr(eng, '_pool', []):
+                cur.wait_stream(e.stream)
             ops.copy_async(self._stage[0], frames[0], hs * ws * 3)(cur.cuda_stream)
             ops.run(ops.ingest_rgb8(self._stage[0], Hs=hs, Ws=ws, Hd=H, Wd=W, out_chw=self._first[0]), cur.cuda_stream)
             cur.synchronize()        # once per clip: the engine works on its own stream

@@ -7,16 +7,18 @@
 //               mass side output (transformer.py:636-643);
 //   short-term and self attention : one key frame, no temporal embedding.
 //
-// Decomposition (flash-decoding style): grid = (query tiles of 128) x heads x key
-// chunks.  A chunk is a contiguous key range of ONE memory frame, described by a
-// device-resident table so a captured hipGraph stays valid while the bank's slot
-// table changes.  Every workgroup produces an unnormalised partial O plus (m, l);
-// k_attn_combine merges the chunks, normalises, writes bf16 O and the mass matrix.
+// Decomposition: grid = (query tiles of 128) x heads x key GROUPS x clips.  The keys are described by a
+// device-resident table of ROWS (a row = a contiguous key range of ONE memory frame: slot, range, temporal-PE
+// slot), so a captured hipGraph stays valid while the bank's slot table changes.  A workgroup walks a GROUP of
+// consecutive rows (several memory frames when enough workgroups exist without splitting further) and keeps ONE
+// running (m_ref, l, O) for all of them; at every row end it records that row's (m_ref, l_row) pair, from which
+// k_attn_mass derives the per-memory-frame probability mass (transformer.py:636-643) without ever materialising
+// the attention matrix.  With one group the normalised bf16 output is written by this kernel itself; with several,
+// each group leaves an unnormalised fp32 partial + (m, l) and k_attn_combine merges them.
 //
-// Per workgroup: 4 waves x 32 query rows.  K/V tiles of 64 keys go global ->
-// registers -> LDS (double buffered); K stays row-major [key][32] with an XOR chunk
-// swizzle (conflict-free ds_read_b128), V is transposed on the way in to [d][key]
-// so the PV A-fragment is two ds_read_b64.
+// Per workgroup: 4 waves x 32 query rows.  K/V tiles of 64 keys go global -> registers -> LDS (double buffered, one
+// barrier per tile, prefetch runs across row boundaries); K stays row-major [key][32] with an XOR chunk swizzle
+// (conflict-free ds_read_b128), V row-major and read TRANSPOSED (ds_read_b64_tr_b16).
 //   S^T = K . Q^T   : v_mfma_f32_32x32x16_bf16, A = K rows (keys), B = Q^T held in
 //                     registers for the whole kernel; the query sits on the lane,
 //                     so row max / row sum are in-lane plus one exchange with lane^32.
@@ -25,9 +27,21 @@
 //                     registers 8s..8s+7 of lane half h are keys 16s+8(j>>2)+4h+(j&3),
 //                     and the V^T A-fragment is read in that same key order.
 // Logits live in the log2 domain: Q is pre-scaled by log2(e)/sqrt(32).
+//
+// Softmax reference.  With d = 32 the VALU (one v_exp_f32 per score) is the limiter, so the loop carries no per-score
+// work besides exp2 + bf16 packing: the reference m_ref and the temporal-PE bias are the C operand of the first QK MFMA
+// (S' = S - m_ref comes out of the matrix pipe), row sums come from a ones-A-operand MFMA on the same P fragments, and
+// the FAST pass fixes m_ref = the maximum of the group's FIRST tile and never looks at a maximum again: floating point
+// keeps the relative precision of P = 2^(S - m_ref), O and l whatever the offset, so a later, larger score is harmless
+// until 2^(S - m_ref) leaves the fp32 range.  That case is detected after the walk (l above 2^64, inf or NaN for any
+// query of the workgroup) and the whole group is redone by the SAFE pass, the classic online softmax (tile maximum,
+// m_ref moved and O / l rescaled whenever a tile exceeds it by 2^8).  Both passes give the same result to fp32 rounding;
+// tests force the fallback with a key 2^100 above the first tile.
 #include "common.h"
 #include "../../include/rmem.h"
+#include <atomic>
 #include <mutex>
+#include <type_traits>
 #include <vector>
 
 namespace {
@@ -35,7 +49,8 @@ namespace {
 constexpr int D = 32;          // head dim
 constexpr int KT = 64;         // keys per LDS tile
 constexpr float NEG_BIG = -1.0e30f;
-constexpr float RESCALE_THR = 8.0f;   // log2 units: P <= 2^8 between rescales (bf16 keeps 8 significant bits at any scale)
+constexpr float RESCALE_THR = 8.0f;          // SAFE pass, log2 units: P <= 2^8 between rescales
+constexpr float L_LIMIT = 1.8446744e19f;     // 2^64: a fast-pass row sum above it (or inf / NaN) sends the group to the SAFE pass
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
@@ -46,12 +61,16 @@ struct AttnParams {
   const rmem_attn_chunk* chunks; int nchunks; int lk; int per_chunk;
   const float* pe_cur; const float* pe_mem;
   int Lq, heads, C, nq;
-  float* opart; float* ml;
+  int ngroups, rpg;               // key groups per (query tile, head); table rows per group
+  float* opart; float* mlg;       // per group: unnormalised partial O, (m_ref, l)      (ngroups > 1)
+  float* ml;                      // per table row: (m_ref at the row's end, l_row)     (mass output wanted), or null
   float qscale;
-  bf16* direct_out; int ldo;      // one chunk only: normalised bf16 output straight from this kernel (no combine launch)
-  // several clips in one launch (identical shapes; clip c's operands sit c * stride further, its chunk rows at c * nchunks)
-  int nclips; long q_cs, kv_cs, out_cs, opart_cs, ml_cs;
+  bf16* out; int ldo;             // normalised bf16 output (written here when ngroups == 1)
+  // several clips in one launch (identical shapes; clip c's operands sit c * stride further, its table rows at c * nchunks)
+  int nclips; long q_cs, kv_cs, out_cs, opart_cs, mlg_cs, ml_cs;
 };
+
+struct Row { int slot, kb, kn, pe_slot; };
 
 __device__ __forceinline__ int kswz(int row, int chunk) { return row * D + ((chunk ^ ((row >> 2) & 3)) << 3); }
 
@@ -61,15 +80,63 @@ __device__ __forceinline__ float pair_max(float x) {
   return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 
-// MEM = true: memory-read flavour (chunk table, temporal PE); false: one plain key frame.  Two symbols so a
-// kernel trace separates the long-term memory read from the short-term / self attention launches.
-//
-// Softmax bookkeeping is "lazy": the running reference m_ref (not the true max) is folded into the MFMA
-// accumulator's initial value together with the temporal-PE bias, so S' = S - m_ref comes out of the matrix
-// pipe and P = exp2(S') needs no subtraction.  Only when a tile's maximum exceeds m_ref by more than
-// RESCALE_THR (or on the first tile) is m_ref moved and O / l rescaled -- a wave-uniform, rare branch.
-// The row sums l come from the matrix pipe too (a ones A-operand against the same P^T fragments), which
-// leaves max + exp2 + bf16 packing as the only per-score VALU work (the d = 32 bottleneck).
+// buffer-descriptor LDS-DMA (buffer_load_dwordx4 ... offen lds): global -> LDS without VGPR staging; a lane whose offset
+// lies beyond the descriptor's byte count gets zeros from the hardware range check (the ragged tail of a row needs no
+// per-lane test).  The descriptor type and the builtins exist only in the device pass; the host pass needs the names.
+typedef __attribute__((address_space(3))) void* lptr_t;
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const void* base, int bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ void buf_load_lds16(rsrc_t r, lptr_t dst, int voff, int soff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, dst, 16, voff, soff, 0, 0);
+}
+#else
+struct rsrc_t {};
+__device__ inline rsrc_t make_rsrc(const void*, int) { return {}; }
+__device__ inline void buf_load_lds16(rsrc_t, lptr_t, int, int) {}
+#endif
+
+// LDS reads of the tile loop as inline asm with counted waits: the compiler cannot tell that the LDS-DMA in flight (next tile,
+// OTHER buffer) does not alias the tile being read and would drain it (s_waitcnt vmcnt(0)) in front of the first ds_read of
+// every tile, which serialises the prefetch with the arithmetic.  LDS operations return in order, so lgkmcnt(N) = "all but
+// the N youngest have landed"; the fragments pass through the wait so that their consumers stay behind it.
+#ifdef RMEM_ATTN_C_LDS
+template <int OFF>
+__device__ __forceinline__ bf16x8 lds_b128(unsigned addr) {
+  return *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>((size_t)(addr + OFF));
+}
+template <int OFF>
+__device__ __forceinline__ s16x4 lds_tr16(unsigned addr) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(size_t)(addr + OFF));
+}
+#else
+template <int OFF>
+__device__ __forceinline__ bf16x8 lds_b128(unsigned addr) {
+  bf16x8 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+template <int OFF>
+__device__ __forceinline__ s16x4 lds_tr16(unsigned addr) {
+  s16x4 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+#endif
+template <int N>
+__device__ __forceinline__ void lds_wait4(bf16x8& a, bf16x8& b, bf16x8& c, bf16x8& d) {
+  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N));
+}
+struct PvFrag { s16x4 lo[2], hi[2]; bf16x8 ones[2]; };      // one 32-key block: V^T fragments and row-sum operands of its 2 slabs
+template <int N>
+__device__ __forceinline__ void lds_wait_pv(PvFrag& f) {
+  asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(f.lo[0]), "+v"(f.hi[0]), "+v"(f.lo[1]), "+v"(f.hi[1]), "+v"(f.ones[0]), "+v"(f.ones[1]) : "n"(N));
+}
+
+// MEM = true: memory-read flavour (row table, temporal PE); false: one plain key frame cut into nchunks ranges.  Two
+// symbols so a kernel trace separates the long-term memory read from the short-term / self attention launches.
 // TIMED changes nothing but the symbol: launches bracketed by rmem_profile_* HIP events use the <true, true> instance, so
 // a kernel trace of the same run lists exactly the launches bench.py timed under their own name.
 template <bool MEM, bool TIMED = false>
@@ -77,15 +144,21 @@ __global__ __launch_bounds__(256) void k_attn_partial(AttnParams pin) {
   AttnParams p = pin;
   __shared__ __attribute__((aligned(16))) bf16 Ks[2][KT * D];   // [key][32], 16-byte chunks XOR-swizzled
   __shared__ __attribute__((aligned(16))) bf16 Vs[2][KT * D];   // [key][32] row-major, read transposed (ds_read_b64_tr_b16)
+  // 1.0 / 0.0 per key of the tile: the A operand of the row-sum MFMA.  A row's ragged last tile (HW = 1674 = 26 * 64 + 10) is
+  // padded with K = V = 0 keys (the DMA's range check); they add nothing to O, and reading the "ones" from here keeps them
+  // out of l without a single per-score select (masking S instead costs 90 VALU instructions per tile once the compiler
+  // if-converts it)
+  __shared__ __attribute__((aligned(16))) bf16 Ones[2][KT];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // provably wave-uniform: LDS-DMA destinations stay in SGPRs
   const int lq = lane & 31, lh = lane >> 5;
   // XCD-aware decode of the 1-D grid: hardware deals consecutive block ids round-robin over the 8 XCDs (private 4 MiB
-  // L2 each), so ids that are congruent mod 8 are made to walk (head, chunk) pairs contiguously -- all query tiles that
-  // read the same K/V chunk run on one XCD and share its L2 (speed only; any placement is correct).
-  int qt, head, c;
+  // L2 each), so ids that are congruent mod 8 are made to walk (head, group) pairs contiguously -- all query tiles that
+  // read the same K/V rows run on one XCD and share its L2 (speed only; any placement is correct).
+  int qt, head, g;
   {
-    const int nq = p.nq, total = nq * p.heads * p.nchunks * p.nclips;
+    const int nq = p.nq, total = nq * p.heads * p.ngroups * p.nclips;
     const int b = blockIdx.x, xcd = b & 7, j = b >> 3;
     const int qd = total >> 3, rm = total & 7;
     const int idx = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + j;
@@ -93,203 +166,308 @@ __global__ __launch_bounds__(256) void k_attn_partial(AttnParams pin) {
     qt = idx - pair * nq;
     head = pair % p.heads;
     const int rest = pair / p.heads;
-    c = rest % p.nchunks;
-    const int clip = rest / p.nchunks;
+    g = rest % p.ngroups;
+    const int clip = rest / p.ngroups;
     p.q += clip * p.q_cs;
     if (!MEM) { p.k += clip * p.kv_cs; p.v += clip * p.kv_cs; }
     else p.chunks += clip * p.nchunks;          // bank slots in the table are global (clip * slots + slot)
     p.opart += clip * p.opart_cs;
-    p.ml += clip * p.ml_cs;
-    if (p.direct_out) p.direct_out += clip * p.out_cs;
+    p.mlg += clip * p.mlg_cs;
+    if (p.ml) p.ml += clip * p.ml_cs;
+    p.out += clip * p.out_cs;
   }
+  const int c0 = g * p.rpg, c1 = min(c0 + p.rpg, p.nchunks);
 
-  int slot, kb, kn, pe_slot;
-  if (MEM) {
-    const rmem_attn_chunk ch = p.chunks[c];
-    slot = ch.slot; kb = ch.key_begin; kn = ch.key_count; pe_slot = ch.pe_slot;
-  } else {
-    slot = 0; kb = c * p.per_chunk; kn = min(p.per_chunk, p.lk - kb); pe_slot = -1;
-  }
-  const bf16* Kp = p.k + (long)slot * p.slot_stride + head * D;
-  const bf16* Vp = p.v + (long)slot * p.slot_stride + head * D;
+  auto row_info = [&](int c) -> Row {
+    Row r;
+    if (MEM) {
+      // the table row is the same for the whole workgroup; say so (the row's descriptors must live in SGPRs, otherwise every
+      // DMA is wrapped in a waterfall loop)
+      const rmem_attn_chunk ch = p.chunks[c];
+      r.slot = __builtin_amdgcn_readfirstlane(ch.slot); r.kb = __builtin_amdgcn_readfirstlane(ch.key_begin);
+      r.kn = __builtin_amdgcn_readfirstlane(ch.key_count); r.pe_slot = __builtin_amdgcn_readfirstlane(ch.pe_slot);
+    } else {
+      r.slot = 0; r.kb = c * p.per_chunk; r.kn = min(p.per_chunk, p.lk - r.kb); r.pe_slot = -1;
+    }
+    return r;
+  };
 
-  // ---- Q^T fragment (B operand) and the temporal-PE logit bias ----
+  // ---- Q^T fragment (B operand), pre-scaled, with the current-frame temporal PE added ----
   const int qrow = min(qt * 128 + wave * 32 + lq, p.Lq - 1);
   bf16x8 qf[2];
-  float bias = 0.f;
   const bool has_cur = MEM && p.pe_cur != nullptr;        // workgroup-uniform
-  const bool has_mem = MEM && pe_slot >= 0 && p.pe_mem != nullptr;
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
     const int d0 = head * D + 16 * s + 8 * lh;
     const bf16x8 raw = *reinterpret_cast<const bf16x8*>(p.q + (long)qrow * p.ldq + d0);
-    f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0, m0 = c0, m1 = c0;
-    if (has_cur) { c0 = *reinterpret_cast<const f32x4*>(p.pe_cur + d0); c1 = *reinterpret_cast<const f32x4*>(p.pe_cur + d0 + 4); }
-    if (has_mem) {
-      const float* pm = p.pe_mem + pe_slot * p.C + d0;
-      m0 = *reinterpret_cast<const f32x4*>(pm); m1 = *reinterpret_cast<const f32x4*>(pm + 4);
-    }
+    f32x4 c0v = {0.f, 0.f, 0.f, 0.f}, c1v = c0v;
+    if (has_cur) { c0v = *reinterpret_cast<const f32x4*>(p.pe_cur + d0); c1v = *reinterpret_cast<const f32x4*>(p.pe_cur + d0 + 4); }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float f = (float)raw[j] + (j < 4 ? c0[j & 3] : c1[j & 3]);
-      const bf16 b = (bf16)(f * p.qscale);
-      qf[s][j] = b;
-      bias += (float)b * (j < 4 ? m0[j & 3] : m1[j & 3]);
-    }
+    for (int j = 0; j < 8; ++j) qf[s][j] = (bf16)(((float)raw[j] + (j < 4 ? c0v[j & 3] : c1v[j & 3])) * p.qscale);
   }
-  bias += __shfl_xor(bias, 32, 64);
-
-  // ---- staging state: thread -> (key, 16-byte chunk of the head's 64-byte row) ----
-  const int skey = tid >> 2, schunk = tid & 3;
-  bf16x8 rk, rv;
-  const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-  auto load_tile = [&](int t) {
-    const int kidx = t * KT + skey;
-    rk = zero8; rv = zero8;
-    if (kidx < kn) {
-      const long off = (long)(kb + kidx) * p.ldkv + schunk * 8;
-      rk = *reinterpret_cast<const bf16x8*>(Kp + off);
-      rv = *reinterpret_cast<const bf16x8*>(Vp + off);
+  // logit bias of a row: q' . pe_mem[pe_slot] (the reference adds pe_mem to the keys, transformer.py:594-626)
+  auto row_bias = [&](int pe_slot) -> float {
+    float bias = 0.f;
+    if (MEM && pe_slot >= 0 && p.pe_mem != nullptr) {     // workgroup-uniform
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const float* pm = p.pe_mem + pe_slot * p.C + head * D + 16 * s + 8 * lh;
+        const f32x4 m0 = *reinterpret_cast<const f32x4*>(pm), m1 = *reinterpret_cast<const f32x4*>(pm + 4);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bias += (float)qf[s][j] * (j < 4 ? m0[j & 3] : m1[j & 3]);
+      }
+      bias += __shfl_xor(bias, 32, 64);
     }
+    return bias;
   };
-  auto store_tile = [&](int buf) {
-    *reinterpret_cast<bf16x8*>(&Ks[buf][kswz(skey, schunk)]) = rk;
-    *reinterpret_cast<bf16x8*>(&Vs[buf][skey * D + schunk * 8]) = rv;
+
+  // ---- staging: a wave-instruction moves 16 keys x 64 B (this head's slice of K or V) straight into LDS.  Lane ->
+  // (key = 16 * wave + lane / 4, LDS position lane % 4); the K tile's XOR swizzle is applied to the SOURCE chunk. ----
+  const int skey = 16 * wave + (lane >> 2), spos = lane & 3;
+  const int voff_k = (skey * p.ldkv + ((spos ^ ((skey >> 2) & 3)) << 3)) * 2;
+  const int voff_v = (skey * p.ldkv + (spos << 3)) * 2;
+  // Ones[] is kept in the k-order of the P^T fragment (see the header: k = 8h + j of a 16-key slab is key 8(j>>2) + 4h + (j&3)),
+  // so that one 16-byte read per (block, slab, lane half) is the row-sum MFMA's A operand
+  const int sones = (skey & ~15) | (((skey >> 2) & 1) << 3) | (((skey >> 3) & 1) << 2) | (skey & 3);
+  const int tile_elems = KT * p.ldkv;
+  const bf16* row_k = nullptr;                  // first key of the open row at this head's columns (wave-uniform)
+  const bf16* row_v = nullptr;
+  int row_bytes = 0, row_kn = 0;
+  auto open_row = [&](const Row& r) {
+    const long off = (long)r.slot * p.slot_stride + (long)r.kb * p.ldkv + head * D;
+    row_k = p.k + off; row_v = p.v + off;
+    row_bytes = ((r.kn - 1) * p.ldkv + D) * 2;  // up to the end of the last key's slice
+    row_kn = r.kn;
+  };
+  // tile t of the open row -> LDS buffer buf (asynchronous: s_waitcnt vmcnt before use).  The descriptor is rebuilt per tile
+  // (scalar work) so that it starts at the tile and ends with the row: the hardware range check covers the per-lane offset
+  // only (not soffset), and this way a lane beyond the row's last key is out of range by its own offset and reads zeros.
+  auto dma_tile = [&](int t, int buf) {
+    const int left = row_bytes - t * tile_elems * 2;
+    // (the plain LDS store goes first: behind a DMA the compiler would wait for the DMA before it)
+    if (spos == 0) Ones[buf][sones] = (bf16)(t * KT + skey < row_kn ? 1.0f : 0.0f);
+    buf_load_lds16(make_rsrc(row_k + (long)t * tile_elems, left), (lptr_t)&Ks[buf][wave * 16 * D], voff_k, 0);
+    buf_load_lds16(make_rsrc(row_v + (long)t * tile_elems, left), (lptr_t)&Vs[buf][wave * 16 * D], voff_v, 0);
   };
 
   // transposed-read addressing of the V tile: 16-lane group g reads a 4-key x 16-d block; lane 4q+p of the group
   // supplies the address of key row q, d columns 4p..4p+3 and receives d column (lane & 15), keys 0..3
   const int tr_off = ((4 * lh + ((lane & 15) >> 2)) * D) + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
-
-  const bf16 one = (bf16)1.0f;
-  const bf16x8 ones = {one, one, one, one, one, one, one, one};
-  f32x16 oacc, lacc;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) { oacc[r] = 0.f; lacc[r] = 0.f; }
-  float m_ref = 0.f;
-  // bias - m_ref replicated over the 16 accumulator registers; it is the C operand of the first S^T MFMA of
-  // every block and is only rewritten on a rescale, so no per-tile register fill is needed (D != C)
-  f32x16 cinit;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) cinit[r] = bias;
+  // LDS byte addresses of this lane's fragments in buffer 0 (buffer and block are instruction offsets)
+  const unsigned k_addr[2] = {(unsigned)(size_t)(lptr_t)&Ks[0][kswz(lq, lh)], (unsigned)(size_t)(lptr_t)&Ks[0][kswz(lq, 2 + lh)]};
+  const unsigned v_addr = (unsigned)(size_t)(lptr_t)&Vs[0][tr_off];
+  const unsigned o_addr = (unsigned)(size_t)(lptr_t)&Ones[0][8 * lh];
 
   // HW = 1674 = 13 * 128 + 10: in the last query tile only wave 0 owns real rows.  The other waves still stage K/V and meet
-  // the barriers, but skip the softmax / MFMA work (the kernel is VALU-bound: 3 of 56 wave-tiles per (head, chunk) saved).
+  // the barriers, but skip the softmax / MFMA work (3 of 56 wave-tiles per (head, group) saved).
   const bool wave_active = qt * 128 + wave * 32 < p.Lq;
-  const int ntiles = (kn + KT - 1) / KT;
-  load_tile(0);
-  store_tile(0);
-  __syncthreads();
-  if (!wave_active) {            // staging-only twin of the main loop: same loads, stores and barriers, no arithmetic
-    for (int t = 0; t < ntiles; ++t) {
-      if (t + 1 < ntiles) { load_tile(t + 1); store_tile((t & 1) ^ 1); }
-      __syncthreads();
-    }
-    return;
-  }
-
-  for (int t = 0; t < ntiles; ++t) {
-    const int cur = t & 1;
-    if (t + 1 < ntiles) load_tile(t + 1);
-
-    // S'^T = K . Q^T + (bias - m_ref) for the two 32-key blocks of this tile
-    asm volatile("" : "+v"(cinit));          // keep it a live register block (do not rematerialise per tile)
-    f32x16 sacc[2];
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(&Ks[cur][kswz(b * 32 + lq, lh)]);
-      const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(&Ks[cur][kswz(b * 32 + lq, 2 + lh)]);
-      sacc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, qf[0], cinit, 0, 0, 0);
-      sacc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, qf[1], sacc[b], 0, 0, 0);
-    }
-    if (t == ntiles - 1 && (kn & (KT - 1))) {
-      const int base = t * KT + 4 * lh;
-#pragma unroll
-      for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          if (base + b * 32 + (r & 3) + 8 * (r >> 2) >= kn) sacc[b][r] = NEG_BIG;
-    }
-
-    // tile maximum per query (the other 16 keys of each block sit in lane ^ 32)
-    float tmax = fmaxf(sacc[0][0], sacc[1][0]);
-#pragma unroll
-    for (int r = 1; r < 16; ++r) tmax = fmaxf(fmaxf(tmax, sacc[0][r]), sacc[1][r]);   // v_max3_f32
-    tmax = pair_max(tmax);
-    const bool need = (t == 0) || (tmax > RESCALE_THR);
-    if (__any(need)) {                       // rare after the first tile: move the reference, rescale O and l
-      const float delta = need ? tmax : 0.f;
-      m_ref += delta;
-      const float sc = __builtin_amdgcn_exp2f(-delta);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { oacc[r] *= sc; lacc[r] *= sc; cinit[r] -= delta; }
-#pragma unroll
-      for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sacc[b][r] -= delta;
-    }
-    bf16x8 pb[2][2];
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) pb[b][r >> 3][r & 7] = (bf16)__builtin_amdgcn_exp2f(sacc[b][r]);
-
-    // O^T += V^T . P^T and l += 1^T . P^T (same B fragments)
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        const bf16* vb = &Vs[cur][(b * 32 + 16 * s) * D + tr_off];
-        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)vb);
-        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vb + 8 * D));
-        const __attribute__((ext_vector_type(8))) short a16 = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        const bf16x8 a = __builtin_bit_cast(bf16x8, a16);
-        oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pb[b][s], oacc, 0, 0, 0);
-        lacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pb[b][s], lacc, 0, 0, 0);
-      }
-
-    if (t + 1 < ntiles) store_tile(cur ^ 1);
-    __syncthreads();
-  }
-
   const int qg = qt * 128 + wave * 32 + lq;
-  if (p.direct_out) {
-    if (qg < p.Lq) {
-      const float inv = 1.f / lacc[0];
-      bf16* o = p.direct_out + (long)qg * p.ldo + head * D + 4 * lh;
+
+  f32x16 oacc;
+  float m_ref, ltot;
+
+  // One pass over the group's rows.  SAFE = false: m_ref is the first tile's maximum and stays; true: online softmax.
+  auto walk = [&](auto safe_tag) {
+    constexpr bool SAFE = decltype(safe_tag)::value;
+    f32x16 lacc, cinit;
 #pragma unroll
-      for (int g = 0; g < 4; ++g)    // C/D rows (r&3) + 8(r>>2) + 4h -> d = 8g + 4h + (0..3)
-        *reinterpret_cast<bf16x4*>(o + 8 * g) = bf16x4{(bf16)(oacc[4 * g] * inv), (bf16)(oacc[4 * g + 1] * inv),
-                                                       (bf16)(oacc[4 * g + 2] * inv), (bf16)(oacc[4 * g + 3] * inv)};
+    for (int r = 0; r < 16; ++r) { oacc[r] = 0.f; lacc[r] = 0.f; }
+    m_ref = 0.f; ltot = 0.f;
+    int c = c0;
+    Row cur = row_info(c);
+    int ntiles = (cur.kn + KT - 1) / KT, t = 0;
+    {
+      // (bias - m_ref) replicated over the 16 accumulator registers: the C operand of the first S^T MFMA of every
+      // block, rewritten only at a row boundary or a rescale, so no per-tile register fill is needed (D != C)
+      const float bias = wave_active ? row_bias(cur.pe_slot) : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) cinit[r] = bias;
+    }
+    open_row(cur);
+    dma_tile(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // One 64-key tile out of LDS buffer BUF.  MAXMODE 0: no maximum at all (FAST pass after its first tile); 1: the group's
+    // first tile (m_ref := tile maximum, nothing accumulated yet); 2: SAFE pass (move m_ref and rescale when a tile exceeds
+    // it by 2^8).  The FAST steady state must not carry any of the extras: predicated off they are if-converted into ~60
+    // subtractions / maxima per tile, which is exactly the VALU work this kernel cannot afford -- hence one copy per
+    // MAXMODE.  Padded keys of a ragged tile score S' = bias - m_ref (K = 0): a finite P that meets V = 0 and a 0 in the
+    // row-sum operand.
+    auto tile = [&](auto mode_tag, auto buf_tag) {
+      constexpr int MAXMODE = decltype(mode_tag)::value;
+      constexpr int BUF = decltype(buf_tag)::value;
+      // S'^T = K . Q^T + (bias - m_ref) for the two 32-key blocks of this tile
+      constexpr int KB = BUF * KT * D * 2, VB = BUF * KT * D * 2, OB = BUF * KT * 2;      // byte offsets of the buffer
+      bf16x8 ka[2][2];
+      ka[0][0] = lds_b128<KB>(k_addr[0]);
+      ka[0][1] = lds_b128<KB>(k_addr[1]);
+      ka[1][0] = lds_b128<KB + 32 * D * 2>(k_addr[0]);
+      ka[1][1] = lds_b128<KB + 32 * D * 2>(k_addr[1]);
+      lds_wait4<0>(ka[0][0], ka[0][1], ka[1][0], ka[1][1]);
+      f32x16 sacc[2];
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        // D != C spelled out in the steady state: left to the compiler, one of the two blocks is computed in place on a
+        // 16-register COPY of cinit (8 v_mov_b64 per tile).  An MFMA inside inline asm is invisible to the compiler's hazard
+        // recogniser, so it is used ONLY where nothing near it can be a hazard: in the steady-state tile cinit was last
+        // written before the previous barrier (a VALU write of SrcC directly in front of the MFMA needs wait states -- the
+        // first tile, whose cinit is a fresh constant, read stale registers through this path), and the marker below keeps
+        // the operands allocated until both asm MFMAs have started (the matrix pipe reads SrcC when the instruction executes).
+        if (MAXMODE == 0) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(sacc[b]) : "v"(ka[b][0]), "v"(qf[0]), "v"(cinit));
+        else sacc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[b][0], qf[0], cinit, 0, 0, 0);
+        sacc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[b][1], qf[1], sacc[b], 0, 0, 0);
+      }
+      if (MAXMODE == 0) asm volatile("" : "+v"(sacc[1]) : "v"(cinit), "v"(ka[0][0]), "v"(ka[1][0]), "v"(qf[0]));
+      // the 6 reads of one 32-key block's V^T fragments and row-sum operands; issued one block ahead of their use, so that
+      // their latency sits under the exponentials (and at most one block's fragments are live)
+      PvFrag pv;
+      auto read_pv = [&](auto blk_tag) {
+        constexpr int B = decltype(blk_tag)::value;
+        pv.lo[0] = lds_tr16<VB + (B * 32) * D * 2>(v_addr);
+        pv.hi[0] = lds_tr16<VB + (B * 32 + 8) * D * 2>(v_addr);
+        pv.ones[0] = lds_b128<OB + (B * 32) * 2>(o_addr);
+        pv.lo[1] = lds_tr16<VB + (B * 32 + 16) * D * 2>(v_addr);
+        pv.hi[1] = lds_tr16<VB + (B * 32 + 24) * D * 2>(v_addr);
+        pv.ones[1] = lds_b128<OB + (B * 32 + 16) * 2>(o_addr);
+      };
+      read_pv(std::integral_constant<int, 0>{});
+      if (MAXMODE != 0) {
+        // tile maximum per query (the other 16 keys of each block sit in lane ^ 32)
+        float tmax = fmaxf(sacc[0][0], sacc[1][0]);
+#pragma unroll
+        for (int r = 1; r < 16; ++r) tmax = fmaxf(fmaxf(tmax, sacc[0][r]), sacc[1][r]);   // v_max3_f32
+        tmax = pair_max(tmax);
+        if (MAXMODE == 1) {
+          m_ref = tmax;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) cinit[r] -= tmax;
+#pragma unroll
+          for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc[b][r] -= tmax;
+        } else {
+          const bool need = tmax > RESCALE_THR;
+          if (__any(need)) {                     // rare: move the reference, rescale O and l
+            const float delta = need ? tmax : 0.f;
+            m_ref += delta;
+            const float sc = __builtin_amdgcn_exp2f(-delta);
+            ltot *= sc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { oacc[r] *= sc; lacc[r] *= sc; cinit[r] -= delta; }
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) sacc[b][r] -= delta;
+          }
+        }
+      }
+      // P = exp2(S'), packed to bf16: the B operand of O^T += V^T . P^T and l += 1^T . P^T (same fragments)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        bf16x8 pb[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) pb[r >> 3][r & 7] = (bf16)__builtin_amdgcn_exp2f(sacc[b][r]);
+        lds_wait_pv<0>(pv);
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) {
+          const __attribute__((ext_vector_type(8))) short a16 = {pv.lo[sl][0], pv.lo[sl][1], pv.lo[sl][2], pv.lo[sl][3],
+                                                                 pv.hi[sl][0], pv.hi[sl][1], pv.hi[sl][2], pv.hi[sl][3]};
+          const bf16x8 a = __builtin_bit_cast(bf16x8, a16);
+          oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pb[sl], oacc, 0, 0, 0);
+          lacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pv.ones[sl], pb[sl], lacc, 0, 0, 0);
+        }
+        if (b == 0) read_pv(std::integral_constant<int, 1>{});
+      }
+    };
+
+    // One loop step on LDS buffer BUF: start the DMA of the next tile (possibly the next row's first) into the other buffer,
+    // compute this tile, close the row if it ends here, then wait for the DMA and meet the barrier that publishes it.
+    // Returns true after the group's last tile.
+    auto step = [&](auto mode_tag, auto buf_tag) -> bool {
+      constexpr int BUF = decltype(buf_tag)::value;
+      const bool last_in_row = t + 1 >= ntiles;
+      const bool last = last_in_row && c + 1 >= c1;
+      Row nxt = cur;
+      if (last_in_row && !last) { nxt = row_info(c + 1); open_row(nxt); }
+      if (!last) dma_tile(last_in_row ? 0 : t + 1, BUF ^ 1);
+      if (wave_active) tile(mode_tag, buf_tag);
+      if (last_in_row) {
+        if (wave_active) {
+          // the row's own (reference, sum): all the mass output needs; the running total keeps the group's normaliser
+          if (p.ml != nullptr && lh == 0 && qg < p.Lq)
+            *reinterpret_cast<f32x2*>(p.ml + (((long)c * p.heads + head) * p.Lq + qg) * 2) = f32x2{m_ref, lacc[0]};
+          ltot += lacc[0];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) lacc[r] = 0.f;
+        }
+        if (last) return true;
+        ++c; cur = nxt; t = 0;
+        ntiles = (cur.kn + KT - 1) / KT;
+        if (wave_active) {
+          const float bias = row_bias(cur.pe_slot) - m_ref;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) cinit[r] = bias;
+        }
+      } else {
+        ++t;
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      return false;
+    };
+    constexpr int STEADY = SAFE ? 2 : 0;
+    using B0 = std::integral_constant<int, 0>;
+    using B1 = std::integral_constant<int, 1>;
+    if (step(std::integral_constant<int, 1>{}, B0{})) return;
+    for (;;) {                                   // two steps per trip: the LDS buffer index is a compile-time constant
+      if (step(std::integral_constant<int, STEADY>{}, B1{})) return;
+      if (step(std::integral_constant<int, STEADY>{}, B0{})) return;
+    }
+  };
+
+  walk(std::false_type{});
+  // any query of the workgroup whose sums left the safe range sends the whole group through the online-softmax pass
+  // (the vote is also the barrier that frees the LDS tiles for it)
+  if (__syncthreads_or(wave_active && !(ltot <= L_LIMIT))) walk(std::true_type{});
+  if (!wave_active) return;
+
+  if (p.ngroups == 1) {
+    if (qg < p.Lq) {
+      const float inv = 1.f / ltot;
+      bf16* o = p.out + (long)qg * p.ldo + head * D + 4 * lh;
+#pragma unroll
+      for (int gg = 0; gg < 4; ++gg)    // C/D rows (r&3) + 8(r>>2) + 4h -> d = 8g + 4h + (0..3)
+        *reinterpret_cast<bf16x4*>(o + 8 * gg) = bf16x4{(bf16)(oacc[4 * gg] * inv), (bf16)(oacc[4 * gg + 1] * inv),
+                                                        (bf16)(oacc[4 * gg + 2] * inv), (bf16)(oacc[4 * gg + 3] * inv)};
     }
     return;
   }
   if (qg < p.Lq) {
-    // partial O layout [chunk][head][G = d / 4][q] x float4: a half-wave stores 512 contiguous bytes per instruction
-    const long ch = (long)c * p.heads + head;
+    // partial O layout [group][head][G = d / 4][q] x float4: a half-wave stores 512 contiguous bytes per instruction
+    const long ch = (long)g * p.heads + head;
     f32x4* o = reinterpret_cast<f32x4*>(p.opart) + ch * 8 * p.Lq + qg;
 #pragma unroll
-    for (int g = 0; g < 4; ++g)  // C/D rows (r&3) + 8(r>>2) + 4h  ->  d = 8g + 4h + (0..3)  ->  G = 2g + h
-      o[(long)(2 * g + lh) * p.Lq] = f32x4{oacc[4 * g], oacc[4 * g + 1], oacc[4 * g + 2], oacc[4 * g + 3]};
-    if (lh == 0) *reinterpret_cast<f32x2*>(p.ml + (ch * p.Lq + qg) * 2) = f32x2{m_ref, lacc[0]};
+    for (int gg = 0; gg < 4; ++gg)  // C/D rows (r&3) + 8(r>>2) + 4h  ->  d = 8g + 4h + (0..3)  ->  G = 2g + h
+      o[(long)(2 * gg + lh) * p.Lq] = f32x4{oacc[4 * gg], oacc[4 * gg + 1], oacc[4 * gg + 2], oacc[4 * gg + 3]};
+    if (lh == 0) *reinterpret_cast<f32x2*>(p.mlg + (ch * p.Lq + qg) * 2) = f32x2{m_ref, ltot};
   }
 }
 
 struct CombineParams {
-  const float* opart; const float* ml;
-  const rmem_attn_chunk* chunks; int nchunks;
+  const float* opart; const float* mlg; int ngroups;      // per key group: partial O, (m, l)
+  const float* ml; const rmem_attn_chunk* chunks; int nchunks;   // per table row: (m, l_row) -> mass
   int Lq, heads;
   bf16* out; int ldo;
   float* mass; int T;
-  long out_cs, opart_cs, ml_cs, mass_cs;     // per-clip strides (blockIdx.z = clip)
+  long out_cs, opart_cs, mlg_cs, ml_cs, mass_cs;     // per-clip strides (blockIdx.z = clip)
 };
 
-// merge the key chunks.  grid = (query blocks of 64, 16); thread = (query, head, 4 channels): consecutive lanes
-// read consecutive queries of the [chunk][head][G][q] partial layout.  Blocks with blockIdx.y == 0 also
-// reduce the per-chunk (m, l) pairs to the per-memory-frame probability mass (mean over heads).
+// merge the key groups.  grid = (query blocks of 64, 16, clips); thread = (query, head, 4 channels): consecutive lanes
+// read consecutive queries of the [group][head][G][q] partial layout.
 __global__ __launch_bounds__(256) void k_attn_combine(CombineParams pin) {
   CombineParams p = pin;
-  p.opart += blockIdx.z * p.opart_cs; p.ml += blockIdx.z * p.ml_cs; p.out += blockIdx.z * p.out_cs;
+  p.opart += blockIdx.z * p.opart_cs; p.mlg += blockIdx.z * p.mlg_cs; p.out += blockIdx.z * p.out_cs;
   const int tid = threadIdx.x;
   const int ql = tid & 63;
   const int q = blockIdx.x * 64 + ql;
@@ -300,12 +478,12 @@ __global__ __launch_bounds__(256) void k_attn_combine(CombineParams pin) {
   if (head < p.heads) {
     const f32x4* op = reinterpret_cast<const f32x4*>(p.opart);
     float m = NEG_BIG;
-    for (int c = 0; c < p.nchunks; ++c) m = fmaxf(m, p.ml[(((long)c * p.heads + head) * p.Lq + qc) * 2]);
+    for (int c = 0; c < p.ngroups; ++c) m = fmaxf(m, p.mlg[(((long)c * p.heads + head) * p.Lq + qc) * 2]);
     f32x4 num = {0.f, 0.f, 0.f, 0.f};
     float den = 0.f;
-    for (int c = 0; c < p.nchunks; ++c) {
+    for (int c = 0; c < p.ngroups; ++c) {
       const long ch = (long)c * p.heads + head;
-      const f32x2 mlv = *reinterpret_cast<const f32x2*>(p.ml + (ch * p.Lq + qc) * 2);
+      const f32x2 mlv = *reinterpret_cast<const f32x2*>(p.mlg + (ch * p.Lq + qc) * 2);
       const float w = __builtin_amdgcn_exp2f(mlv[0] - m);
       den += w * mlv[1];
       num += op[(ch * 8 + G) * p.Lq + qc] * w;
@@ -317,7 +495,7 @@ __global__ __launch_bounds__(256) void k_attn_combine(CombineParams pin) {
   }
 }
 
-// per-memory-frame probability mass from the per-chunk (m, l) pairs: mass[q][t] = mean_h sum_{c in t} w_c l_c / den_h.
+// per-memory-frame probability mass from the per-row (m, l) pairs: mass[q][t] = mean_h sum_{rows of t} w_r l_r / den_h.
 // thread = (query, head pair); 64 queries per block
 __global__ __launch_bounds__(256) void k_attn_mass(CombineParams pin) {
   CombineParams p = pin;
@@ -356,7 +534,7 @@ __global__ void k_prof_nop() {}
 
 struct ProfState {
   std::mutex mu;
-  bool on = false;
+  std::atomic<bool> on{false};   // read by every memory-read launch without the lock; everything else under mu
   float bracket_ms = 0.f;       // HIP-event bracket cost around an empty kernel (calibrated in rmem_profile_start)
   std::vector<hipEvent_t> ev;   // pairs
   std::vector<double> flops;
@@ -394,13 +572,13 @@ extern "C" int rmem_profile_start(int max_launches) {
       g_prof.bracket_ms = best < 1e8f ? best : 0.f;
     }
   }
-  g_prof.on = true;
+  g_prof.on.store(true);
   return 0;
 }
 
 extern "C" int rmem_profile_stop(double* total_ms, double* total_flops, int* launches) {
   std::lock_guard<std::mutex> lk(g_prof.mu);
-  g_prof.on = false;
+  g_prof.on.store(false);
   double ms = 0.0, fl = 0.0;
   for (size_t i = 0; i < g_prof.used; ++i) {
     float t = 0.f;
@@ -418,7 +596,16 @@ extern "C" int rmem_profile_stop(double* total_ms, double* total_flops, int* lau
 }
 
 extern "C" size_t rmem_attn_workspace_bytes(int Lq, int heads, int nchunks) {
-  return (size_t)nchunks * heads * Lq * (D + 2) * sizeof(float);
+  // worst case one group per table row: partial O (D floats) + group (m, l) + row (m, l) per (row, head, query)
+  return (size_t)nchunks * heads * Lq * (D + 4) * sizeof(float);
+}
+
+// workgroups a launch should have before several table rows are walked by one workgroup (7 per CU; experiments:
+// RMEM_ATTN_WGS).  Fewer, longer workgroups write fewer fp32 partials (none at all with one group).
+static int attn_target_wgs() {
+  const char* e = getenv("RMEM_ATTN_WGS");        // read per call (not inside graph replays): tests force 1 group / 1 row per group
+  const int x = e ? atoi(e) : 0;
+  return x > 0 ? x : 1792;
 }
 
 extern "C" int rmem_mem_read_attn_clips(const void* q, int ldq, const void* k_bank, const void* v_bank, long long slot_stride,
@@ -428,7 +615,7 @@ extern "C" int rmem_mem_read_attn_clips(const void* q, int ldq, const void* k_ba
                                         long long out_clip_stride, void* workspace, void* stream) {
   RMEM_REQUIRE(nclips >= 1 && nclips <= 64, "rmem_mem_read_attn: 1..64 clips");
   RMEM_REQUIRE(q_clip_stride % 8 == 0 && kv_clip_stride % 8 == 0 && out_clip_stride % 8 == 0, "rmem_mem_read_attn: clip strides must be multiples of 8 elements");
-  const long long prof_keys = chunks ? (long long)lk_single : 0;   // with a chunk table lk_single carries the total key count (timing only)
+  const long long prof_keys = chunks ? (long long)lk_single : 0;   // with a row table lk_single carries the total key count (timing only)
   RMEM_REQUIRE(q && k_bank && v_bank && out && workspace, "rmem_mem_read_attn: null argument");
   RMEM_REQUIRE(heads >= 1 && heads <= 8, "rmem_mem_read_attn: heads must be in 1..8 (head dim is fixed at 32)");
   RMEM_REQUIRE(Lq > 0 && nchunks >= 1 && nchunks <= 32, "rmem_mem_read_attn: need Lq > 0 and 1 <= nchunks <= 32");
@@ -446,24 +633,32 @@ extern "C" int rmem_mem_read_attn_clips(const void* q, int ldq, const void* k_ba
   RMEM_REQUIRE(chunks || (long)p.per_chunk * (nchunks - 1) < lk_single, "rmem_mem_read_attn: too many chunks for lk_single");
   p.pe_cur = pe_cur; p.pe_mem = pe_mem; p.Lq = Lq; p.heads = heads; p.C = heads * D;
   p.nclips = nclips; p.q_cs = q_clip_stride; p.kv_cs = kv_clip_stride; p.out_cs = out_clip_stride;
-  p.opart_cs = (long)nchunks * heads * Lq * D; p.ml_cs = (long)nchunks * heads * Lq * 2;
-  p.opart = (float*)workspace; p.ml = p.opart + (size_t)nclips * p.opart_cs;
   p.qscale = 1.4426950408889634f / sqrtf((float)D);
   p.nq = (Lq + 127) / 128;
-  const bool direct = !chunks && nchunks == 1;          // a single key range: no partials to merge
-  p.direct_out = direct ? (bf16*)out : nullptr;
-  p.ldo = ldo;
-  dim3 grid(p.nq * heads * nchunks * nclips);
+  // rows per workgroup: as many as keep >= attn_target_wgs() workgroups in the launch
+  {
+    const int base = p.nq * heads * nclips;
+    int groups = (attn_target_wgs() + base - 1) / base;
+    groups = groups < 1 ? 1 : (groups > nchunks ? nchunks : groups);
+    p.rpg = (nchunks + groups - 1) / groups;
+    p.ngroups = (nchunks + p.rpg - 1) / p.rpg;
+  }
+  // workspace: [clip][group] partial O | [clip][group] (m, l) | [clip][row] (m, l)
+  p.opart_cs = (long)p.ngroups * heads * Lq * D; p.mlg_cs = (long)p.ngroups * heads * Lq * 2; p.ml_cs = (long)nchunks * heads * Lq * 2;
+  p.opart = (float*)workspace; p.mlg = p.opart + (size_t)nclips * p.opart_cs;
+  p.ml = attn_mass ? p.mlg + (size_t)nclips * p.mlg_cs : nullptr;
+  p.out = (bf16*)out; p.ldo = ldo;
+  dim3 grid(p.nq * heads * p.ngroups * nclips);
   if (chunks) {
     // time this launch if asked to (never while the stream is being captured into a graph)
     long slot_i = -1;
     double keys = 0.0;
-    if (g_prof.on && prof_keys > 0) {
+    if (g_prof.on.load(std::memory_order_relaxed) && prof_keys > 0) {
       hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
       (void)hipStreamIsCapturing(s, &cs);
       if (cs == hipStreamCaptureStatusNone) {
         std::lock_guard<std::mutex> lk(g_prof.mu);
-        if (g_prof.on && g_prof.used * 2 + 1 < g_prof.ev.size()) { slot_i = (long)g_prof.used++; keys = (double)prof_keys; }
+        if (g_prof.on.load() && g_prof.used * 2 + 1 < g_prof.ev.size()) { slot_i = (long)g_prof.used++; keys = (double)prof_keys; }
       }
     }
     if (slot_i >= 0) (void)hipEventRecord(g_prof.ev[2 * slot_i], s);
@@ -476,12 +671,11 @@ extern "C" int rmem_mem_read_attn_clips(const void* q, int ldq, const void* k_ba
   } else {
     hipLaunchKernelGGL((k_attn_partial<false, false>), grid, dim3(256), 0, s, p);
   }
-  if (direct) return rmem_check_launch("rmem_mem_read_attn");
   CombineParams cp;
-  cp.opart = p.opart; cp.ml = p.ml; cp.chunks = chunks; cp.nchunks = nchunks; cp.Lq = Lq; cp.heads = heads;
-  cp.out = (bf16*)out; cp.ldo = ldo; cp.mass = attn_mass; cp.T = T;
-  cp.out_cs = out_clip_stride; cp.opart_cs = p.opart_cs; cp.ml_cs = p.ml_cs; cp.mass_cs = (long)Lq * T;
-  hipLaunchKernelGGL(k_attn_combine, dim3((Lq + 63) / 64, 16, nclips), dim3(256), 0, s, cp);
+  cp.opart = p.opart; cp.mlg = p.mlg; cp.ngroups = p.ngroups; cp.ml = p.ml; cp.chunks = chunks; cp.nchunks = nchunks;
+  cp.Lq = Lq; cp.heads = heads; cp.out = (bf16*)out; cp.ldo = ldo; cp.mass = attn_mass; cp.T = T;
+  cp.out_cs = out_clip_stride; cp.opart_cs = p.opart_cs; cp.mlg_cs = p.mlg_cs; cp.ml_cs = p.ml_cs; cp.mass_cs = (long)Lq * T;
+  if (p.ngroups > 1) hipLaunchKernelGGL(k_attn_combine, dim3((Lq + 63) / 64, 16, nclips), dim3(256), 0, s, cp);
   if (attn_mass) hipLaunchKernelGGL(k_attn_mass, dim3((Lq + 63) / 64, 1, nclips), dim3(256), 0, s, cp);
   return rmem_check_launch("rmem_mem_read_attn");
 }

@@ -94,10 +94,9 @@ class GroupRuntime:
         self.slots: List[List[int]] = [[] for _ in range(B)]            # per clip: logical order t -> local slot
         self.free: List[List[int]] = [list(range(bank_slots)) for _ in range(B)]
         self.chunks = torch.zeros(B * MAX_CHUNKS, 8, dtype=torch.int32, device=device)
-        self.chunks_host = torch.zeros(8, B * MAX_CHUNKS, 8, dtype=torch.int32).pin_memory()
+        self.chunks_ring = ops.PinnedRing(4, (B * MAX_CHUNKS, 8), torch.int32, device)
         self.append_slots = torch.full((B,), -1, dtype=torch.int32, device=device)   # global destination slot per clip
-        self.append_host = torch.zeros(8, B, dtype=torch.int32).pin_memory()
-        self._stage = 0
+        self.append_ring = ops.PinnedRing(4, (B,), torch.int32, device)
         self._prog: Dict[str, list] = {}
 
     # ------------------------------------------------------------------ bank bookkeeping (host) + device tables
@@ -115,30 +114,48 @@ class GroupRuntime:
         splits = max(1, min(8 // T, MAX_CHUNKS // T))
         return splits, T * splits
 
-    def upload_chunks(self, stream: int):
-        """One block of rows per clip for the current (equal) bank size; bank slots are global indexes c * S + local slot."""
-        T = self.T
-        assert all(len(s) == T for s in self.slots)
+    def _chunk_rows(self, slots: List[List[int]]):
+        """Chunk-table rows (global slot, key begin, key count, temporal-PE slot, t) for per-clip slot orders of equal length."""
+        T = len(slots[0])
+        assert all(len(s) == T for s in slots)
         splits, n = self.chunk_plan(T)
         pes = temporal_slots(T)
         per = (self.L + splits - 1) // splits
         rows = []
         for c in range(self.B):
-            for t, s in enumerate(self.slots[c]):
+            for t, s in enumerate(slots[c]):
                 for kb in range(0, self.L, per):
                     rows.append((c * self.S + s, kb, min(per, self.L - kb), pes[t], t))
-        self._stage = (self._stage + 1) % self.chunks_host.shape[0]
-        host = self.chunks_host[self._stage]
+        return rows, n
+
+    def upload_chunks(self, stream: int):
+        """One block of rows per clip for the current (equal) bank size; bank slots are global indexes c * S + local slot."""
+        rows, n = self._chunk_rows(self.slots)
+        host = self.chunks_ring.next()          # waits for the upload that last read this row (normally long done)
         host.zero_()
         host[:len(rows), :5] = torch.tensor(rows, dtype=torch.int32)
-        ops.copy_async(self.chunks, host, self.B * n * 8 * 4)(stream)
+        self.chunks_ring.upload(self.chunks, self.B * n * 8 * 4, stream)
 
     def upload_append_slots(self, local_slots: List[int], stream: int):
-        host = self.append_host[self._stage % self.append_host.shape[0]]
-        self._stage += 1
+        host = self.append_ring.next()
         for c, s in enumerate(local_slots):
             host[c] = c * self.S + s if s >= 0 else -1
-        ops.copy_async(self.append_slots, host, self.B * 4)(stream)
+        self.append_ring.upload(self.append_slots, self.B * 4, stream)
+
+    def mem_read_probe(self, T: int, layer: int = 0):
+        """The long-term memory read of ``layer`` at bank size T as a stand-alone Op over this runtime's own buffers (bench.py's
+        roofline leg): same shapes, chunk plan, kernel and launch as prog_lstt's, but with its own chunk table (bank slots
+        0 .. T-1 of every clip in logical order) so the engine's device state is untouched.  Returns (op, algorithmic FLOPs)."""
+        if not 1 <= T <= self.S:
+            raise ops.RmemError(f'mem_read_probe: T = {T} outside 1..{self.S}')
+        rows, n = self._chunk_rows([list(range(T)) for _ in range(self.B)])
+        table = torch.zeros(self.B * n, 8, dtype=torch.int32)
+        table[:, :5] = torch.tensor(rows, dtype=torch.int32)
+        self._probe_chunks = table.to(self.dev)
+        L, C, i = self.L, D_MODEL, layer
+        op = self._attn(self.curr_Q[i], C, self.bank_K[i], self.bank_V[i], C, self.att, slot_stride=L * C, chunks=self._probe_chunks,
+                        nchunks=n, lk_single=T * L, pe_cur=self.P['pe_cur'], pe_mem=self.P['pe_mem'], mass=None, T=T)
+        return op, 4.0 * L * (T * L) * C * self.B
 
     # ------------------------------------------------------------------ helpers
     def _conv(self, *a, **kw):

@@ -185,7 +185,9 @@ class AOTEngine:
         rt = self._ensure_runtime(img)
         if self.input_size_2d is None:
             self.update_size(img.shape[2:], (rt.H16, rt.W16))
-        self._pending_evict = None
+        # a deferred eviction belongs to the bank that is about to be reset, but its effect on long_memories_indexes
+        # (the reference keeps that list across the reset, aot_engine.py:323) and on the policy state must still happen
+        self._resolve_pending()
         with self._scope():
             self.img_in.copy_(img.reshape(3, rt.H, rt.W), non_blocking=True)
             self._set_label(mask)

@@ -315,6 +315,35 @@ def copy_async(dst, src, nbytes: int) -> Op:
     return Op(_lib.lib().rmem_copy_async, (_ptr(dst), _ptr(src), nbytes), 'rmem_copy_async', (dst, src))
 
 
+class PinnedRing:
+    """Pinned host staging rows for small tables that are re-sent to the device while earlier frames are still queued
+    (bank chunk tables, append-slot tables).  A row is rewritten only after the H2D copy that last read it has EXECUTED:
+    every upload records a HIP event on the launch stream and ``next()`` synchronises that row's event (normally long
+    signalled, so this is free); graph replay enqueues ~10x faster than the GPU runs, so a plain modulo ring would wrap
+    under a queued copy."""
+
+    def __init__(self, rows: int, shape, dtype, device):
+        self.host = torch.zeros(rows, *shape, dtype=dtype).pin_memory()
+        self.events = [None] * rows
+        self.device = device
+        self.i = 0
+
+    def next(self) -> torch.Tensor:
+        self.i = (self.i + 1) % self.host.shape[0]
+        ev = self.events[self.i]
+        if ev is not None:
+            ev.synchronize()
+        return self.host[self.i]
+
+    def upload(self, dst: torch.Tensor, nbytes: int, stream: int):
+        """Enqueue host row -> dst on ``stream`` and remember when it has been read."""
+        copy_async(dst, self.host[self.i], nbytes)(stream)
+        ev = self.events[self.i]
+        if ev is None:
+            ev = self.events[self.i] = torch.cuda.Event()
+        ev.record(torch.cuda.ExternalStream(stream, device=self.device))
+
+
 def scatter_blocks(src, dst, slots, *, nclips, block_bytes, slot_bytes) -> Op:
     """block c of src -> dst + slots[c] * slot_bytes (slots: device int32 table, negative = skip)."""
     _dev(src, dst, slots)

@@ -131,8 +131,7 @@ class ClipRuntime:
         self.logits = torch.zeros(M4, 16, dtype=F32, device=device)
         # ---- memory bank ----
         self.chunks = torch.zeros(self.max_chunks, 8, dtype=torch.int32, device=device)
-        self.chunks_host = torch.zeros(8, self.max_chunks, 8, dtype=torch.int32).pin_memory()
-        self._chunk_stage = 0
+        self.chunks_ring = ops.PinnedRing(4, (self.max_chunks, 8), torch.int32, device)
         self.scores_host = torch.zeros(MAX_CHUNKS, dtype=F32).pin_memory()
         self.bank_generation = 0             # bumped when the bank is re-allocated: launch lists / graphs built on it are stale
         self._alloc_bank(bank_slots)
@@ -210,23 +209,39 @@ class ClipRuntime:
     def _keys_per_chunk(self, splits: int) -> int:
         return (self.L + splits - 1) // splits
 
-    def upload_chunks(self, stream: int):
-        """Write the chunk table for the current slot order (call after every bank change)."""
-        T = len(self.slots)
+    def _chunk_rows(self, slots: List[int]):
+        T = len(slots)
         splits, n = self.chunk_plan(T)
         pes = temporal_slots(T)
         per = self._keys_per_chunk(splits)
         rows = []
-        for t, s in enumerate(self.slots):
+        for t, s in enumerate(slots):
             for kb in range(0, self.L, per):
                 rows.append((s, kb, min(per, self.L - kb), pes[t], t))
         assert len(rows) == n
-        # a fresh pinned staging row per upload: an earlier async upload may still be reading the previous one
-        self._chunk_stage = (self._chunk_stage + 1) % self.chunks_host.shape[0]
-        host = self.chunks_host[self._chunk_stage]
+        return rows, n
+
+    def mem_read_probe(self, T: int, layer: int = 0):
+        """Stand-alone Op of the long-term memory read at bank size T (bench.py's roofline leg; see GroupRuntime.mem_read_probe)."""
+        if not 1 <= T <= self.S:
+            raise ops.RmemError(f'mem_read_probe: T = {T} outside 1..{self.S}')
+        rows, n = self._chunk_rows(list(range(T)))
+        table = torch.zeros(n, 8, dtype=torch.int32)
+        table[:, :5] = torch.tensor(rows, dtype=torch.int32)
+        self._probe_chunks = table.to(self.dev)
+        L, C, i = self.L, D_MODEL, layer
+        op = self._attn(self.curr_Q[i], C, self.bank_K[i], self.bank_V[i], C, self.att, slot_stride=L * C, chunks=self._probe_chunks,
+                        nchunks=n, lk_single=T * L, pe_cur=self.P['pe_cur'], pe_mem=self.P['pe_mem'], mass=None, T=T)
+        return op, 4.0 * L * (T * L) * C
+
+    def upload_chunks(self, stream: int):
+        """Write the chunk table for the current slot order (call after every bank change)."""
+        rows, n = self._chunk_rows(self.slots)
+        # a pinned staging row whose previous upload has executed (ops.PinnedRing waits for it if it has not)
+        host = self.chunks_ring.next()
         host.zero_()
         host[:n, :5] = torch.tensor(rows, dtype=torch.int32)
-        ops.copy_async(self.chunks, host, self.max_chunks * 8 * 4)(stream)
+        self.chunks_ring.upload(self.chunks, self.max_chunks * 8 * 4, stream)
 
     # ------------------------------------------------------------------ programs
     def _conv(self, *a, **kw):

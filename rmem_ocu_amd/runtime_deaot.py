@@ -81,6 +81,24 @@ class DeAOTRuntime(ClipRuntime):
     def _keys_per_chunk(self, splits: int) -> int:
         return ((self.L + splits - 1) // splits + 63) // 64 * 64
 
+    def mem_read_probe(self, T: int, layer: int = 0):
+        """Stand-alone Op of layer's long-term gated attention at bank size T over this runtime's own buffers (bench.py's roofline
+        leg): same launch as prog_lstt's, own chunk table (bank slots 0 .. T-1), no mass, so engine state is untouched."""
+        if not 1 <= T <= self.S:
+            raise ops.RmemError(f'mem_read_probe: T = {T} outside 1..{self.S}')
+        rows, n = self._chunk_rows(list(range(T)))
+        table = torch.zeros(n, 8, dtype=torch.int32)
+        table[:, :5] = torch.tensor(rows, dtype=torch.int32)
+        self._probe_chunks = table.to(self.dev)
+        i, L, P = layer, self.L, self.P
+        ua, ldua, ub = self._gate(i)
+        op = ops.gated_attn(self.qvu[i], self.bank_K[i], self.bank_V[i], ua, self.g2, self.gp_ws, Lq=L, DV=E2, ldq=QVU,
+                            ldk=D_ATT, ldv=E2, ldua=ldua, ldo=E2, k_slot_stride=L * D_ATT, v_slot_stride=L * E2,
+                            chunks=self._probe_chunks, nchunks=n, frames=T, keys_per_frame=L, pe_cur=P['pe_cur'],
+                            pe_mem=P['pe_mem'], u_b=ub, ldub=E1, usplit=E1, mass=None,
+                            dw=P[f'g{i}.long_dw.w'], H=self.H16, W=self.W16)
+        return op, 2.0 * L * (T * L) * (D_ATT + E2)
+
     # ------------------------------------------------------------------ programs
     def _gate(self, i: int):
         """(u_a, ldua, u_b): cat_curr_U = [SiLU(U) | ones] in layer 0, [SiLU(U) | SiLU(ID_U)] after (1115-1124)."""

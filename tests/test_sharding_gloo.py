@@ -1,11 +1,18 @@
-"""The N > 1 path on CPU: two ranks over gloo shard a clip list, 'process' their clips and rank 0
-gathers (frames, seconds, checksum) -- the only exchange the clip-parallel design has."""
+"""The N > 1 path on CPU: ranks over gloo take a clip list from ClipFeeder (job-wide ticket queue on the TCPStore, or the
+static longest-first split), 'run' their clips through clip_runner.pump with stub slots and rank 0 gathers
+(frames, seconds, checksum) -- the only exchange the clip-parallel design has.  Also: bench.py --gpus N launches its own
+ranks and propagates their exit code."""
 import os
 import socket
+import subprocess
+import sys
 
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _free_port():
@@ -16,30 +23,63 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, lengths, q):
+class _StubSlot:
+    """Stands in for GroupSlot / ClipSlot: a unit of equal-length clips, one step = one frame of each."""
+
+    def __init__(self, delay):
+        self.done, self.left, self.ids, self.delay, self.ran = True, 0, [], delay, []
+
+    def start(self, ids, n):
+        self.ids, self.left, self.done = ids, n - 1, n <= 1
+        self.ran.append(list(ids))
+
+    def step(self):
+        import time
+        time.sleep(self.delay)
+        self.left -= 1
+        self.done = self.left <= 0
+
+
+def _worker(rank, world, port, lengths, group, mode, q):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group('gloo', rank=rank, world_size=world)
-    from rmem_ocu_amd.clip_runner import gather_stats, shard_clips
-    mine = shard_clips(len(lengths), rank, world, lengths)
-    frames = float(sum(lengths[i] - 1 for i in mine))            # propagated frames (frame 0 is the reference frame)
-    seconds = 1.0 + rank                                          # rank 1 is the slow one
+    from rmem_ocu_amd.clip_runner import ClipFeeder, gather_stats, pump
+    feeder = ClipFeeder(lengths, rank, world, group=group, mode=mode)
+    slots = [_StubSlot(0.002 * (1 + 3 * rank)) for _ in range(2)]       # rank 1 is 4x slower
+    frames = [0]
+
+    def start(s):
+        ids = feeder.next_unit()
+        if ids is None:
+            return False
+        s.start(ids, lengths[ids[0]])
+        frames[0] += sum(lengths[i] - 1 for i in ids)                   # propagated frames (frame 0 is the reference frame)
+        return True
+
+    dist.barrier()
+    pump(slots, start, 10 ** 9, group)
+    mine = [i for s in slots for u in s.ran for i in u]
     checksum = float(sum((i + 1) * lengths[i] for i in mine))
     dist.barrier()
-    out = gather_stats(frames, seconds, checksum, dist, rank, world, torch.device('cpu'))
+    out = gather_stats(float(frames[0]), 1.0 + rank, checksum, dist, rank, world, torch.device('cpu'))
+    counts = [None] * world
+    dist.all_gather_object(counts, (len(mine), sorted(mine)))
     if rank == 0:
-        q.put(out)
+        q.put((out, counts))
     dist.destroy_process_group()
 
 
-def test_two_rank_shard_and_gather():
-    lengths = [36, 80, 600, 12, 90, 300, 45, 45, 80]
+@pytest.mark.parametrize('mode', ['queue', 'static'])
+def test_two_rank_feeder_pump_and_gather(mode):
+    # static: a skewed list (one clip is 40 % of the job); queue: many similar units, so the faster rank must end up with more
+    lengths = [36, 80, 600, 12, 90, 300, 45, 45, 80, 80, 36, 36] if mode == 'static' else [40, 36] * 16
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, lengths, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, lengths, 2, mode, q)) for r in range(2)]
     for p in procs:
         p.start()
-    out = q.get(timeout=120)
+    out, counts = q.get(timeout=180)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -47,3 +87,34 @@ def test_two_rank_shard_and_gather():
     assert total_frames == sum(n - 1 for n in lengths)
     assert max_seconds == 2.0                                     # max over ranks, as bench.py reports
     assert checksum == sum((i + 1) * n for i, n in enumerate(lengths))
+    all_ids = sorted(counts[0][1] + counts[1][1])
+    assert all_ids == list(range(len(lengths)))                   # every clip ran exactly once, on exactly one rank
+    if mode == 'queue':                                           # the fast rank took more of the list (work stealing)
+        f0 = sum(lengths[i] for i in counts[0][1])
+        f1 = sum(lengths[i] for i in counts[1][1])
+        assert f0 > f1, (f0, f1)
+
+
+def test_group_units_and_static_feeder_single_rank():
+    from rmem_ocu_amd.clip_runner import ClipFeeder, group_units
+    lengths = [80, 40, 80, 80, 40, 80, 80]
+    units = group_units(lengths, 4)
+    assert units == [[0, 2, 3, 5], [6], [1, 4]]                   # equal lengths together, longest first, remainder units
+    f = ClipFeeder(lengths, group=4)
+    got = [f.next_unit() for _ in range(4)]
+    assert got[:3] == [[0, 2, 3, 5], [6], [1, 4]] and got[3] is None      # most frames first, ties in list order
+    c = ClipFeeder(lengths, group=4, cyclic=True)
+    assert [c.next_unit() for _ in range(4)][3] == [0, 2, 3, 5]
+
+
+def test_bench_self_launch_propagates_rank_failure():
+    """`python bench.py --gpus 2` with no WORLD_SIZE starts two ranks itself (no GPU here: the ranks refuse to run, and the
+    launcher must hand that failure on instead of printing a line)."""
+    if torch.cuda.is_available():
+        pytest.skip('needs a GPU-less host: on a GPU box this would run the benchmark')
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '0'],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert 'needs an MI355X' in (r.stdout + r.stderr)
+    assert '"metric"' not in r.stdout
