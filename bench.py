@@ -64,7 +64,8 @@ WORKLOADS = {
     # the model the reference's shipped eval_vost.sh runs: R50-DeAOTL, bank 1 + 8 (configs/models/r50_deaotl.py:8-9), cfg-2 geometry
     'davis17_480p_r50deaot_N9': dict(model='r50_deaotl', video=(480, 854), lengths=(80,), clips_per_gpu=64, objs=3, former=1, latter=8, net=None),
     # cfg 5 geometry: 720p, Swin-B, bank N = 12 (1 + 11), align_corners False -> network size = video size (multiple of 16)
-    'lvos_720p_swinb_N12': dict(model='swinb_aotl', video=(720, 1280), lengths=(150,), clips_per_gpu=4, objs=2, former=1, latter=11, net=(720, 1280)),
+    'lvos_720p_swinb_N12': dict(model='swinb_aotl', video=(720, 1280), lengths=(150,), clips_per_gpu=4, objs=2, former=1, latter=11, net=(720, 1280),
+                                dtype='fp16'),
     # cfg 2 geometry with a skewed clip list (mixed lengths): exercises the feeder's length buckets and queue
     'davis17_480p_r50_N8_mixed': dict(model='r50_aotl', video=(480, 854), lengths=(100, 80, 60, 40), clips_per_gpu=64, objs=3, former=1, latter=7, net=None),
 }
@@ -149,6 +150,8 @@ def parse_args(argv=None):
                     help='frames the ResNet-50 encoder runs ahead inside a clip (one launch per layer for all of them)')
     ap.add_argument('--feeder', default=None, choices=['queue', 'static'],
                     help='how the clip list reaches the ranks: job-wide ticket queue (default for N > 1) or static longest-first split')
+    ap.add_argument('--dtype', default=None, choices=['bf16', 'fp16'],
+                    help="16-bit operand type of the kernels (cfg.MODEL_DTYPE); default: the workload's (bf16; fp16 for the cfg-5 workload)")
     ap.add_argument('--roofline-launches', type=int, default=32, help='isolated T = 8 memory-read launches timed after the timed region')
     return ap.parse_args(argv)
 
@@ -189,6 +192,7 @@ def main():
     VIDEO_HW, NUM_OBJS = wl['video'], wl['objs']
     cfg = get_config('pre_vost', 'bench', wl['model'])
     cfg.FORMER_MEM_LEN, cfg.LATTER_MEM_LEN = wl['former'], wl['latter']
+    cfg.MODEL_DTYPE = args.dtype or wl.get('dtype', 'bf16')
     model = build_vos_model(cfg.MODEL_VOS, cfg).cuda(local_rank)
     deaot = cfg.MODEL_VOS == 'deaot'
     model.load_state_dict(synth_state_dict(0, encoder=cfg.MODEL_ENCODER, model='deaot' if deaot else 'aot'))
@@ -332,7 +336,7 @@ def main():
             'metric': 'frames/sec (whole node) 480p VOS, N=8 memory bank' if args.workload == 'davis17_480p_r50_N8'
             else f'frames/sec (whole node) {args.workload}', 'value': round(total_steps / elapsed, 2), 'unit': 'frames/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * elapsed / args.steps, 4),
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': cfg.MODEL_DTYPE, 'data': 'synthetic',
             'config': {'workload': args.workload, 'clip_frames': list(wl['lengths']) if len(wl['lengths']) > 1 else wl['lengths'][0],
                        'job_clips': len(lengths), 'clip_feeder': feeder.mode, 'video_hw': list(VIDEO_HW), 'network_hw': list(net_hw),
                        'tokens': L16, 'objects': NUM_OBJS,

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define RMEM_ABI_VERSION 4
+#define RMEM_ABI_VERSION 5
 
 int rmem_abi_version(void);
 const char* rmem_last_error_string(void);
@@ -171,9 +171,9 @@ int rmem_window_attn(const void* qkv, const float* qkv_bias, const float* bias_m
                      int C, int heads, int shift, void* stream);
 
 /* y = a + b (bf16).  Replaces the `curr_v + curr_id_emb` adds of layers/transformer.py:279-285. */
-int rmem_add_bf16(const void* a, const void* b, void* y, long long n, void* stream);
+int rmem_add16(const void* a, const void* b, void* y, long long n, void* stream);
 /* n <= 8 such adds of equal length as one launch (the per-layer adds of one memory update are independent). */
-int rmem_add_bf16_grouped(int n, const void* const* a, const void* const* b, void* const* y, long long count, void* stream);
+int rmem_add16_grouped(int n, const void* const* a, const void* const* b, void* const* y, long long count, void* stream);
 
 /* GroupNorm on NHWC bf16 with fused activation (0 none, 1 ReLU, 2 exact GELU).
  * Replaces: layers/basic.py:31-32 (GN(32)+GELU of the conv-FFN) and layers/basic.py:69-70 +
@@ -312,6 +312,46 @@ int rmem_graph_begin(void* stream);
 int rmem_graph_end(void* stream, void** graph_exec_out);
 int rmem_graph_launch(void* graph_exec, void* stream);
 int rmem_graph_destroy(void* graph_exec);
+
+
+/* ------------------------------------------------------------------ IEEE-half flavour
+ * Every entry point above that takes 16-bit operands ("bf16" pointers: activations, weights, bank entries) exists a second time
+ * with the suffix _f16: identical signature, layout and semantics, but the 16-bit element type is IEEE binary16 instead of
+ * bfloat16 (accumulation, residual streams and all statistics stay fp32).  This is the operand type of the reference's --amp
+ * path (tools/eval.py:45-47: torch.cuda.amp.autocast) and of BASELINE cfg 5; with 11 significant bits instead of 8 it is also the
+ * flavour that reaches >= 0.999 mask IoU against the fp32 reference.  Differences: the memory-read kernel
+ * always runs its online-softmax pass (P = exp2(S - m) must stay below 2^16), and values beyond +-65504 overflow, as under
+ * autocast.  Element-type-agnostic entry points (workspace sizes, fp32 / uint8 post-processing, copies, graphs, timers) have no twin. */
+int rmem_conv2d_nhwc_f16(const rmem_conv_desc* desc, const void* x, const void* w, const float* bias, const void* residual, void* y, void* y2, void* workspace, void* stream);
+int rmem_mem_read_attn_f16(const void* q, int ldq, const void* k_bank, const void* v_bank, long long slot_stride, int ldkv, const rmem_attn_chunk* chunks, int nchunks, int lk_single, const float* pe_cur, const float* pe_mem, int Lq, int heads, void* out, int ldo, float* attn_mass, int T, void* workspace, void* stream);
+int rmem_mem_read_attn_clips_f16(const void* q, int ldq, const void* k_bank, const void* v_bank, long long slot_stride, int ldkv, const rmem_attn_chunk* chunks, int nchunks, int lk_single, const float* pe_cur, const float* pe_mem, int Lq, int heads, void* out, int ldo, float* attn_mass, int T, int nclips, long long q_clip_stride, long long kv_clip_stride, long long out_clip_stride, void* workspace, void* stream);
+int rmem_layernorm256_f16(const void* a, int a_is_f32, int lda, const void* b, int b_is_f32, int ldb, const float* gamma, const float* beta, float eps, int M, void* y_bf16, int ldy, const float* pos, void* ypos_bf16, int ldyp, float* y_f32, int ldyf, void* stream);
+int rmem_layernorm_f16(const void* a, int a_is_f32, int lda, const float* gamma, const float* beta, float eps, int M, int C, void* y_bf16, int ldy, float* y_f32, int ldyf, void* stream);
+int rmem_patch_merge_ln_f16(const float* x, int H, int W, int C, const float* gamma, const float* beta, float eps, void* y_bf16, void* stream);
+int rmem_window_attn_f16(const void* qkv, const float* qkv_bias, const float* bias_mask_table, void* out, int H, int W, int C, int heads, int shift, void* stream);
+int rmem_add16_f16(const void* a, const void* b, void* y, long long n, void* stream);
+int rmem_add16_grouped_f16(int n, const void* const* a, const void* const* b, void* const* y, long long count, void* stream);
+int rmem_layernorm256_pair_f16(const void* a0, const void* b0, void* y0, const void* a1, const void* b1, void* y1, const float* gamma, const float* beta, float eps, int M, void* stream);
+int rmem_conv1x1_dual_nhwc_f16(const rmem_conv_desc* desc, const void* x, const void* x2, int H2, int W2, int Cin2, int stride2, const void* w_cat, const float* bias, void* y, void* stream);
+int rmem_linear_grouped_f16(const rmem_conv_desc* desc, int n, const void* const* x, const void* const* w, const float* const* bias, const void* const* residual, void* const* y, void* stream);
+int rmem_groupnorm_nhwc_f16(const void* x, int M, int C, int groups, const float* gamma, const float* beta, float eps, int act, void* y, float* workspace, void* stream);
+int rmem_groupnorm_f32_nhwc_f16(const float* x, int M, int C, int groups, const float* gamma, const float* beta, float eps, int act, void* y, float* workspace, void* stream);
+int rmem_groupnorm_nhwc_images_f16(const void* x, int images, int M, int C, int groups, const float* gamma, const float* beta, float eps, int act, void* y, float* workspace, void* stream);
+int rmem_groupnorm_head_nhwc_images_f16(const void* x, int images, int M, int C, int groups, const float* gamma, const float* beta, float eps, int act, const void* w, const float* bias, int N, float* y, int ldy, float* workspace, void* stream);
+int rmem_gn_act_dwconv5x5_nhwc_images_f16(const void* x, int images, int H, int W, int C, int groups, const float* gamma, const float* beta, float eps, int act, const float* w_t, void* y, float* workspace, void* stream);
+int rmem_gn_act_dwconv5x5_nhwc_f16(const void* x, int H, int W, int C, int groups, const float* gamma, const float* beta, float eps, int act, const float* w_t, void* y, float* workspace, void* stream);
+int rmem_dwconv5x5_nhwc_f16(const void* x, const float* w_t, void* y, int H, int W, int C, void* stream);
+int rmem_image_to_nhwc8_f16(const float* img_chw, void* out, int H, int W, void* stream);
+int rmem_image_to_nhwc8_images_f16(const float* img_chw, void* out, int images, int H, int W, void* stream);
+int rmem_ingest_rgb8_f16(const unsigned char* rgb_hwc, int Hs, int Ws, int Hd, int Wd, float* out_chw, void* out_nhwc8, void* stream);
+int rmem_maxpool3x3s2_nhwc_f16(const void* x, void* y, int H, int W, int C, void* stream);
+int rmem_maxpool3x3s2_nhwc_images_f16(const void* x, void* y, int images, int H, int W, int C, void* stream);
+int rmem_bilinear_nhwc_f16(const void* x, void* y, int Hi, int Wi, int Ho, int Wo, int C, int align_corners, void* stream);
+int rmem_bilinear_nhwc_images_f16(const void* x, void* y, int images, int Hi, int Wi, int Ho, int Wo, int C, int align_corners, void* stream);
+int rmem_label_to_onehot16_f16(const void* label, int label_is_f32, int Hs, int Ws, int Hd, int Wd, int num_classes, void* out, void* stream);
+int rmem_label_to_onehot16_images_f16(const void* label, int label_is_f32, int images, int Hs, int Ws, int Hd, int Wd, int num_classes, void* out, void* stream);
+int rmem_gated_attn_f16(const void* q, int ldq, const void* k_bank, long long k_slot_stride, int ldk, const void* v_bank, long long v_slot_stride, int ldv, const rmem_attn_chunk* chunks, int nchunks, int frames, int keys_per_frame, const float* pe_cur, const float* pe_mem, int Lq, int DV, const void* u_a, int ldua, const void* u_b, int ldub, int usplit, void* out, int ldo, float* attn_mass, const float* dw_w_t, int H, int W, void* workspace, void* stream);
+int rmem_local_gated_attn_f16(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const float* rel, int ldrel, int H, int W, int DV, const void* u_a, int ldua, const void* u_b, int ldub, int usplit, void* out, int ldo, const float* dw_w_t, void* workspace, void* stream);
 
 #ifdef __cplusplus
 }

@@ -30,6 +30,7 @@ class EngineConfig:
         self.MODEL_ATT_HEADS = 8
         self.MODEL_LSTT_NUM = 3
         self.MODEL_EPSILON = 1e-5
+        self.MODEL_DTYPE = 'bf16'            # build-specific: 16-bit operand type of the HIP kernels, 'bf16' | 'fp16' (the reference: --amp)
         self.FORMER_MEM_LEN = 1
         self.LATTER_MEM_LEN = 7              # "N = 8" <=> 1 + 7
         self.USE_TEMPORAL_POSITIONAL_EMBEDDING = True

@@ -3,6 +3,9 @@
 #include "../../include/rmem.h"
 #include <string.h>
 #include <stdio.h>
+#include <atomic>
+#include <mutex>
+#include <vector>
 
 static thread_local char g_err[512] = "";
 
@@ -74,4 +77,98 @@ extern "C" int rmem_copy2d_async(void* dst, long long dst_pitch, const void* src
   HIP_TRY(hipMemcpy2DAsync(dst, (size_t)dst_pitch, src, (size_t)src_pitch, (size_t)row_bytes, (size_t)rows, hipMemcpyDeviceToDevice,
                            (hipStream_t)stream), "rmem_copy2d_async");
   return 0;
+}
+
+// ---- opt-in launch timers (bench.py's roofline leg): HIP events around selected launches, on the launch stream ----
+// Process-wide state, off unless started; `on` is read by every launch without the lock, everything else under `mu`.
+namespace {
+__global__ void k_prof_nop() {}
+
+struct ProfState {
+  std::mutex mu;
+  std::atomic<bool> on{false};
+  float bracket_ms = 0.f;       // HIP-event bracket cost around an empty kernel (calibrated in start)
+  std::vector<hipEvent_t> ev;   // pairs
+  std::vector<double> flops;
+  size_t used = 0;
+};
+ProfState g_prof[2];
+
+int prof_start(ProfState& st, int max_launches, const char* who) {
+  std::lock_guard<std::mutex> lk(st.mu);
+  if (max_launches <= 0) { rmem_set_error("rmem_profile_start: max_launches must be > 0"); return -1; }
+  while (st.ev.size() < (size_t)max_launches * 2) {
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) { rmem_set_error(who); return -3; }
+    st.ev.push_back(e);
+  }
+  st.flops.assign(max_launches, 0.0);
+  st.used = 0;
+  // calibrate what two event records around ONE launch cost by themselves: bracket an empty kernel on an idle stream,
+  // keep the minimum of 32 trials; stop() subtracts it from every timed launch
+  hipStream_t cs;
+  if (hipStreamCreate(&cs) == hipSuccess) {
+    float best = 1e9f;
+    for (int i = 0; i < 32; ++i) {
+      (void)hipEventRecord(st.ev[0], cs);
+      hipLaunchKernelGGL(k_prof_nop, dim3(1), dim3(64), 0, cs);
+      (void)hipEventRecord(st.ev[1], cs);
+      (void)hipEventSynchronize(st.ev[1]);
+      float t = 0.f;
+      if (hipEventElapsedTime(&t, st.ev[0], st.ev[1]) == hipSuccess && t < best) best = t;
+    }
+    (void)hipStreamDestroy(cs);
+    st.bracket_ms = best < 1e8f ? best : 0.f;
+  }
+  st.on.store(true);
+  return 0;
+}
+
+int prof_stop(ProfState& st, double* total_ms, double* total_flops, int* launches, const char* who) {
+  std::lock_guard<std::mutex> lk(st.mu);
+  st.on.store(false);
+  double ms = 0.0, fl = 0.0;
+  for (size_t i = 0; i < st.used; ++i) {
+    float t = 0.f;
+    if (hipEventSynchronize(st.ev[2 * i + 1]) != hipSuccess || hipEventElapsedTime(&t, st.ev[2 * i], st.ev[2 * i + 1]) != hipSuccess) {
+      rmem_set_error(who);
+      return -3;
+    }
+    ms += fmaxf(t - st.bracket_ms, 0.f);
+    fl += st.flops[i];
+  }
+  if (total_ms) *total_ms = ms;
+  if (total_flops) *total_flops = fl;
+  if (launches) *launches = (int)st.used;
+  return 0;
+}
+}  // namespace
+
+int rmem_prof_begin(int channel, void* stream, double flops) {
+  ProfState& st = g_prof[channel];
+  if (!st.on.load(std::memory_order_relaxed)) return -1;
+  hipStream_t s = (hipStream_t)stream;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing(s, &cs);
+  if (cs != hipStreamCaptureStatusNone) return -1;
+  int slot = -1;
+  {
+    std::lock_guard<std::mutex> lk(st.mu);
+    if (st.on.load() && st.used * 2 + 1 < st.ev.size()) { slot = (int)st.used++; st.flops[slot] = flops; }
+  }
+  if (slot >= 0) (void)hipEventRecord(st.ev[2 * slot], s);
+  return slot;
+}
+
+void rmem_prof_end(int channel, int slot, void* stream) {
+  if (slot >= 0) (void)hipEventRecord(g_prof[channel].ev[2 * slot + 1], (hipStream_t)stream);
+}
+
+extern "C" int rmem_profile_start(int max_launches) { return prof_start(g_prof[RMEM_PROF_MEM_READ], max_launches, "rmem_profile_start: hipEventCreate failed"); }
+extern "C" int rmem_profile_stop(double* total_ms, double* total_flops, int* launches) {
+  return prof_stop(g_prof[RMEM_PROF_MEM_READ], total_ms, total_flops, launches, "rmem_profile_stop: event query failed");
+}
+extern "C" int rmem_gated_profile_start(void) { return prof_start(g_prof[RMEM_PROF_GATED_PV], 256, "rmem_gated_profile_start: hipEventCreate failed"); }
+extern "C" int rmem_gated_profile_stop(double* total_ms, double* total_flops, int* launches) {
+  return prof_stop(g_prof[RMEM_PROF_GATED_PV], total_ms, total_flops, launches, "rmem_gated_profile_stop: event query failed");
 }

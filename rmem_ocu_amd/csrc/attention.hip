@@ -13,7 +13,7 @@
 // consecutive rows (several memory frames when enough workgroups exist without splitting further) and keeps ONE
 // running (m_ref, l, O) for all of them; at every row end it records that row's (m_ref, l_row) pair, from which
 // k_attn_mass derives the per-memory-frame probability mass (transformer.py:636-643) without ever materialising
-// the attention matrix.  With one group the normalised bf16 output is written by this kernel itself; with several,
+// the attention matrix.  With one group the normalised e16 output is written by this kernel itself; with several,
 // each group leaves an unnormalised fp32 partial + (m, l) and k_attn_combine merges them.
 //
 // Per workgroup: 4 waves x 32 query rows.  K/V tiles of 64 keys go global -> registers -> LDS (double buffered, one
@@ -23,13 +23,13 @@
 //                     registers for the whole kernel; the query sits on the lane,
 //                     so row max / row sum are in-lane plus one exchange with lane^32.
 //                     The temporal-PE term q'.pe[slot] is the accumulator's initial value.
-//   O^T += V^T . P^T: the S^T accumulator (exp2'd, packed to bf16) IS the B operand:
+//   O^T += V^T . P^T: the S^T accumulator (exp2'd, packed to e16) IS the B operand:
 //                     registers 8s..8s+7 of lane half h are keys 16s+8(j>>2)+4h+(j&3),
 //                     and the V^T A-fragment is read in that same key order.
 // Logits live in the log2 domain: Q is pre-scaled by log2(e)/sqrt(32).
 //
 // Softmax reference.  With d = 32 the VALU (one v_exp_f32 per score) is the limiter, so the loop carries no per-score
-// work besides exp2 + bf16 packing: the reference m_ref and the temporal-PE bias are the C operand of the first QK MFMA
+// work besides exp2 + e16 packing: the reference m_ref and the temporal-PE bias are the C operand of the first QK MFMA
 // (S' = S - m_ref comes out of the matrix pipe), row sums come from a ones-A-operand MFMA on the same P fragments, and
 // the FAST pass fixes m_ref = the maximum of the group's FIRST tile and never looks at a maximum again: floating point
 // keeps the relative precision of P = 2^(S - m_ref), O and l whatever the offset, so a later, larger score is harmless
@@ -39,25 +39,24 @@
 // tests force the fallback with a key 2^100 above the first tile.
 #include "common.h"
 #include "../../include/rmem.h"
-#include <atomic>
-#include <mutex>
 #include <type_traits>
-#include <vector>
 
 namespace {
 
 constexpr int D = 32;          // head dim
 constexpr int KT = 64;         // keys per LDS tile
+constexpr int NB = 4;          // LDS ring depth: NB - 1 tiles in flight by LDS-DMA (one tile ahead does not cover the
+                               // L2 -> LDS latency when every CU streams: the kernel then waits on vmcnt at every tile)
 constexpr float NEG_BIG = -1.0e30f;
 constexpr float RESCALE_THR = 8.0f;          // SAFE pass, log2 units: P <= 2^8 between rescales
-constexpr float L_LIMIT = 1.8446744e19f;     // 2^64: a fast-pass row sum above it (or inf / NaN) sends the group to the SAFE pass
+[[maybe_unused]] constexpr float L_LIMIT = 1.8446744e19f;     // 2^64: a fast-pass row sum above it (or inf / NaN) sends the group to the SAFE pass
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
 struct AttnParams {
-  const bf16* q; int ldq;
-  const bf16* k; const bf16* v; long slot_stride; int ldkv;
+  const e16* q; int ldq;
+  const e16* k; const e16* v; long slot_stride; int ldkv;
   const rmem_attn_chunk* chunks; int nchunks; int lk; int per_chunk;
   const float* pe_cur; const float* pe_mem;
   int Lq, heads, C, nq;
@@ -65,7 +64,7 @@ struct AttnParams {
   float* opart; float* mlg;       // per group: unnormalised partial O, (m_ref, l)      (ngroups > 1)
   float* ml;                      // per table row: (m_ref at the row's end, l_row)     (mass output wanted), or null
   float qscale;
-  bf16* out; int ldo;             // normalised bf16 output (written here when ngroups == 1)
+  e16* out; int ldo;             // normalised e16 output (written here when ngroups == 1)
   // several clips in one launch (identical shapes; clip c's operands sit c * stride further, its table rows at c * nchunks)
   int nclips; long q_cs, kv_cs, out_cs, opart_cs, mlg_cs, ml_cs;
 };
@@ -104,8 +103,8 @@ __device__ inline void buf_load_lds16(rsrc_t, lptr_t, int, int) {}
 // the N youngest have landed"; the fragments pass through the wait so that their consumers stay behind it.
 #ifdef RMEM_ATTN_C_LDS
 template <int OFF>
-__device__ __forceinline__ bf16x8 lds_b128(unsigned addr) {
-  return *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>((size_t)(addr + OFF));
+__device__ __forceinline__ e16x8 lds_b128(unsigned addr) {
+  return *reinterpret_cast<const __attribute__((address_space(3))) e16x8*>((size_t)(addr + OFF));
 }
 template <int OFF>
 __device__ __forceinline__ s16x4 lds_tr16(unsigned addr) {
@@ -113,8 +112,8 @@ __device__ __forceinline__ s16x4 lds_tr16(unsigned addr) {
 }
 #else
 template <int OFF>
-__device__ __forceinline__ bf16x8 lds_b128(unsigned addr) {
-  bf16x8 v;
+__device__ __forceinline__ e16x8 lds_b128(unsigned addr) {
+  e16x8 v;
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
   return v;
 }
@@ -126,10 +125,10 @@ __device__ __forceinline__ s16x4 lds_tr16(unsigned addr) {
 }
 #endif
 template <int N>
-__device__ __forceinline__ void lds_wait4(bf16x8& a, bf16x8& b, bf16x8& c, bf16x8& d) {
+__device__ __forceinline__ void lds_wait4(e16x8& a, e16x8& b, e16x8& c, e16x8& d) {
   asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N));
 }
-struct PvFrag { s16x4 lo[2], hi[2]; bf16x8 ones[2]; };      // one 32-key block: V^T fragments and row-sum operands of its 2 slabs
+struct PvFrag { s16x4 lo[2], hi[2]; e16x8 ones[2]; };      // one 32-key block: V^T fragments and row-sum operands of its 2 slabs
 template <int N>
 __device__ __forceinline__ void lds_wait_pv(PvFrag& f) {
   asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(f.lo[0]), "+v"(f.hi[0]), "+v"(f.lo[1]), "+v"(f.hi[1]), "+v"(f.ones[0]), "+v"(f.ones[1]) : "n"(N));
@@ -140,15 +139,19 @@ __device__ __forceinline__ void lds_wait_pv(PvFrag& f) {
 // TIMED changes nothing but the symbol: launches bracketed by rmem_profile_* HIP events use the <true, true> instance, so
 // a kernel trace of the same run lists exactly the launches bench.py timed under their own name.
 template <bool MEM, bool TIMED = false>
-__global__ __launch_bounds__(256) void k_attn_partial(AttnParams pin) {
+__global__ __launch_bounds__(256, 3) void k_attn_partial(AttnParams pin) {
   AttnParams p = pin;
-  __shared__ __attribute__((aligned(16))) bf16 Ks[2][KT * D];   // [key][32], 16-byte chunks XOR-swizzled
-  __shared__ __attribute__((aligned(16))) bf16 Vs[2][KT * D];   // [key][32] row-major, read transposed (ds_read_b64_tr_b16)
+  __shared__ __attribute__((aligned(16))) e16 Ks[NB][KT * D];  // ring of NB tiles: [key][32], 16-byte chunks XOR-swizzled
+  __shared__ __attribute__((aligned(16))) e16 Vs[NB][KT * D];  // [key][32] row-major, read transposed (ds_read_b64_tr_b16)
   // 1.0 / 0.0 per key of the tile: the A operand of the row-sum MFMA.  A row's ragged last tile (HW = 1674 = 26 * 64 + 10) is
   // padded with K = V = 0 keys (the DMA's range check); they add nothing to O, and reading the "ones" from here keeps them
   // out of l without a single per-score select (masking S instead costs 90 VALU instructions per tile once the compiler
   // if-converts it)
-  __shared__ __attribute__((aligned(16))) bf16 Ones[2][KT];
+  __shared__ __attribute__((aligned(16))) e16 Ones[NB][KT];
+#ifdef RMEM_ATTN_LDS_PAD          // occupancy experiments only: extra LDS per workgroup limits the workgroups per CU
+  __shared__ char lds_pad[RMEM_ATTN_LDS_PAD];
+  if (threadIdx.x == 1023) lds_pad[blockIdx.x & 7] = 1;
+#endif
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // provably wave-uniform: LDS-DMA destinations stay in SGPRs
@@ -194,16 +197,16 @@ __global__ __launch_bounds__(256) void k_attn_partial(AttnParams pin) {
 
   // ---- Q^T fragment (B operand), pre-scaled, with the current-frame temporal PE added ----
   const int qrow = min(qt * 128 + wave * 32 + lq, p.Lq - 1);
-  bf16x8 qf[2];
+  e16x8 qf[2];
   const bool has_cur = MEM && p.pe_cur != nullptr;        // workgroup-uniform
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
     const int d0 = head * D + 16 * s + 8 * lh;
-    const bf16x8 raw = *reinterpret_cast<const bf16x8*>(p.q + (long)qrow * p.ldq + d0);
+    const e16x8 raw = *reinterpret_cast<const e16x8*>(p.q + (long)qrow * p.ldq + d0);
     f32x4 c0v = {0.f, 0.f, 0.f, 0.f}, c1v = c0v;
     if (has_cur) { c0v = *reinterpret_cast<const f32x4*>(p.pe_cur + d0); c1v = *reinterpret_cast<const f32x4*>(p.pe_cur + d0 + 4); }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) qf[s][j] = (bf16)(((float)raw[j] + (j < 4 ? c0v[j & 3] : c1v[j & 3])) * p.qscale);
+    for (int j = 0; j < 8; ++j) qf[s][j] = (e16)(((float)raw[j] + (j < 4 ? c0v[j & 3] : c1v[j & 3])) * p.qscale);
   }
   // logit bias of a row: q' . pe_mem[pe_slot] (the reference adds pe_mem to the keys, transformer.py:594-626)
   auto row_bias = [&](int pe_slot) -> float {
@@ -230,24 +233,36 @@ __global__ __launch_bounds__(256) void k_attn_partial(AttnParams pin) {
   // so that one 16-byte read per (block, slab, lane half) is the row-sum MFMA's A operand
   const int sones = (skey & ~15) | (((skey >> 2) & 1) << 3) | (((skey >> 3) & 1) << 2) | (skey & 3);
   const int tile_elems = KT * p.ldkv;
-  const bf16* row_k = nullptr;                  // first key of the open row at this head's columns (wave-uniform)
-  const bf16* row_v = nullptr;
-  int row_bytes = 0, row_kn = 0;
-  auto open_row = [&](const Row& r) {
+  // The DMA cursor runs NB - 1 tiles ahead of the arithmetic, across row boundaries: (row dc, tile dt) with the row's base
+  // pointers at this head's columns (wave-uniform: SGPRs).
+  const e16* row_k = nullptr;
+  const e16* row_v = nullptr;
+  int row_bytes = 0, row_kn = 0, dc = 0, dt = 0, dnt = 0;
+  auto open_row = [&](int c) {
+    const Row r = row_info(c);
     const long off = (long)r.slot * p.slot_stride + (long)r.kb * p.ldkv + head * D;
     row_k = p.k + off; row_v = p.v + off;
     row_bytes = ((r.kn - 1) * p.ldkv + D) * 2;  // up to the end of the last key's slice
     row_kn = r.kn;
+    dc = c; dt = 0; dnt = (r.kn + KT - 1) / KT;
   };
-  // tile t of the open row -> LDS buffer buf (asynchronous: s_waitcnt vmcnt before use).  The descriptor is rebuilt per tile
-  // (scalar work) so that it starts at the tile and ends with the row: the hardware range check covers the per-lane offset
-  // only (not soffset), and this way a lane beyond the row's last key is out of range by its own offset and reads zeros.
-  auto dma_tile = [&](int t, int buf) {
-    const int left = row_bytes - t * tile_elems * 2;
+  // Next tile of the group -> LDS buffer BUF (asynchronous: counted s_waitcnt vmcnt before use); false once the group is
+  // exhausted.  The descriptor is rebuilt per tile (scalar work) so that it starts at the tile and ends with the row: the
+  // hardware range check covers the per-lane offset only (not soffset), and this way a lane beyond the row's last key is out
+  // of range by its own offset and reads zeros.
+  auto dma_next = [&](auto buf_tag) -> bool {
+    constexpr int BUF = decltype(buf_tag)::value;
+    if (dc >= c1) return false;
+    const int left = row_bytes - dt * tile_elems * 2;
     // (the plain LDS store goes first: behind a DMA the compiler would wait for the DMA before it)
-    if (spos == 0) Ones[buf][sones] = (bf16)(t * KT + skey < row_kn ? 1.0f : 0.0f);
-    buf_load_lds16(make_rsrc(row_k + (long)t * tile_elems, left), (lptr_t)&Ks[buf][wave * 16 * D], voff_k, 0);
-    buf_load_lds16(make_rsrc(row_v + (long)t * tile_elems, left), (lptr_t)&Vs[buf][wave * 16 * D], voff_v, 0);
+    if (spos == 0) Ones[BUF][sones] = (e16)(dt * KT + skey < row_kn ? 1.0f : 0.0f);
+    buf_load_lds16(make_rsrc(row_k + (long)dt * tile_elems, left), (lptr_t)&Ks[BUF][wave * 16 * D], voff_k, 0);
+    buf_load_lds16(make_rsrc(row_v + (long)dt * tile_elems, left), (lptr_t)&Vs[BUF][wave * 16 * D], voff_v, 0);
+    if (++dt >= dnt) {
+      if (dc + 1 < c1) open_row(dc + 1);
+      else dc = c1;
+    }
+    return true;
   };
 
   // transposed-read addressing of the V tile: 16-lane group g reads a 4-key x 16-d block; lane 4q+p of the group
@@ -283,10 +298,15 @@ __global__ __launch_bounds__(256) void k_attn_partial(AttnParams pin) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) cinit[r] = bias;
     }
-    open_row(cur);
-    dma_tile(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    using B0 = std::integral_constant<int, 0>;
+    using B1 = std::integral_constant<int, 1>;
+    using B2 = std::integral_constant<int, 2>;
+    using B3 = std::integral_constant<int, 3>;
+    static_assert(NB == 4, "the step sequence below is written out for a ring of 4");
+    open_row(c0);
+    dma_next(B0{});
+    dma_next(B1{});
+    bool more = dma_next(B2{});      // false: every tile of the group has been issued
 
     // One 64-key tile out of LDS buffer BUF.  MAXMODE 0: no maximum at all (FAST pass after its first tile); 1: the group's
     // first tile (m_ref := tile maximum, nothing accumulated yet); 2: SAFE pass (move m_ref and rescale when a tile exceeds
@@ -298,8 +318,8 @@ __global__ __launch_bounds__(256) void k_attn_partial(AttnParams pin) {
       constexpr int MAXMODE = decltype(mode_tag)::value;
       constexpr int BUF = decltype(buf_tag)::value;
       // S'^T = K . Q^T + (bias - m_ref) for the two 32-key blocks of this tile
-      constexpr int KB = BUF * KT * D * 2, VB = BUF * KT * D * 2, OB = BUF * KT * 2;      // byte offsets of the buffer
-      bf16x8 ka[2][2];
+      constexpr int KB = BUF * KT * D * 2, VB = BUF * KT * D * 2, OB = BUF * KT * 2;      // byte offsets of the ring slot
+      e16x8 ka[2][2];
       ka[0][0] = lds_b128<KB>(k_addr[0]);
       ka[0][1] = lds_b128<KB>(k_addr[1]);
       ka[1][0] = lds_b128<KB + 32 * D * 2>(k_addr[0]);
@@ -314,9 +334,9 @@ __global__ __launch_bounds__(256) void k_attn_partial(AttnParams pin) {
         // written before the previous barrier (a VALU write of SrcC directly in front of the MFMA needs wait states -- the
         // first tile, whose cinit is a fresh constant, read stale registers through this path), and the marker below keeps
         // the operands allocated until both asm MFMAs have started (the matrix pipe reads SrcC when the instruction executes).
-        if (MAXMODE == 0) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(sacc[b]) : "v"(ka[b][0]), "v"(qf[0]), "v"(cinit));
-        else sacc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[b][0], qf[0], cinit, 0, 0, 0);
-        sacc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[b][1], qf[1], sacc[b], 0, 0, 0);
+        if (MAXMODE == 0) asm volatile(RMEM_MFMA_32x32x16_ASM " %0, %1, %2, %3" : "=&v"(sacc[b]) : "v"(ka[b][0]), "v"(qf[0]), "v"(cinit));
+        else sacc[b] = RMEM_MFMA_32x32x16(ka[b][0], qf[0], cinit, 0, 0, 0);
+        sacc[b] = RMEM_MFMA_32x32x16(ka[b][1], qf[1], sacc[b], 0, 0, 0);
       }
       if (MAXMODE == 0) asm volatile("" : "+v"(sacc[1]) : "v"(cinit), "v"(ka[0][0]), "v"(ka[1][0]), "v"(qf[0]));
       // the 6 reads of one 32-key block's V^T fragments and row-sum operands; issued one block ahead of their use, so that
@@ -362,35 +382,47 @@ __global__ __launch_bounds__(256) void k_attn_partial(AttnParams pin) {
           }
         }
       }
-      // P = exp2(S'), packed to bf16: the B operand of O^T += V^T . P^T and l += 1^T . P^T (same fragments)
+      // P = exp2(S'), packed to e16: the B operand of O^T += V^T . P^T and l += 1^T . P^T (same fragments)
 #pragma unroll
       for (int b = 0; b < 2; ++b) {
-        bf16x8 pb[2];
+        e16x8 pb[2];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) pb[r >> 3][r & 7] = (bf16)__builtin_amdgcn_exp2f(sacc[b][r]);
+#ifndef RMEM_ATTN_ABLATE_EXP
+        for (int r = 0; r < 16; ++r) pb[r >> 3][r & 7] = (e16)__builtin_amdgcn_exp2f(sacc[b][r]);
+#else
+        for (int r = 0; r < 16; ++r) pb[r >> 3][r & 7] = (e16)(sacc[b][r]);
+#endif
         lds_wait_pv<0>(pv);
 #pragma unroll
         for (int sl = 0; sl < 2; ++sl) {
           const __attribute__((ext_vector_type(8))) short a16 = {pv.lo[sl][0], pv.lo[sl][1], pv.lo[sl][2], pv.lo[sl][3],
                                                                  pv.hi[sl][0], pv.hi[sl][1], pv.hi[sl][2], pv.hi[sl][3]};
-          const bf16x8 a = __builtin_bit_cast(bf16x8, a16);
-          oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pb[sl], oacc, 0, 0, 0);
-          lacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pv.ones[sl], pb[sl], lacc, 0, 0, 0);
+          const e16x8 a = __builtin_bit_cast(e16x8, a16);
+          oacc = RMEM_MFMA_32x32x16(a, pb[sl], oacc, 0, 0, 0);
+#ifndef RMEM_ATTN_ABLATE_L      // timing experiments only (results are then wrong by construction)
+          lacc = RMEM_MFMA_32x32x16(pv.ones[sl], pb[sl], lacc, 0, 0, 0);
+#else
+          lacc[0] += (float)pb[sl][0];
+#endif
         }
         if (b == 0) read_pv(std::integral_constant<int, 1>{});
       }
     };
 
-    // One loop step on LDS buffer BUF: start the DMA of the next tile (possibly the next row's first) into the other buffer,
-    // compute this tile, close the row if it ends here, then wait for the DMA and meet the barrier that publishes it.
-    // Returns true after the group's last tile.
+    // One loop step on ring slot BUF.  The slot's tile was issued three steps ago; with the DMA cursor still running exactly
+    // two younger tiles (4 wave-instructions) are in flight behind it, so vmcnt(4) means "my part of this tile has landed";
+    // the barrier then says so for the whole workgroup AND that everybody is done with the previous tile, whose slot the
+    // next DMA overwrites.  Returns true after the group's last tile.
     auto step = [&](auto mode_tag, auto buf_tag) -> bool {
       constexpr int BUF = decltype(buf_tag)::value;
+      if (more) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifndef RMEM_ATTN_ABLATE_BARRIER
+      __syncthreads();
+#endif
+      if (more) more = dma_next(std::integral_constant<int, (BUF + NB - 1) % NB>{});
       const bool last_in_row = t + 1 >= ntiles;
       const bool last = last_in_row && c + 1 >= c1;
-      Row nxt = cur;
-      if (last_in_row && !last) { nxt = row_info(c + 1); open_row(nxt); }
-      if (!last) dma_tile(last_in_row ? 0 : t + 1, BUF ^ 1);
       if (wave_active) tile(mode_tag, buf_tag);
       if (last_in_row) {
         if (wave_active) {
@@ -402,7 +434,7 @@ __global__ __launch_bounds__(256) void k_attn_partial(AttnParams pin) {
           for (int r = 0; r < 16; ++r) lacc[r] = 0.f;
         }
         if (last) return true;
-        ++c; cur = nxt; t = 0;
+        ++c; cur = row_info(c); t = 0;
         ntiles = (cur.kn + KT - 1) / KT;
         if (wave_active) {
           const float bias = row_bias(cur.pe_slot) - m_ref;
@@ -412,34 +444,39 @@ __global__ __launch_bounds__(256) void k_attn_partial(AttnParams pin) {
       } else {
         ++t;
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
       return false;
     };
     constexpr int STEADY = SAFE ? 2 : 0;
-    using B0 = std::integral_constant<int, 0>;
-    using B1 = std::integral_constant<int, 1>;
-    if (step(std::integral_constant<int, 1>{}, B0{})) return;
-    for (;;) {                                   // two steps per trip: the LDS buffer index is a compile-time constant
-      if (step(std::integral_constant<int, STEADY>{}, B1{})) return;
-      if (step(std::integral_constant<int, STEADY>{}, B0{})) return;
+    using M1 = std::integral_constant<int, 1>;
+    using MS = std::integral_constant<int, STEADY>;
+    if (step(M1{}, B0{})) return;
+    for (;;) {                                   // four steps per trip: the ring slot is a compile-time constant
+      if (step(MS{}, B1{})) return;
+      if (step(MS{}, B2{})) return;
+      if (step(MS{}, B3{})) return;
+      if (step(MS{}, B0{})) return;
     }
   };
 
+#ifdef RMEM_F16
+  // IEEE half carries P only up to 2^16: the reference must be a running maximum, so this flavour always takes the SAFE pass
+  walk(std::true_type{});
+#else
   walk(std::false_type{});
   // any query of the workgroup whose sums left the safe range sends the whole group through the online-softmax pass
   // (the vote is also the barrier that frees the LDS tiles for it)
   if (__syncthreads_or(wave_active && !(ltot <= L_LIMIT))) walk(std::true_type{});
+#endif
   if (!wave_active) return;
 
   if (p.ngroups == 1) {
     if (qg < p.Lq) {
       const float inv = 1.f / ltot;
-      bf16* o = p.out + (long)qg * p.ldo + head * D + 4 * lh;
+      e16* o = p.out + (long)qg * p.ldo + head * D + 4 * lh;
 #pragma unroll
       for (int gg = 0; gg < 4; ++gg)    // C/D rows (r&3) + 8(r>>2) + 4h -> d = 8g + 4h + (0..3)
-        *reinterpret_cast<bf16x4*>(o + 8 * gg) = bf16x4{(bf16)(oacc[4 * gg] * inv), (bf16)(oacc[4 * gg + 1] * inv),
-                                                        (bf16)(oacc[4 * gg + 2] * inv), (bf16)(oacc[4 * gg + 3] * inv)};
+        *reinterpret_cast<e16x4*>(o + 8 * gg) = e16x4{(e16)(oacc[4 * gg] * inv), (e16)(oacc[4 * gg + 1] * inv),
+                                                        (e16)(oacc[4 * gg + 2] * inv), (e16)(oacc[4 * gg + 3] * inv)};
     }
     return;
   }
@@ -458,7 +495,7 @@ struct CombineParams {
   const float* opart; const float* mlg; int ngroups;      // per key group: partial O, (m, l)
   const float* ml; const rmem_attn_chunk* chunks; int nchunks;   // per table row: (m, l_row) -> mass
   int Lq, heads;
-  bf16* out; int ldo;
+  e16* out; int ldo;
   float* mass; int T;
   long out_cs, opart_cs, mlg_cs, ml_cs, mass_cs;     // per-clip strides (blockIdx.z = clip)
 };
@@ -490,7 +527,7 @@ __global__ __launch_bounds__(256) void k_attn_combine(CombineParams pin) {
     }
     if (live) {
       const f32x4 o = num * (1.f / den);
-      *reinterpret_cast<bf16x4*>(p.out + (long)q * p.ldo + head * D + 4 * G) = bf16x4{(bf16)o[0], (bf16)o[1], (bf16)o[2], (bf16)o[3]};
+      *reinterpret_cast<e16x4*>(p.out + (long)q * p.ldo + head * D + 4 * G) = e16x4{(e16)o[0], (e16)o[1], (e16)o[2], (e16)o[3]};
     }
   }
 }
@@ -529,76 +566,14 @@ __global__ __launch_bounds__(256) void k_attn_mass(CombineParams pin) {
   }
 }
 
-// ---- optional launch timing of the memory-read kernel (bench.py's roofline leg) ----
-__global__ void k_prof_nop() {}
-
-struct ProfState {
-  std::mutex mu;
-  std::atomic<bool> on{false};   // read by every memory-read launch without the lock; everything else under mu
-  float bracket_ms = 0.f;       // HIP-event bracket cost around an empty kernel (calibrated in rmem_profile_start)
-  std::vector<hipEvent_t> ev;   // pairs
-  std::vector<double> flops;
-  size_t used = 0;
-};
-ProfState g_prof;
-
 }  // namespace
 
-extern "C" int rmem_profile_start(int max_launches) {
-  std::lock_guard<std::mutex> lk(g_prof.mu);
-  RMEM_REQUIRE(max_launches > 0, "rmem_profile_start: max_launches must be > 0");
-  while (g_prof.ev.size() < (size_t)max_launches * 2) {
-    hipEvent_t e;
-    if (hipEventCreate(&e) != hipSuccess) { rmem_set_error("rmem_profile_start: hipEventCreate failed"); return -3; }
-    g_prof.ev.push_back(e);
-  }
-  g_prof.flops.assign(max_launches, 0.0);
-  g_prof.used = 0;
-  // calibrate what two event records around ONE launch cost by themselves: bracket an empty kernel on an idle stream,
-  // keep the minimum of 32 trials; rmem_profile_stop subtracts it from every timed launch
-  {
-    hipStream_t cs;
-    if (hipStreamCreate(&cs) == hipSuccess) {
-      float best = 1e9f;
-      for (int i = 0; i < 32; ++i) {
-        (void)hipEventRecord(g_prof.ev[0], cs);
-        hipLaunchKernelGGL(k_prof_nop, dim3(1), dim3(64), 0, cs);
-        (void)hipEventRecord(g_prof.ev[1], cs);
-        (void)hipEventSynchronize(g_prof.ev[1]);
-        float t = 0.f;
-        if (hipEventElapsedTime(&t, g_prof.ev[0], g_prof.ev[1]) == hipSuccess && t < best) best = t;
-      }
-      (void)hipStreamDestroy(cs);
-      g_prof.bracket_ms = best < 1e8f ? best : 0.f;
-    }
-  }
-  g_prof.on.store(true);
-  return 0;
-}
-
-extern "C" int rmem_profile_stop(double* total_ms, double* total_flops, int* launches) {
-  std::lock_guard<std::mutex> lk(g_prof.mu);
-  g_prof.on.store(false);
-  double ms = 0.0, fl = 0.0;
-  for (size_t i = 0; i < g_prof.used; ++i) {
-    float t = 0.f;
-    if (hipEventSynchronize(g_prof.ev[2 * i + 1]) != hipSuccess || hipEventElapsedTime(&t, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]) != hipSuccess) {
-      rmem_set_error("rmem_profile_stop: event query failed");
-      return -3;
-    }
-    ms += fmaxf(t - g_prof.bracket_ms, 0.f);
-    fl += g_prof.flops[i];
-  }
-  if (total_ms) *total_ms = ms;
-  if (total_flops) *total_flops = fl;
-  if (launches) *launches = (int)g_prof.used;
-  return 0;
-}
-
+#ifndef RMEM_F16
 extern "C" size_t rmem_attn_workspace_bytes(int Lq, int heads, int nchunks) {
   // worst case one group per table row: partial O (D floats) + group (m, l) + row (m, l) per (row, head, query)
   return (size_t)nchunks * heads * Lq * (D + 4) * sizeof(float);
 }
+#endif
 
 // workgroups a launch should have before several table rows are walked by one workgroup (7 per CU; experiments:
 // RMEM_ATTN_WGS).  Fewer, longer workgroups write fewer fp32 partials (none at all with one group).
@@ -608,7 +583,7 @@ static int attn_target_wgs() {
   return x > 0 ? x : 1792;
 }
 
-extern "C" int rmem_mem_read_attn_clips(const void* q, int ldq, const void* k_bank, const void* v_bank, long long slot_stride,
+extern "C" int RMEM_API(rmem_mem_read_attn_clips)(const void* q, int ldq, const void* k_bank, const void* v_bank, long long slot_stride,
                                         int ldkv, const rmem_attn_chunk* chunks, int nchunks, int lk_single,
                                         const float* pe_cur, const float* pe_mem, int Lq, int heads, void* out, int ldo,
                                         float* attn_mass, int T, int nclips, long long q_clip_stride, long long kv_clip_stride,
@@ -627,7 +602,7 @@ extern "C" int rmem_mem_read_attn_clips(const void* q, int ldq, const void* k_ba
   RMEM_REQUIRE(!pe_mem || chunks, "rmem_mem_read_attn: pe_mem needs a chunk table");
   hipStream_t s = (hipStream_t)stream;
   AttnParams p;
-  p.q = (const bf16*)q; p.ldq = ldq; p.k = (const bf16*)k_bank; p.v = (const bf16*)v_bank;
+  p.q = (const e16*)q; p.ldq = ldq; p.k = (const e16*)k_bank; p.v = (const e16*)v_bank;
   p.slot_stride = slot_stride; p.ldkv = ldkv; p.chunks = chunks; p.nchunks = nchunks;
   p.lk = lk_single; p.per_chunk = chunks ? 0 : (lk_single + nchunks - 1) / nchunks;
   RMEM_REQUIRE(chunks || (long)p.per_chunk * (nchunks - 1) < lk_single, "rmem_mem_read_attn: too many chunks for lk_single");
@@ -647,43 +622,31 @@ extern "C" int rmem_mem_read_attn_clips(const void* q, int ldq, const void* k_ba
   p.opart_cs = (long)p.ngroups * heads * Lq * D; p.mlg_cs = (long)p.ngroups * heads * Lq * 2; p.ml_cs = (long)nchunks * heads * Lq * 2;
   p.opart = (float*)workspace; p.mlg = p.opart + (size_t)nclips * p.opart_cs;
   p.ml = attn_mass ? p.mlg + (size_t)nclips * p.mlg_cs : nullptr;
-  p.out = (bf16*)out; p.ldo = ldo;
+  p.out = (e16*)out; p.ldo = ldo;
   dim3 grid(p.nq * heads * p.ngroups * nclips);
   if (chunks) {
-    // time this launch if asked to (never while the stream is being captured into a graph)
-    long slot_i = -1;
-    double keys = 0.0;
-    if (g_prof.on.load(std::memory_order_relaxed) && prof_keys > 0) {
-      hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-      (void)hipStreamIsCapturing(s, &cs);
-      if (cs == hipStreamCaptureStatusNone) {
-        std::lock_guard<std::mutex> lk(g_prof.mu);
-        if (g_prof.on.load() && g_prof.used * 2 + 1 < g_prof.ev.size()) { slot_i = (long)g_prof.used++; keys = (double)prof_keys; }
-      }
-    }
-    if (slot_i >= 0) (void)hipEventRecord(g_prof.ev[2 * slot_i], s);
+    // time this launch if asked to (rmem_profile_start; never while the stream is being captured into a graph)
+    const int slot_i = prof_keys > 0 ? rmem_prof_begin(RMEM_PROF_MEM_READ, s, 4.0 * (double)Lq * (double)prof_keys * (double)(heads * D) * nclips)
+                                     : -1;                                                  // FLOPs: QK^T + PV
     if (slot_i >= 0) hipLaunchKernelGGL((k_attn_partial<true, true>), grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL((k_attn_partial<true, false>), grid, dim3(256), 0, s, p);
-    if (slot_i >= 0) {
-      (void)hipEventRecord(g_prof.ev[2 * slot_i + 1], s);
-      g_prof.flops[slot_i] = 4.0 * (double)Lq * keys * (double)(heads * D) * nclips;   // QK^T + PV
-    }
+    if (slot_i >= 0) rmem_prof_end(RMEM_PROF_MEM_READ, slot_i, s);
   } else {
     hipLaunchKernelGGL((k_attn_partial<false, false>), grid, dim3(256), 0, s, p);
   }
   CombineParams cp;
   cp.opart = p.opart; cp.mlg = p.mlg; cp.ngroups = p.ngroups; cp.ml = p.ml; cp.chunks = chunks; cp.nchunks = nchunks;
-  cp.Lq = Lq; cp.heads = heads; cp.out = (bf16*)out; cp.ldo = ldo; cp.mass = attn_mass; cp.T = T;
+  cp.Lq = Lq; cp.heads = heads; cp.out = (e16*)out; cp.ldo = ldo; cp.mass = attn_mass; cp.T = T;
   cp.out_cs = out_clip_stride; cp.opart_cs = p.opart_cs; cp.mlg_cs = p.mlg_cs; cp.ml_cs = p.ml_cs; cp.mass_cs = (long)Lq * T;
   if (p.ngroups > 1) hipLaunchKernelGGL(k_attn_combine, dim3((Lq + 63) / 64, 16, nclips), dim3(256), 0, s, cp);
   if (attn_mass) hipLaunchKernelGGL(k_attn_mass, dim3((Lq + 63) / 64, 1, nclips), dim3(256), 0, s, cp);
   return rmem_check_launch("rmem_mem_read_attn");
 }
 
-extern "C" int rmem_mem_read_attn(const void* q, int ldq, const void* k_bank, const void* v_bank, long long slot_stride,
+extern "C" int RMEM_API(rmem_mem_read_attn)(const void* q, int ldq, const void* k_bank, const void* v_bank, long long slot_stride,
                                   int ldkv, const rmem_attn_chunk* chunks, int nchunks, int lk_single,
                                   const float* pe_cur, const float* pe_mem, int Lq, int heads, void* out, int ldo,
                                   float* attn_mass, int T, void* workspace, void* stream) {
-  return rmem_mem_read_attn_clips(q, ldq, k_bank, v_bank, slot_stride, ldkv, chunks, nchunks, lk_single, pe_cur, pe_mem, Lq, heads, out,
+  return RMEM_API(rmem_mem_read_attn_clips)(q, ldq, k_bank, v_bank, slot_stride, ldkv, chunks, nchunks, lk_single, pe_cur, pe_mem, Lq, heads, out,
                                   ldo, attn_mass, T, 1, 0, 0, 0, workspace, stream);
 }

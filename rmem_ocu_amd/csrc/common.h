@@ -3,10 +3,26 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-typedef __bf16 bf16;
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+// The 16-bit element type of activations, weights and the memory bank.  Every kernel translation unit is compiled twice:
+// once with e16 = bfloat16 (the entry points of include/rmem.h under their plain names) and once with -DRMEM_F16, e16 = IEEE
+// half, exported as <name>_f16 -- the operand type of the reference's --amp path (tools/eval.py:45-47, torch autocast) and of
+// BASELINE cfg 5.  Accumulation, residual streams, softmax statistics and normalisation statistics are fp32 in both.
+#ifdef RMEM_F16
+typedef _Float16 e16;
+#define RMEM_API(name) name##_f16
+#define RMEM_MFMA_32x32x16 __builtin_amdgcn_mfma_f32_32x32x16_f16
+#define RMEM_MFMA_16x16x32 __builtin_amdgcn_mfma_f32_16x16x32_f16
+#define RMEM_MFMA_32x32x16_ASM "v_mfma_f32_32x32x16_f16"
+#else
+typedef __bf16 e16;
+#define RMEM_API(name) name
+#define RMEM_MFMA_32x32x16 __builtin_amdgcn_mfma_f32_32x32x16_bf16
+#define RMEM_MFMA_16x16x32 __builtin_amdgcn_mfma_f32_16x16x32_bf16
+#define RMEM_MFMA_32x32x16_ASM "v_mfma_f32_32x32x16_bf16"
+#endif
+typedef __attribute__((ext_vector_type(2))) e16 e16x2;
+typedef __attribute__((ext_vector_type(4))) e16 e16x4;
+typedef __attribute__((ext_vector_type(8))) e16 e16x8;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -42,9 +58,14 @@ __device__ __forceinline__ float rmem_bilerp(float a, float b, float c, float d,
   return __builtin_fmaf(bot, wy, top * uy);
 }
 
-// error plumbing shared by the C-ABI translation units (api.cpp owns the storage)
+// error plumbing shared by the C-ABI translation units (api.hip owns the storage)
 extern "C" void rmem_set_error(const char* msg);
 int rmem_check_launch(const char* what);
+// opt-in launch timers (api.hip): channel 0 = memory-read attention, 1 = gated attention's value GEMM.  begin() returns a slot
+// (>= 0) after recording the start event on the stream, or -1 when the channel is off, full, or the stream is being captured.
+enum { RMEM_PROF_MEM_READ = 0, RMEM_PROF_GATED_PV = 1 };
+int rmem_prof_begin(int channel, void* stream, double flops);
+void rmem_prof_end(int channel, int slot, void* stream);
 
 #define RMEM_REQUIRE(cond, msg)        \
   do {                                 \

@@ -7,16 +7,16 @@
 //
 // With one head the value side (2 * Lq * Lk * 1024 flop) outweighs the score side (2 * Lq * Lk * 128) eight to one, and
 // one 128 x Lk score matrix serves all 1024 value columns.  So, unlike the d = 32 memory read (attention.hip), the
-// probabilities are materialised ONCE in bf16 and the value side runs as a plain tiled GEMM:
+// probabilities are materialised ONCE in e16 and the value side runs as a plain tiled GEMM:
 //   k_gp_scores<., 0>  S = Q K^T (+ temporal-PE bias | window mask + relative embedding)  ->  per-chunk row maxima
-//   k_gp_scores<., 1>  same S again (6.5 GFLOP at cfg 2, cheaper than storing fp32 S)     ->  P = exp2(S - max) in bf16,
+//   k_gp_scores<., 1>  same S again (6.5 GFLOP at cfg 2, cheaper than storing fp32 S)     ->  P = exp2(S - max) in e16,
 //                      [Lq][frames * Lp] with every 64-key tile fully written (zeros past a frame's end); per-chunk row sums
 //   k_gp_pv            O = P V: 128 x 256 output tile per workgroup, 4 waves of 64 x 128, 64-key steps, P and V tiles
 //                      through a 3-deep LDS ring filled by global_load_lds (source-side XOR swizzle), V read transposed
 //                      (ds_read_b64_tr_b16); key groups give split-K slabs
-//   k_gp_combine       sum the slabs, 1 / row sum, gate by U, bf16 (and the per-memory-frame probability mass)
+//   k_gp_combine       sum the slabs, 1 / row sum, gate by U, e16 (and the per-memory-frame probability mass)
 // Scores live in the log2 domain (Q pre-scaled by log2(e) / sqrt(128)).  Exact softmax: the maximum is the true row
-// maximum, so P <= 1 and the bf16 P keeps 8 significant bits at every magnitude.
+// maximum, so P <= 1 and the e16 P keeps 8 significant bits at every magnitude.
 #include "common.h"
 #include "../../include/rmem.h"
 #include <math.h>
@@ -43,14 +43,14 @@ __device__ uint4 g_gp_zero16[1];
 struct GpRow { int slot, kb, kn, pe_slot, t; };
 
 struct GpParams {
-  const bf16* q; int ldq;
-  const bf16* k; long k_slot_stride; int ldk;
-  const bf16* v; long v_slot_stride; int ldv;
+  const e16* q; int ldq;
+  const e16* k; long k_slot_stride; int ldk;
+  const e16* v; long v_slot_stride; int ldv;
   const rmem_attn_chunk* rows; int nrows; int lk; int per;
   const float* pe_cur; const float* pe_mem;
   int Lq, Lqp;             // Lqp: Lq rounded up to QT (row count of P, mpart, lpart, slabs)
   int Lp; int ldp;         // P columns per memory frame (multiple of 64), P row stride
-  float* mpart; float* lpart; bf16* P;
+  float* mpart; float* lpart; e16* P;
   float qscale;
   int H, W; const float* rel; int ldrel;      // local-window mode
   int DV, nq, ncs, groups, rows_per_group;
@@ -87,40 +87,40 @@ __device__ __forceinline__ float half_sum(float v) {
 // 4 waves = (query half qh) x (key half kh): a wave owns 64 queries x 32 keys of every 64-key tile.  S = Q K^T with the
 // query on the MFMA row: A = Q fragments (registers, whole kernel), B = K rows from LDS ([key][128], 16-byte chunks
 // XOR-swizzled by key & 15).  The accumulator then has the KEY on the lane and 16 query rows per block in registers, so a
-// row of P leaves as 32 consecutive bf16.
+// row of P leaves as 32 consecutive e16.
 template <int MODE, int PASS>
 __global__ __launch_bounds__(256) void k_gp_scores(GpParams p) {
-  __shared__ __attribute__((aligned(16))) bf16 Ks[2][KT * DQ];
+  __shared__ __attribute__((aligned(16))) e16 Ks[2][KT * DQ];
   __shared__ float red[2][QT];
   __shared__ float mq[QT];
-  __shared__ __attribute__((aligned(16))) bf16 Pst[PASS == 1 ? 4 : 1][32 * 32];
+  __shared__ __attribute__((aligned(16))) e16 Pst[PASS == 1 ? 4 : 1][32 * 32];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int qh = wave >> 1, kh = wave & 1, lq = lane & 31, kg = lane >> 5;
   const int q0 = blockIdx.x * QT;
   const GpRow row = get_row<MODE>(p, blockIdx.y);
-  const bf16* Kp = p.k + (long)row.slot * p.k_slot_stride + (long)row.kb * p.ldk;
+  const e16* Kp = p.k + (long)row.slot * p.k_slot_stride + (long)row.kb * p.ldk;
   const bool has_cur = MODE == 1 && p.pe_cur != nullptr;
   const bool has_mem = MODE == 1 && row.pe_slot >= 0 && p.pe_mem != nullptr;
 
   // ---- Q fragments (A operand): query rows 64 qh + 32 b + (lane & 31), d = 16 s + 8 kg .. + 7 ----
-  bf16x8 qf[2][8];
+  e16x8 qf[2][8];
 #pragma unroll
   for (int b = 0; b < 2; ++b) {
     const int qrow = min(q0 + 64 * qh + 32 * b + lq, p.Lq - 1);
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
       const int d0 = 16 * s + 8 * kg;
-      const bf16x8 raw = *reinterpret_cast<const bf16x8*>(p.q + (long)qrow * p.ldq + d0);
+      const e16x8 raw = *reinterpret_cast<const e16x8*>(p.q + (long)qrow * p.ldq + d0);
       f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0;
       if (has_cur) { c0 = *reinterpret_cast<const f32x4*>(p.pe_cur + d0); c1 = *reinterpret_cast<const f32x4*>(p.pe_cur + d0 + 4); }
 #pragma unroll
-      for (int j = 0; j < 8; ++j) qf[b][s][j] = (bf16)(((float)raw[j] + (j < 4 ? c0[j & 3] : c1[j & 3])) * p.qscale);
+      for (int j = 0; j < 8; ++j) qf[b][s][j] = (e16)(((float)raw[j] + (j < 4 ? c0[j & 3] : c1[j & 3])) * p.qscale);
     }
   }
 
   // ---- temporal-PE logit bias of this table row, per query: Qs . pe_mem[slot] through the matrix pipe.  The B operand is
-  // the embedding broadcast over all 32 columns (split into bf16 high + low parts: ~2^-17 relative), so every lane ends up
+  // the embedding broadcast over all 32 columns (split into e16 high + low parts: ~2^-17 relative), so every lane ends up
   // with the bias of exactly the 2 x 16 query rows its score accumulators hold ----
   f32x16 bacc[2];
 #pragma unroll
@@ -132,17 +132,17 @@ __global__ __launch_bounds__(256) void k_gp_scores(GpParams p) {
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
       const f32x4 e0 = *reinterpret_cast<const f32x4*>(pm + 16 * s), e1 = *reinterpret_cast<const f32x4*>(pm + 16 * s + 4);
-      bf16x8 hi8, lo8;
+      e16x8 hi8, lo8;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const float e = j < 4 ? e0[j & 3] : e1[j & 3];
-        hi8[j] = (bf16)e;
-        lo8[j] = (bf16)(e - (float)hi8[j]);
+        hi8[j] = (e16)e;
+        lo8[j] = (e16)(e - (float)hi8[j]);
       }
 #pragma unroll
       for (int b = 0; b < 2; ++b) {
-        bacc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[b][s], hi8, bacc[b], 0, 0, 0);
-        bacc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[b][s], lo8, bacc[b], 0, 0, 0);
+        bacc[b] = RMEM_MFMA_32x32x16(qf[b][s], hi8, bacc[b], 0, 0, 0);
+        bacc[b] = RMEM_MFMA_32x32x16(qf[b][s], lo8, bacc[b], 0, 0, 0);
       }
     }
   }
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256) void k_gp_scores(GpParams p) {
     if (t_hi < t_lo) t_hi = t_lo;
   }
   if (p.debug & 4) t_hi = t_lo;
-  bf16* Pq = p.P + (long)row.t * p.Lp + row.kb;       // + q * ldp + key index inside the row
+  e16* Pq = p.P + (long)row.t * p.Lp + row.kb;       // + q * ldp + key index inside the row
   float mx[2][16];       // PASS 0: running maxima of this lane's rows
   float ls4[4] = {0.f, 0.f, 0.f, 0.f};   // PASS 1: row-sum pieces of rows 16 i + (lane >> 2), keys 8 (lane & 3) .. + 7 of every tile
 #pragma unroll
@@ -198,21 +198,21 @@ __global__ __launch_bounds__(256) void k_gp_scores(GpParams p) {
     for (int r = 0; r < 16; ++r) cinit[b][r] = off[b][r];
 
   // staging: thread -> 4 x (key, 16-byte chunk) of the 64 x 256 B tile
-  bf16x8 rk[4];
-  const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+  e16x8 rk[4];
+  const e16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
   auto load_tile = [&](int t) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int id = tid + 256 * i, key = id >> 4, chunk = id & 15;
       const int kidx = t * KT + key;
-      rk[i] = kidx < row.kn ? *reinterpret_cast<const bf16x8*>(Kp + (long)kidx * p.ldk + chunk * 8) : zero8;
+      rk[i] = kidx < row.kn ? *reinterpret_cast<const e16x8*>(Kp + (long)kidx * p.ldk + chunk * 8) : zero8;
     }
   };
   auto store_tile = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int id = tid + 256 * i, key = id >> 4, chunk = id & 15;
-      *reinterpret_cast<bf16x8*>(&Ks[buf][key * DQ + ((chunk ^ (key & 15)) << 3)]) = rk[i];
+      *reinterpret_cast<e16x8*>(&Ks[buf][key * DQ + ((chunk ^ (key & 15)) << 3)]) = rk[i];
     }
   };
 
@@ -222,16 +222,16 @@ __global__ __launch_bounds__(256) void k_gp_scores(GpParams p) {
   }
   __syncthreads();
   const int kl = 32 * kh + lq;                        // this lane's key inside a tile
-  bf16* pst = &Pst[wave][0];                          // this wave's [64 q][32 keys] transposition pad
+  e16* pst = &Pst[wave][0];                          // this wave's [64 q][32 keys] transposition pad
   for (int t = t_lo; t < t_hi; ++t) {
     const int cur = (t - t_lo) & 1;
     if (t + 1 < t_hi) load_tile(t + 1);
     f32x16 acc[2];
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
-      const bf16x8 kf = *reinterpret_cast<const bf16x8*>(&Ks[cur][kl * DQ + (((2 * s + kg) ^ (kl & 15)) << 3)]);
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[0][s], kf, s == 0 ? cinit[0] : acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[1][s], kf, s == 0 ? cinit[1] : acc[1], 0, 0, 0);
+      const e16x8 kf = *reinterpret_cast<const e16x8*>(&Ks[cur][kl * DQ + (((2 * s + kg) ^ (kl & 15)) << 3)]);
+      acc[0] = RMEM_MFMA_32x32x16(qf[0][s], kf, s == 0 ? cinit[0] : acc[0], 0, 0, 0);
+      acc[1] = RMEM_MFMA_32x32x16(qf[1][s], kf, s == 0 ? cinit[1] : acc[1], 0, 0, 0);
     }
     const int kidx = t * KT + kl;
     const bool kvalid = kidx < row.kn;
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(256) void k_gp_scores(GpParams p) {
           sv += rl[b][r] * LOG2E;
         }
         if (PASS == 0) mx[b][r] = fmaxf(mx[b][r], ok ? sv : NEG_BIG);
-        else pst[r32 * 32 + lq] = (bf16)(ok ? __builtin_amdgcn_exp2f(sv) : 0.f);
+        else pst[r32 * 32 + lq] = (e16)(ok ? __builtin_amdgcn_exp2f(sv) : 0.f);
       }
       if (PASS == 1) {
         // the wave's 32 x 32 block leaves as 16-byte pieces: lane -> (row 16 i + (lane >> 2), keys 8 (lane & 3) .. + 7).
@@ -279,8 +279,8 @@ __global__ __launch_bounds__(256) void k_gp_scores(GpParams p) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
           const int r32 = 16 * i + (lane >> 2);
-          const bf16x8 v = *reinterpret_cast<const bf16x8*>(&pst[r32 * 32 + (lane & 3) * 8]);
-          *reinterpret_cast<bf16x8*>(Pq + (long)(q0 + 64 * qh + 32 * b + r32) * p.ldp + t * KT + 32 * kh + (lane & 3) * 8) = v;
+          const e16x8 v = *reinterpret_cast<const e16x8*>(&pst[r32 * 32 + (lane & 3) * 8]);
+          *reinterpret_cast<e16x8*>(Pq + (long)(q0 + 64 * qh + 32 * b + r32) * p.ldp + t * KT + 32 * kh + (lane & 3) * 8) = v;
           float sum = 0.f;
 #pragma unroll
           for (int j = 0; j < 8; ++j) sum += (float)v[j];
@@ -335,11 +335,11 @@ __global__ __launch_bounds__(256) void k_gp_scores(GpParams p) {
 }
 
 // ---- P.V fragment plumbing (inline-asm LDS reads, counted waits) ----
-struct PvFrags { bf16x8 a[2]; s16x4 lo[4], hi[4]; };
+struct PvFrags { e16x8 a[2]; s16x4 lo[4], hi[4]; };
 constexpr int PV_PB = QT * KT * 2;            // bytes of the P tile in a stage (the V tile follows)
 
-__device__ __forceinline__ bf16x8 lds_b128(unsigned addr) {
-  bf16x8 v;
+__device__ __forceinline__ e16x8 lds_b128(unsigned addr) {
+  e16x8 v;
   asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
   return v;
 }
@@ -373,9 +373,9 @@ __device__ __forceinline__ void pv_mma(const PvFrags& f, f32x16 (&acc)[2][4]) {
   for (int c = 0; c < 4; ++c) {
     const __attribute__((ext_vector_type(8))) short b16 = {f.lo[c][0], f.lo[c][1], f.lo[c][2], f.lo[c][3],
                                                            f.hi[c][0], f.hi[c][1], f.hi[c][2], f.hi[c][3]};
-    const bf16x8 b = __builtin_bit_cast(bf16x8, b16);
-    acc[0][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[0], b, acc[0][c], 0, 0, 0);
-    acc[1][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[1], b, acc[1][c], 0, 0, 0);
+    const e16x8 b = __builtin_bit_cast(e16x8, b16);
+    acc[0][c] = RMEM_MFMA_32x32x16(f.a[0], b, acc[0][c], 0, 0, 0);
+    acc[1][c] = RMEM_MFMA_32x32x16(f.a[1], b, acc[1][c], 0, 0, 0);
   }
 }
 
@@ -453,8 +453,8 @@ __global__ __launch_bounds__(256) void k_gp_pv(GpParams p) {
   auto issue = [&](int stage) {
     char* Ps = smem + stage * SB;
     char* Vs = Ps + PB;
-    const bf16* psrc = p.P + ir_pc + i_t * KT;
-    const bf16* vsrc = p.v + (long)ir_slot * p.v_slot_stride + (long)(ir_kb + i_t * KT) * p.ldv;
+    const e16* psrc = p.P + ir_pc + i_t * KT;
+    const e16* vsrc = p.v + (long)ir_slot * p.v_slot_stride + (long)(ir_kb + i_t * KT) * p.ldv;
     const int left = ir_kn - i_t * KT;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -538,8 +538,8 @@ __global__ __launch_bounds__(256) void k_gp_pv(GpParams p) {
 
 struct GpCombine {
   const float* slabs; int groups; const float* lpart; int nrows; int Lq, Lqp, DV;
-  const bf16* ua; int ldua; const bf16* ub; int ldub; int usplit;
-  bf16* out; int ldo;
+  const e16* ua; int ldua; const e16* ub; int ldub; int usplit;
+  e16* out; int ldo;
   const rmem_attn_chunk* rows; float* mass; int T;
   const float* dw; int H, W;        // optional: depth-wise 5x5 (weights [25][DV]) applied to the gated output in the same launch
 };
@@ -560,28 +560,28 @@ __global__ __launch_bounds__(256) void k_gp_combine(GpCombine p) {
     for (int j = 0; j < 4; ++j) { v[j] += a[j]; v[4 + j] += b[j]; }
   }
   const float inv = 1.f / l;
-  bf16x8 o;
+  e16x8 o;
   if (c < p.usplit) {
-    const bf16x8 u = *reinterpret_cast<const bf16x8*>(p.ua + (long)q * p.ldua + c);
+    const e16x8 u = *reinterpret_cast<const e16x8*>(p.ua + (long)q * p.ldua + c);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = (bf16)(v[j] * inv * (float)u[j]);
+    for (int j = 0; j < 8; ++j) o[j] = (e16)(v[j] * inv * (float)u[j]);
   } else if (p.ub) {
-    const bf16x8 u = *reinterpret_cast<const bf16x8*>(p.ub + (long)q * p.ldub + (c - p.usplit));
+    const e16x8 u = *reinterpret_cast<const e16x8*>(p.ub + (long)q * p.ldub + (c - p.usplit));
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = (bf16)(v[j] * inv * (float)u[j]);
+    for (int j = 0; j < 8; ++j) o[j] = (e16)(v[j] * inv * (float)u[j]);
   } else {                                          // torch.ones_like(curr_U) half of layer 0 (transformer.py:1117-1118)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = (bf16)(v[j] * inv);
+    for (int j = 0; j < 8; ++j) o[j] = (e16)(v[j] * inv);
   }
-  *reinterpret_cast<bf16x8*>(p.out + (long)q * p.ldo + c) = o;
+  *reinterpret_cast<e16x8*>(p.out + (long)q * p.ldo + c) = o;
 }
 
 // combine + depth-wise 5x5 in one launch (attention.py:208-210: outputs * U -> dw_conv): a tile of 8 x 16 queries x 64 value
-// columns with its 2-pixel halo is combined ONCE into LDS (bf16, the rounding the two-launch path stores), then the 25 taps
+// columns with its 2-pixel halo is combined ONCE into LDS (e16, the rounding the two-launch path stores), then the 25 taps
 // read LDS.  Saves the [Lq, DV] round trip and a launch per attention call.
 constexpr int CT_H = 8, CT_W = 16, CT_C = 64, CT_HW = (CT_H + 4) * (CT_W + 4);
 __global__ __launch_bounds__(256) void k_gp_combine_dwconv(GpCombine p) {
-  __shared__ __attribute__((aligned(16))) bf16 tile[CT_HW * CT_C];
+  __shared__ __attribute__((aligned(16))) e16 tile[CT_HW * CT_C];
   __shared__ __attribute__((aligned(16))) float wl[25 * CT_C];
   __shared__ float inv_l[CT_HW];
   const int tid = threadIdx.x;
@@ -602,13 +602,13 @@ __global__ __launch_bounds__(256) void k_gp_combine_dwconv(GpCombine p) {
     inv_l[i] = v;
   }
   __syncthreads();
-  const bf16* up = c0 < p.usplit ? p.ua + c0 : (p.ub ? p.ub + (c0 - p.usplit) : nullptr);
+  const e16* up = c0 < p.usplit ? p.ua + c0 : (p.ub ? p.ub + (c0 - p.usplit) : nullptr);
   const int ldu = c0 < p.usplit ? p.ldua : p.ldub;
   for (int i = tid; i < CT_HW * (CT_C / 8); i += 256) {
     const int pix = i >> 3, ch8 = i & 7;
     const int hy = pix / (CT_W + 4), hx = pix - hy * (CT_W + 4);
     const int gy = ty * CT_H + hy - 2, gx = tx * CT_W + hx - 2;
-    bf16x8 o = {0, 0, 0, 0, 0, 0, 0, 0};
+    e16x8 o = {0, 0, 0, 0, 0, 0, 0, 0};
     if ((unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W) {
       const int q = gy * p.W + gx;
       float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -620,15 +620,15 @@ __global__ __launch_bounds__(256) void k_gp_combine_dwconv(GpCombine p) {
       }
       const float inv = inv_l[pix];
       if (up) {
-        const bf16x8 u = *reinterpret_cast<const bf16x8*>(up + (long)q * ldu + ch8 * 8);
+        const e16x8 u = *reinterpret_cast<const e16x8*>(up + (long)q * ldu + ch8 * 8);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = (bf16)(v[j] * inv * (float)u[j]);
+        for (int j = 0; j < 8; ++j) o[j] = (e16)(v[j] * inv * (float)u[j]);
       } else {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = (bf16)(v[j] * inv);
+        for (int j = 0; j < 8; ++j) o[j] = (e16)(v[j] * inv);
       }
     }
-    *reinterpret_cast<bf16x8*>(&tile[pix * CT_C + ch8 * 8]) = o;
+    *reinterpret_cast<e16x8*>(&tile[pix * CT_C + ch8 * 8]) = o;
   }
   __syncthreads();
 #pragma unroll
@@ -645,16 +645,16 @@ __global__ __launch_bounds__(256) void k_gp_combine_dwconv(GpCombine p) {
     for (int dx = 0; dx < 5; ++dx)                   // dx outer, dy inner: the summation order of k_dwconv5 (bit-identical)
 #pragma unroll
       for (int dy = 0; dy < 5; ++dy) {
-        const bf16x8 d = *reinterpret_cast<const bf16x8*>(&tile[((oy + dy) * (CT_W + 4) + ox + dx) * CT_C + ch8 * 8]);
+        const e16x8 d = *reinterpret_cast<const e16x8*>(&tile[((oy + dy) * (CT_W + 4) + ox + dx) * CT_C + ch8 * 8]);
         const float* wt = &wl[(dy * 5 + dx) * CT_C + ch8 * 8];
         const f32x4 w0 = *reinterpret_cast<const f32x4*>(wt), w1 = *reinterpret_cast<const f32x4*>(wt + 4);
 #pragma unroll
         for (int j = 0; j < 4; ++j) { acc[j] += (float)d[j] * w0[j]; acc[4 + j] += (float)d[4 + j] * w1[j]; }
       }
-    bf16x8 o;
+    e16x8 o;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = (bf16)acc[j];
-    *reinterpret_cast<bf16x8*>(p.out + ((long)gy * p.W + gx) * p.ldo + c0 + ch8 * 8) = o;
+    for (int j = 0; j < 8; ++j) o[j] = (e16)acc[j];
+    *reinterpret_cast<e16x8*>(p.out + ((long)gy * p.W + gx) * p.ldo + c0 + ch8 * 8) = o;
   }
 }
 
@@ -710,18 +710,6 @@ int check_common(const void* q, int ldq, const void* k, int ldk, const void* v, 
   return 0;
 }
 
-// ---- optional launch timing of k_gp_pv (bench.py's roofline leg for the DeAOT workload) ----
-struct GpProf {
-  bool on = false;
-  float bracket_ms = 0.f;
-  hipEvent_t ev[2 * 256];
-  bool have = false;
-  double flops[256];
-  int used = 0;
-};
-GpProf g_gprof;
-__global__ void k_gp_nop() {}
-
 template <int MODE>
 void launch_all(GpParams& p, const GpPlan& g, GpCombine& c, bool timed, double flops, hipStream_t s) {
   const dim3 sg(p.nq, p.nrows);
@@ -729,17 +717,10 @@ void launch_all(GpParams& p, const GpPlan& g, GpCombine& c, bool timed, double f
   hipLaunchKernelGGL((k_gp_scores<MODE, 1>), sg, dim3(256), 0, s, p);
   const dim3 pg(p.nq * p.ncs * p.groups);
   constexpr int PM = MODE == 1 ? 1 : 0;
-  int slot = -1;
-  if (timed && g_gprof.on && g_gprof.used < 256) {
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    (void)hipStreamIsCapturing(s, &cs);
-    if (cs == hipStreamCaptureStatusNone) slot = g_gprof.used++;
-  }
+  const int slot = timed ? rmem_prof_begin(RMEM_PROF_GATED_PV, s, flops) : -1;      // rmem_gated_profile_start: bench.py's DeAOT roofline leg
   if (slot >= 0) {
-    (void)hipEventRecord(g_gprof.ev[2 * slot], s);
     hipLaunchKernelGGL((k_gp_pv<PM, true>), pg, dim3(256), 0, s, p);
-    (void)hipEventRecord(g_gprof.ev[2 * slot + 1], s);
-    g_gprof.flops[slot] = flops;
+    rmem_prof_end(RMEM_PROF_GATED_PV, slot, s);
   } else {
     hipLaunchKernelGGL((k_gp_pv<PM, false>), pg, dim3(256), 0, s, p);
   }
@@ -751,56 +732,14 @@ void launch_all(GpParams& p, const GpPlan& g, GpCombine& c, bool timed, double f
 
 }  // namespace
 
-extern "C" int rmem_gated_profile_start(void) {
-  if (!g_gprof.have) {
-    for (int i = 0; i < 512; ++i)
-      if (hipEventCreate(&g_gprof.ev[i]) != hipSuccess) { rmem_set_error("rmem_gated_profile_start: hipEventCreate failed"); return -3; }
-    g_gprof.have = true;
-  }
-  hipStream_t cs;
-  float best = 1e9f;
-  if (hipStreamCreate(&cs) == hipSuccess) {
-    for (int i = 0; i < 32; ++i) {
-      (void)hipEventRecord(g_gprof.ev[0], cs);
-      hipLaunchKernelGGL(k_gp_nop, dim3(1), dim3(64), 0, cs);
-      (void)hipEventRecord(g_gprof.ev[1], cs);
-      (void)hipEventSynchronize(g_gprof.ev[1]);
-      float t = 0.f;
-      if (hipEventElapsedTime(&t, g_gprof.ev[0], g_gprof.ev[1]) == hipSuccess && t < best) best = t;
-    }
-    (void)hipStreamDestroy(cs);
-  }
-  g_gprof.bracket_ms = best < 1e8f ? best : 0.f;
-  g_gprof.used = 0;
-  g_gprof.on = true;
-  return 0;
-}
-
-extern "C" int rmem_gated_profile_stop(double* total_ms, double* total_flops, int* launches) {
-  g_gprof.on = false;
-  double ms = 0.0, fl = 0.0;
-  for (int i = 0; i < g_gprof.used; ++i) {
-    float t = 0.f;
-    if (hipEventSynchronize(g_gprof.ev[2 * i + 1]) != hipSuccess ||
-        hipEventElapsedTime(&t, g_gprof.ev[2 * i], g_gprof.ev[2 * i + 1]) != hipSuccess) {
-      rmem_set_error("rmem_gated_profile_stop: event query failed");
-      return -3;
-    }
-    ms += fmaxf(t - g_gprof.bracket_ms, 0.f);
-    fl += g_gprof.flops[i];
-  }
-  if (total_ms) *total_ms = ms;
-  if (total_flops) *total_flops = fl;
-  if (launches) *launches = g_gprof.used;
-  return 0;
-}
-
+#ifndef RMEM_F16
 extern "C" size_t rmem_gated_attn_workspace_bytes(int Lq, int DV, int frames, int keys_per_frame, int nrows) {
   if (Lq <= 0 || DV < CW || DV % CW || frames < 1 || keys_per_frame < 1 || nrows < 1 || nrows > MAX_ROWS) return 0;
   return plan(Lq, DV, frames, keys_per_frame, nrows).total;
 }
+#endif
 
-extern "C" int rmem_gated_attn(const void* q, int ldq, const void* k_bank, long long k_slot_stride, int ldk, const void* v_bank,
+extern "C" int RMEM_API(rmem_gated_attn)(const void* q, int ldq, const void* k_bank, long long k_slot_stride, int ldk, const void* v_bank,
                                long long v_slot_stride, int ldv, const rmem_attn_chunk* chunks, int nchunks, int frames,
                                int keys_per_frame, const float* pe_cur, const float* pe_mem, int Lq, int DV, const void* u_a,
                                int ldua, const void* u_b, int ldub, int usplit, void* out, int ldo, float* attn_mass,
@@ -814,8 +753,8 @@ extern "C" int rmem_gated_attn(const void* q, int ldq, const void* k_bank, long 
   RMEM_REQUIRE(k_slot_stride % 8 == 0 && v_slot_stride % 8 == 0, "rmem_gated_attn: slot strides must be multiples of 8 elements");
   RMEM_REQUIRE(!dw_w_t || (H > 0 && W > 0 && H * W == Lq && usplit % 64 == 0), "rmem_gated_attn: the fused depth-wise conv needs H * W == Lq and usplit % 64 == 0");
   GpParams p = {};
-  p.q = (const bf16*)q; p.ldq = ldq; p.k = (const bf16*)k_bank; p.k_slot_stride = k_slot_stride; p.ldk = ldk;
-  p.v = (const bf16*)v_bank; p.v_slot_stride = v_slot_stride; p.ldv = ldv;
+  p.q = (const e16*)q; p.ldq = ldq; p.k = (const e16*)k_bank; p.k_slot_stride = k_slot_stride; p.ldk = ldk;
+  p.v = (const e16*)v_bank; p.v_slot_stride = v_slot_stride; p.ldv = ldv;
   p.rows = chunks; p.lk = keys_per_frame;
   int nrows = nchunks;
   if (!chunks) {                 // one key frame cut into ranges that start on tile boundaries
@@ -827,14 +766,14 @@ extern "C" int rmem_gated_attn(const void* q, int ldq, const void* k_bank, long 
   p.pe_cur = pe_cur; p.pe_mem = pe_mem; p.Lq = Lq; p.Lqp = g.Lqp; p.Lp = g.Lp; p.ldp = g.ldp;
   RMEM_REQUIRE((long)g.Lqp * g.ldp < (1L << 31), "rmem_gated_attn: probability matrix exceeds 2^31 elements");
   char* ws = (char*)workspace;
-  p.mpart = (float*)ws; p.lpart = (float*)(ws + g.off_l); p.P = (bf16*)(ws + g.off_p); p.slabs = (float*)(ws + g.off_s);
+  p.mpart = (float*)ws; p.lpart = (float*)(ws + g.off_l); p.P = (e16*)(ws + g.off_p); p.slabs = (float*)(ws + g.off_s);
   p.qscale = LOG2E / sqrtf((float)DQ);
   p.DV = DV; p.nq = g.Lqp / QT; p.ncs = DV / CW; p.groups = g.groups; p.rows_per_group = g.rpg;
   { static const int dbg = getenv("RMEM_GP_DEBUG") ? atoi(getenv("RMEM_GP_DEBUG")) : 0; p.debug = dbg; }
   GpCombine c = {};
   c.slabs = p.slabs; c.groups = g.groups; c.lpart = p.lpart; c.nrows = nrows; c.Lq = Lq; c.Lqp = g.Lqp; c.DV = DV;
-  c.ua = (const bf16*)u_a; c.ldua = ldua; c.ub = (const bf16*)u_b; c.ldub = ldub; c.usplit = usplit;
-  c.out = (bf16*)out; c.ldo = ldo; c.rows = chunks; c.mass = attn_mass; c.T = frames;
+  c.ua = (const e16*)u_a; c.ldua = ldua; c.ub = (const e16*)u_b; c.ldub = ldub; c.usplit = usplit;
+  c.out = (e16*)out; c.ldo = ldo; c.rows = chunks; c.mass = attn_mass; c.T = frames;
   c.dw = dw_w_t; c.H = H; c.W = W;
   hipStream_t s = (hipStream_t)stream;
   const double flops = 2.0 * (double)Lq * (double)frames * (double)keys_per_frame * (double)DV;
@@ -843,14 +782,14 @@ extern "C" int rmem_gated_attn(const void* q, int ldq, const void* k_bank, long 
   return rmem_check_launch("rmem_gated_attn");
 }
 
-extern "C" int rmem_local_gated_attn(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const float* rel,
+extern "C" int RMEM_API(rmem_local_gated_attn)(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const float* rel,
                                      int ldrel, int H, int W, int DV, const void* u_a, int ldua, const void* u_b, int ldub,
                                      int usplit, void* out, int ldo, const float* dw_w_t, void* workspace, void* stream) {
   const int L = H * W;
   if (check_common(q, ldq, k, ldk, v, ldv, L, DV, u_a, ldua, u_b, ldub, usplit, out, ldo, workspace, "rmem_local_gated_attn")) return -1;
   RMEM_REQUIRE(rel && H > 0 && W > 0 && W < 32768 && ldrel >= WIN * WIN, "rmem_local_gated_attn: bad rel / H / W");
   GpParams p = {};
-  p.q = (const bf16*)q; p.ldq = ldq; p.k = (const bf16*)k; p.ldk = ldk; p.v = (const bf16*)v; p.ldv = ldv;
+  p.q = (const e16*)q; p.ldq = ldq; p.k = (const e16*)k; p.ldk = ldk; p.v = (const e16*)v; p.ldv = ldv;
   p.lk = L;
   const int want = 8;
   p.per = ((L + want - 1) / want + KT - 1) / KT * KT;
@@ -858,15 +797,15 @@ extern "C" int rmem_local_gated_attn(const void* q, int ldq, const void* k, int 
   const GpPlan g = plan(L, DV, 1, L, p.nrows);
   p.Lq = L; p.Lqp = g.Lqp; p.Lp = g.Lp; p.ldp = g.ldp;
   char* ws = (char*)workspace;
-  p.mpart = (float*)ws; p.lpart = (float*)(ws + g.off_l); p.P = (bf16*)(ws + g.off_p); p.slabs = (float*)(ws + g.off_s);
+  p.mpart = (float*)ws; p.lpart = (float*)(ws + g.off_l); p.P = (e16*)(ws + g.off_p); p.slabs = (float*)(ws + g.off_s);
   p.qscale = LOG2E / sqrtf((float)DQ);
   p.H = H; p.W = W; p.rel = rel; p.ldrel = ldrel;
   p.DV = DV; p.nq = g.Lqp / QT; p.ncs = DV / CW; p.groups = g.groups; p.rows_per_group = g.rpg;
   { static const int dbg = getenv("RMEM_GP_DEBUG") ? atoi(getenv("RMEM_GP_DEBUG")) : 0; p.debug = dbg; }
   GpCombine c = {};
   c.slabs = p.slabs; c.groups = g.groups; c.lpart = p.lpart; c.nrows = p.nrows; c.Lq = L; c.Lqp = g.Lqp; c.DV = DV;
-  c.ua = (const bf16*)u_a; c.ldua = ldua; c.ub = (const bf16*)u_b; c.ldub = ldub; c.usplit = usplit;
-  c.out = (bf16*)out; c.ldo = ldo;
+  c.ua = (const e16*)u_a; c.ldua = ldua; c.ub = (const e16*)u_b; c.ldub = ldub; c.usplit = usplit;
+  c.out = (e16*)out; c.ldo = ldo;
   RMEM_REQUIRE(!dw_w_t || usplit % 64 == 0, "rmem_local_gated_attn: the fused depth-wise conv needs usplit % 64 == 0");
   c.dw = dw_w_t; c.H = H; c.W = W;
   launch_all<2>(p, g, c, false, 0.0, (hipStream_t)stream);

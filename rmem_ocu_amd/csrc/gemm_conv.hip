@@ -2,9 +2,9 @@
 //
 //   Y[m, n] = act( sum_k A[m, k] * Wt[n, k] + bias[n] (+ R[m, n]) )
 //
-// A is never materialised (im2col-free): m = (ho, wo) of an NHWC bf16 feature map
+// A is never materialised (im2col-free): m = (ho, wo) of an NHWC e16 feature map
 // and k = (kh, kw, ci) with ci fastest, gathered straight from HBM in 16-byte
-// (8 x bf16) pieces with zero fill outside the image.  A linear layer is the
+// (8 x e16) pieces with zero fill outside the image.  A linear layer is the
 // 1x1 case (H = rows, W = 1).  Replaces the cuDNN/MIOpen conv + addmm call sites
 // of the reference (encoders/resnet.py:48-68,
 // decoders/fpn.py:36-68, layers/transformer.py:576, 675, 685, models/aot.py:112, 133).
@@ -32,12 +32,12 @@
 namespace {
 
 struct ConvParams {
-  const bf16* x;
-  const bf16* w;
+  const e16* x;
+  const e16* w;
   const float* bias;
   const void* res;
   void* y;
-  bf16* y2;
+  e16* y2;
   float* slabs;          // split-K partials [splits][M][Cout] (fp32) or null
   int H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad;
   int M, K, HoWo;
@@ -45,17 +45,17 @@ struct ConvParams {
   int relu, out_f32, res_f32;
   int ldx;               // input row stride of the 1x1 (GEMM) case
   int act_begin;         // first output channel the activation applies to (multiple of 8)
-  int up_h, up_w, up_align;   // > 0: the (bf16) residual is a [batch][up_h][up_w] map, bilinearly resized to (Ho, Wo) on the fly
+  int up_h, up_w, up_align;   // > 0: the (e16) residual is a [batch][up_h][up_w] map, bilinearly resized to (Ho, Wo) on the fly
   int steps_per_split;   // k-steps (of 32) per gridDim.z slice
   int vec_ok;            // all leading dimensions / pointers allow 8-wide vector access
   long x_elems;          // addressable span of x in elements (fast path: buffer descriptor range)
-  const bf16* x2;        // dual form: second A source, NHWC [batch][H2][W2][Cin2] sampled at stride2; k >= Cin comes from it
+  const e16* x2;        // dual form: second A source, NHWC [batch][H2][W2][Cin2] sampled at stride2; k >= Cin comes from it
   int H2, W2, Cin2, stride2;
   long x2_elems;
   int fast_ok;           // 1: Cin % 64 == 0, <= 32 taps, x and w below 2 GB: scalar k-walk + hardware zero fill; 2: row-run form
 };
 
-// LDS tile rows are 128 B (BK = 64 bf16 = 8 chunks of 16 B).  Physical chunk = chunk ^ ((row >> 1) & 7): the 16 lanes of
+// LDS tile rows are 128 B (BK = 64 e16 = 8 chunks of 16 B).  Physical chunk = chunk ^ ((row >> 1) & 7): the 16 lanes of
 // every ds_read_b128 lane group (rows r..r+3, r+12..r+15 at chunk c and rows r+4..r+11 at chunk c+1) then land on 16
 // distinct 16-byte slots of the 256-byte bank row.
 __device__ __forceinline__ int swz(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 1) & 7)) << 3); }
@@ -68,25 +68,25 @@ __device__ __forceinline__ void finish8(const ConvParams& p, int m, int n, float
     for (int j = 0; j < 4; ++j) { v[j] += b0[j]; v[4 + j] += b1[j]; }
   }
   if (p.y2) {
-    bf16x8 o;
+    e16x8 o;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = (bf16)v[j];
-    *reinterpret_cast<bf16x8*>(p.y2 + (long)m * p.ld2 + n) = o;
+    for (int j = 0; j < 8; ++j) o[j] = (e16)v[j];
+    *reinterpret_cast<e16x8*>(p.y2 + (long)m * p.ld2 + n) = o;
   }
   if (p.res && p.up_h > 0) {
-    // same arithmetic and the same bf16 rounding as k_bilinear_nhwc followed by a plain residual add
+    // same arithmetic and the same e16 rounding as k_bilinear_nhwc followed by a plain residual add
     const int img = m / p.HoWo, rem = m - img * p.HoWo;
     const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
     int y0, y1, x0, x1; float wy, wx;
     rmem_src_coord(oy, p.up_h, p.Ho, p.up_align, y0, y1, wy);
     rmem_src_coord(ox, p.up_w, p.Wo, p.up_align, x0, x1, wx);
-    const bf16* rb = reinterpret_cast<const bf16*>(p.res) + (long)img * p.up_h * p.up_w * p.ldr + n;
-    const bf16x8 a = *reinterpret_cast<const bf16x8*>(rb + ((long)y0 * p.up_w + x0) * p.ldr);
-    const bf16x8 b = *reinterpret_cast<const bf16x8*>(rb + ((long)y0 * p.up_w + x1) * p.ldr);
-    const bf16x8 c = *reinterpret_cast<const bf16x8*>(rb + ((long)y1 * p.up_w + x0) * p.ldr);
-    const bf16x8 d = *reinterpret_cast<const bf16x8*>(rb + ((long)y1 * p.up_w + x1) * p.ldr);
+    const e16* rb = reinterpret_cast<const e16*>(p.res) + (long)img * p.up_h * p.up_w * p.ldr + n;
+    const e16x8 a = *reinterpret_cast<const e16x8*>(rb + ((long)y0 * p.up_w + x0) * p.ldr);
+    const e16x8 b = *reinterpret_cast<const e16x8*>(rb + ((long)y0 * p.up_w + x1) * p.ldr);
+    const e16x8 c = *reinterpret_cast<const e16x8*>(rb + ((long)y1 * p.up_w + x0) * p.ldr);
+    const e16x8 d = *reinterpret_cast<const e16x8*>(rb + ((long)y1 * p.up_w + x1) * p.ldr);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] += (float)(bf16)rmem_bilerp((float)a[j], (float)b[j], (float)c[j], (float)d[j], wx, wy);
+    for (int j = 0; j < 8; ++j) v[j] += (float)(e16)rmem_bilerp((float)a[j], (float)b[j], (float)c[j], (float)d[j], wx, wy);
   } else if (p.res) {
     if (p.res_f32) {
       const float* r = reinterpret_cast<const float*>(p.res) + (long)m * p.ldr + n;
@@ -94,7 +94,7 @@ __device__ __forceinline__ void finish8(const ConvParams& p, int m, int n, float
 #pragma unroll
       for (int j = 0; j < 4; ++j) { v[j] += r0[j]; v[4 + j] += r1[j]; }
     } else {
-      const bf16x8 r = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16*>(p.res) + (long)m * p.ldr + n);
+      const e16x8 r = *reinterpret_cast<const e16x8*>(reinterpret_cast<const e16*>(p.res) + (long)m * p.ldr + n);
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] += (float)r[j];
     }
@@ -116,27 +116,27 @@ __device__ __forceinline__ void finish8(const ConvParams& p, int m, int n, float
     *reinterpret_cast<f32x4*>(y) = f32x4{v[0], v[1], v[2], v[3]};
     *reinterpret_cast<f32x4*>(y + 4) = f32x4{v[4], v[5], v[6], v[7]};
   } else {
-    bf16x8 o;
+    e16x8 o;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = (bf16)v[j];
-    *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p.y) + (long)m * p.ldo + n) = o;
+    for (int j = 0; j < 8; ++j) o[j] = (e16)v[j];
+    *reinterpret_cast<e16x8*>(reinterpret_cast<e16*>(p.y) + (long)m * p.ldo + n) = o;
   }
 }
 
 // scalar tail (Cout not a multiple of 8, or unaligned leading dimensions)
 __device__ __forceinline__ void finish1(const ConvParams& p, int m, int n, float v) {
   if (p.bias) v += p.bias[n];
-  if (p.y2) p.y2[(long)m * p.ld2 + n] = (bf16)v;
+  if (p.y2) p.y2[(long)m * p.ld2 + n] = (e16)v;
   if (p.res)
     v += p.res_f32 ? reinterpret_cast<const float*>(p.res)[(long)m * p.ldr + n]
-                   : (float)reinterpret_cast<const bf16*>(p.res)[(long)m * p.ldr + n];
+                   : (float)reinterpret_cast<const e16*>(p.res)[(long)m * p.ldr + n];
   if (n >= p.act_begin) {
     if (p.relu == 1) v = fmaxf(v, 0.f);
     else if (p.relu == 2) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
     else if (p.relu == 3) v = v / (1.f + expf(-v));
   }
   if (p.out_f32) reinterpret_cast<float*>(p.y)[(long)m * p.ldo + n] = v;
-  else reinterpret_cast<bf16*>(p.y)[(long)m * p.ldo + n] = (bf16)v;
+  else reinterpret_cast<e16*>(p.y)[(long)m * p.ldo + n] = (e16)v;
 }
 
 template <int BM, int BN, int PF, bool IS1X1, bool SPLITK>
@@ -151,8 +151,8 @@ __global__ __launch_bounds__(256) void k_conv_gemm(ConvParams p) {
   constexpr int C_BYTES = (BM / 2) * CP * 4;
   constexpr int SMEM = AB_BYTES > C_BYTES ? AB_BYTES : C_BYTES;
   __shared__ __attribute__((aligned(16))) char smem[SMEM];
-  bf16* As = reinterpret_cast<bf16*>(smem);                 // [2][BM*64]
-  bf16* Bs = As + 2 * BM * BK;                              // [2][BN*64]
+  e16* As = reinterpret_cast<e16*>(smem);                 // [2][BM*64]
+  e16* Bs = As + 2 * BM * BK;                              // [2][BN*64]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -196,21 +196,21 @@ __global__ __launch_bounds__(256) void k_conv_gemm(ConvParams p) {
   }
   const int b_chunk = tid & 7;
 
-  const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+  const e16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
   // register ring: PF tiles of (A, B) pieces in flight from HBM/L2 while earlier tiles are being multiplied
-  bf16x8 ra[PF][NA], rb[PF][NB];
+  e16x8 ra[PF][NA], rb[PF][NB];
 
-  auto load_tile = [&](bf16x8 (&xa)[NA], bf16x8 (&xb)[NB], int k0) {
+  auto load_tile = [&](e16x8 (&xa)[NA], e16x8 (&xb)[NB], int k0) {
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-      bf16x8 v = zero8;
+      e16x8 v = zero8;
       if (IS1X1) {
         const int kidx = k0 + a_chunk * 8;
-        if (a_ok[i] && kidx < p.K) v = *reinterpret_cast<const bf16x8*>(p.x + a_base[i] + kidx);
+        if (a_ok[i] && kidx < p.K) v = *reinterpret_cast<const e16x8*>(p.x + a_base[i] + kidx);
       } else {
         const int hi = a_hi0[i] + a_kh, wi = a_wi0[i] + a_kw;
         if (a_ok[i] && a_kh < p.KH && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W)
-          v = *reinterpret_cast<const bf16x8*>(p.x + a_base[i] + ((long)hi * p.W + wi) * p.Cin + a_ci);
+          v = *reinterpret_cast<const e16x8*>(p.x + a_base[i] + ((long)hi * p.W + wi) * p.Cin + a_ci);
       }
       xa[i] = v;
     }
@@ -223,18 +223,18 @@ __global__ __launch_bounds__(256) void k_conv_gemm(ConvParams p) {
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-      bf16x8 v = zero8;
+      e16x8 v = zero8;
       const int n = n0 + (tid >> 3) + i * 32;
       const int kidx = k0 + b_chunk * 8;
-      if (n < p.Cout && kidx < p.K) v = *reinterpret_cast<const bf16x8*>(p.w + (long)n * p.K + kidx);
+      if (n < p.Cout && kidx < p.K) v = *reinterpret_cast<const e16x8*>(p.w + (long)n * p.K + kidx);
       xb[i] = v;
     }
   };
-  auto store_tile = [&](const bf16x8 (&xa)[NA], const bf16x8 (&xb)[NB], int buf) {
+  auto store_tile = [&](const e16x8 (&xa)[NA], const e16x8 (&xb)[NB], int buf) {
 #pragma unroll
-    for (int i = 0; i < NA; ++i) *reinterpret_cast<bf16x8*>(&As[buf * BM * BK + swz((tid >> 3) + i * 32, a_chunk)]) = xa[i];
+    for (int i = 0; i < NA; ++i) *reinterpret_cast<e16x8*>(&As[buf * BM * BK + swz((tid >> 3) + i * 32, a_chunk)]) = xa[i];
 #pragma unroll
-    for (int i = 0; i < NB; ++i) *reinterpret_cast<bf16x8*>(&Bs[buf * BN * BK + swz((tid >> 3) + i * 32, b_chunk)]) = xb[i];
+    for (int i = 0; i < NB; ++i) *reinterpret_cast<e16x8*>(&Bs[buf * BN * BK + swz((tid >> 3) + i * 32, b_chunk)]) = xb[i];
   };
 
   f32x4 acc[TM][TN];
@@ -260,18 +260,18 @@ __global__ __launch_bounds__(256) void k_conv_gemm(ConvParams p) {
         if (kt + PF < kt1) load_tile(ra[u], rb[u], (kt + PF) * BK);     // slot u was drained into LDS one step ago
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-          bf16x8 af[TM], bfr[TN];
+          e16x8 af[TM], bfr[TN];
 #pragma unroll
           for (int i = 0; i < TM; ++i)
-            af[i] = *reinterpret_cast<const bf16x8*>(&As[cur * BM * BK + swz(wm * (BM / 2) + i * 16 + fr, 4 * ks + fc)]);
+            af[i] = *reinterpret_cast<const e16x8*>(&As[cur * BM * BK + swz(wm * (BM / 2) + i * 16 + fr, 4 * ks + fc)]);
 #pragma unroll
           for (int j = 0; j < TN; ++j)
-            bfr[j] = *reinterpret_cast<const bf16x8*>(&Bs[cur * BN * BK + swz(wn * (BN / 2) + j * 16 + fr, 4 * ks + fc)]);
+            bfr[j] = *reinterpret_cast<const e16x8*>(&Bs[cur * BN * BK + swz(wn * (BN / 2) + j * 16 + fr, 4 * ks + fc)]);
 #pragma unroll
           for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+              acc[i][j] = RMEM_MFMA_16x16x32(af[i], bfr[j], acc[i][j], 0, 0, 0);
         }
         if (kt + 1 < kt1) store_tile(ra[(u + 1) % PF], rb[(u + 1) % PF], cur ^ 1);
         __syncthreads();
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(256) void k_conv_gemm(ConvParams p) {
 // register-staged kernel).  Each wave-instruction fills 8 rows x 128 B of the tile linearly, so the XOR swizzle is
 // applied to the per-lane SOURCE address; padded / out-of-range pieces read a 16-byte zero buffer.  ST-deep LDS ring with
 // counted vmcnt + raw s_barrier; the default is ST = 1 (a single 16 KB buffer, 8 workgroups per CU: see launch()).
-__device__ uint4 g_zero16[1];
+static __device__ uint4 g_zero16[1];
 
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -566,20 +566,20 @@ __device__ __forceinline__ void conv_gemm_dma_body(const ConvParams& p, const in
       const int nxt = stage == 0 ? ST - 1 : stage - 1;  // slot of tile kt+ST-1 == slot of tile kt-1
       if (kt + ST - 1 < kt1) issue(kt + ST - 1, nxt);
     }
-    const bf16* As = reinterpret_cast<const bf16*>(smem + stage * STAGE_BYTES);
-    const bf16* Bs = As + BM * BK;
+    const e16* As = reinterpret_cast<const e16*>(smem + stage * STAGE_BYTES);
+    const e16* Bs = As + BM * BK;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 af[TM], bfr[TN];
+      e16x8 af[TM], bfr[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(&As[swz(wm * (BM / 2) + i * 16 + fr, 4 * ks + fc)]);
+      for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const e16x8*>(&As[swz(wm * (BM / 2) + i * 16 + fr, 4 * ks + fc)]);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(&Bs[swz(wn * (BN / 2) + j * 16 + fr, 4 * ks + fc)]);
+      for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const e16x8*>(&Bs[swz(wn * (BN / 2) + j * 16 + fr, 4 * ks + fc)]);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = RMEM_MFMA_16x16x32(af[i], bfr[j], acc[i][j], 0, 0, 0);
     }
     stage = stage == ST - 1 ? 0 : stage + 1;
   }
@@ -640,7 +640,7 @@ __global__ __launch_bounds__(256) void k_conv_gemm_dma_big(ConvParams p) {
 // memory-update linears of a frame are independent of each other (layers/transformer.py:269-322), and at M = 1674 a launch
 // costs more than its arithmetic.
 struct GroupPtrs {
-  const bf16* x[4]; const bf16* w[4]; const float* bias[4]; const void* res[4]; void* y[4]; bf16* y2[4];
+  const e16* x[4]; const e16* w[4]; const float* bias[4]; const void* res[4]; void* y[4]; e16* y2[4];
 };
 template <bool FAST, int ST = 1>
 __global__ __launch_bounds__(256) void k_gemm_dma_grouped(ConvParams p, GroupPtrs g) {
@@ -759,6 +759,7 @@ bool use_small_tiles(int M, int Cout) {
 
 }  // namespace
 
+#ifndef RMEM_F16
 extern "C" size_t rmem_conv_workspace_bytes(const rmem_conv_desc* d) {
   if (!d) return 0;
   const int M = (d->batch > 0 ? d->batch : 1) * d->Ho * d->Wo, K = d->KH * d->KW * d->Cin;
@@ -766,6 +767,7 @@ extern "C" size_t rmem_conv_workspace_bytes(const rmem_conv_desc* d) {
   const int s = plan_splits(M, d->Cout, K);
   return s > 1 ? (size_t)s * M * d->Cout * sizeof(float) : 0;
 }
+#endif
 
 static int conv_setup(const rmem_conv_desc* d, const void* x, const void* w, const float* bias, const void* residual, void* y,
                       void* y2, ConvParams& p, bool& is1x1) {
@@ -779,7 +781,7 @@ static int conv_setup(const rmem_conv_desc* d, const void* x, const void* w, con
   RMEM_REQUIRE(!residual || d->ldr >= d->Cout, "rmem_conv2d_nhwc: ldr < Cout");
   RMEM_REQUIRE(!y2 || d->ld2 >= d->Cout, "rmem_conv2d_nhwc: ld2 < Cout");
   RMEM_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)w % 16) == 0, "rmem_conv2d_nhwc: x/w must be 16-byte aligned");
-  p.x = (const bf16*)x; p.w = (const bf16*)w; p.bias = bias; p.res = residual; p.y = y; p.y2 = (bf16*)y2;
+  p.x = (const e16*)x; p.w = (const e16*)w; p.bias = bias; p.res = residual; p.y = y; p.y2 = (e16*)y2;
   p.slabs = nullptr;
   p.x2 = nullptr; p.H2 = p.W2 = p.Cin2 = p.stride2 = 0; p.x2_elems = 0;
   p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Ho = Ho; p.Wo = Wo; p.Cout = d->Cout;
@@ -798,7 +800,7 @@ static int conv_setup(const rmem_conv_desc* d, const void* x, const void* w, con
   p.up_h = d->res_up_h; p.up_w = d->res_up_w; p.up_align = d->res_up_align;
   RMEM_REQUIRE(p.up_h >= 0 && p.up_w >= 0 && (p.up_h > 0) == (p.up_w > 0), "rmem_conv2d_nhwc: res_up_h / res_up_w must both be set or both be 0");
   RMEM_REQUIRE(p.up_h == 0 || (residual && !d->res_f32 && p.Cout % 8 == 0 && p.ldr % 8 == 0 && ((uintptr_t)residual % 16) == 0 && p.ldo % 8 == 0),
-               "rmem_conv2d_nhwc: the resized residual must be bf16, 16-byte aligned, with Cout, ldr, ldo multiples of 8");
+               "rmem_conv2d_nhwc: the resized residual must be e16, 16-byte aligned, with Cout, ldr, ldo multiples of 8");
   p.steps_per_split = (p.K + 63) / 64;
   auto al = [](const void* q, int a) { return q == nullptr || ((uintptr_t)q % a) == 0; };
   {
@@ -816,7 +818,7 @@ static int conv_setup(const rmem_conv_desc* d, const void* x, const void* w, con
   return 0;
 }
 
-extern "C" int rmem_conv2d_nhwc(const rmem_conv_desc* d, const void* x, const void* w, const float* bias,
+extern "C" int RMEM_API(rmem_conv2d_nhwc)(const rmem_conv_desc* d, const void* x, const void* w, const float* bias,
                                 const void* residual, void* y, void* y2, void* workspace, void* stream) {
   ConvParams p;
   bool is1x1 = false;
@@ -864,7 +866,7 @@ extern "C" int rmem_conv2d_nhwc(const rmem_conv_desc* d, const void* x, const vo
 
 // Y = act([x | x2 sampled at stride2] * Wcat^T + bias): the last 1x1 conv of a ResNet bottleneck and its (strided) 1x1 shortcut
 // (encoders/resnet.py:48-68, downsample branch) as ONE GEMM over K = Cin + Cin2 -- the shortcut tensor is never written or re-read.
-extern "C" int rmem_conv1x1_dual_nhwc(const rmem_conv_desc* d, const void* x, const void* x2, int H2, int W2, int Cin2, int stride2,
+extern "C" int RMEM_API(rmem_conv1x1_dual_nhwc)(const rmem_conv_desc* d, const void* x, const void* x2, int H2, int W2, int Cin2, int stride2,
                                       const void* w_cat, const float* bias, void* y, void* stream) {
   ConvParams p;
   bool is1x1 = false;
@@ -875,7 +877,7 @@ extern "C" int rmem_conv1x1_dual_nhwc(const rmem_conv_desc* d, const void* x, co
   RMEM_REQUIRE((H2 - 1) / stride2 + 1 == p.Ho && (W2 - 1) / stride2 + 1 == p.Wo, "rmem_conv1x1_dual_nhwc: x2 geometry does not match the output");
   RMEM_REQUIRE(((uintptr_t)x2 % 16) == 0, "rmem_conv1x1_dual_nhwc: x2 must be 16-byte aligned");
   const int nb = d->batch > 0 ? d->batch : 1;
-  p.x2 = (const bf16*)x2; p.H2 = H2; p.W2 = W2; p.Cin2 = Cin2; p.stride2 = stride2;
+  p.x2 = (const e16*)x2; p.H2 = H2; p.W2 = W2; p.Cin2 = Cin2; p.stride2 = stride2;
   p.x2_elems = (long)nb * H2 * W2 * Cin2;
   p.K = p.Cin + Cin2;                                   // Wcat is [Cout][Cin + Cin2]
   p.steps_per_split = p.K / 64;
@@ -893,7 +895,7 @@ extern "C" int rmem_conv1x1_dual_nhwc(const rmem_conv_desc* d, const void* x, co
   return rmem_check_launch("rmem_conv1x1_dual_nhwc");
 }
 
-extern "C" int rmem_linear_grouped(const rmem_conv_desc* d, int n, const void* const* x, const void* const* w,
+extern "C" int RMEM_API(rmem_linear_grouped)(const rmem_conv_desc* d, int n, const void* const* x, const void* const* w,
                                    const float* const* bias, const void* const* residual, void* const* y, void* stream) {
   RMEM_REQUIRE(d && x && w && y && n >= 1 && n <= 4, "rmem_linear_grouped: 1..4 problems");
   ConvParams p;

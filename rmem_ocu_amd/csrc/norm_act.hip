@@ -4,7 +4,7 @@
 //   embedding" second output      (layers/transformer.py:566-568, 574, 659-660, 683, 250-259)
 //   GroupNorm + {none, ReLU, GELU} on NHWC   (layers/basic.py:27-35, 60-70; decoders/fpn.py:44-64)
 //   depth-wise 5x5 convolution on NHWC       (layers/basic.py:19-25, 34)
-//   bf16 elementwise add                      (layers/transformer.py:279-285: curr_V + id_emb)
+//   e16 elementwise add                      (layers/transformer.py:279-285: curr_V + id_emb)
 #include "common.h"
 #include "../../include/rmem.h"
 
@@ -15,13 +15,13 @@ struct LnParams {
   const void* a; int a_f32; int lda;
   const void* b; int b_f32; int ldb;
   const float* gamma; const float* beta; float eps; int M;
-  bf16* y; int ldy; const float* pos; bf16* ypos; int ldyp;
+  e16* y; int ldy; const float* pos; e16* ypos; int ldyp;
   float* yf; int ldyf;
 };
 
 __device__ __forceinline__ f32x4 load4(const void* base, int is_f32, long off) {
   if (is_f32) return *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(base) + off);
-  const bf16x4 v = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16*>(base) + off);
+  const e16x4 v = *reinterpret_cast<const e16x4*>(reinterpret_cast<const e16*>(base) + off);
   return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
 }
 
@@ -43,12 +43,12 @@ __device__ __forceinline__ void layernorm256_body(const LnParams& p) {
   const f32x4 g = *reinterpret_cast<const f32x4*>(p.gamma + c0);
   const f32x4 bt = *reinterpret_cast<const f32x4*>(p.beta + c0);
   const f32x4 o = dv * rstd * g + bt;
-  if (p.y) *reinterpret_cast<bf16x4*>(p.y + (long)row * p.ldy + c0) = bf16x4{(bf16)o[0], (bf16)o[1], (bf16)o[2], (bf16)o[3]};
+  if (p.y) *reinterpret_cast<e16x4*>(p.y + (long)row * p.ldy + c0) = e16x4{(e16)o[0], (e16)o[1], (e16)o[2], (e16)o[3]};
   if (p.yf) *reinterpret_cast<f32x4*>(p.yf + (long)row * p.ldyf + c0) = o;
   if (p.ypos) {
     const f32x4 ps = *reinterpret_cast<const f32x4*>(p.pos + (long)row * 256 + c0);
     const f32x4 q = o + ps;
-    *reinterpret_cast<bf16x4*>(p.ypos + (long)row * p.ldyp + c0) = bf16x4{(bf16)q[0], (bf16)q[1], (bf16)q[2], (bf16)q[3]};
+    *reinterpret_cast<e16x4*>(p.ypos + (long)row * p.ldyp + c0) = e16x4{(e16)q[0], (e16)q[1], (e16)q[2], (e16)q[3]};
   }
 }
 
@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void k_layernorm256_pair(LnPair pp) { layernor
 // generic channel count (Swin-B stages: 128 / 256 / 512 / 1024): one wave per row, C / 64 consecutive channels per lane
 template <int C>
 __global__ __launch_bounds__(256) void k_layernorm_c(const void* a, int a_f32, int lda, const float* gamma, const float* beta, float eps,
-                                                     int M, bf16* y, int ldy, float* yf, int ldyf) {
+                                                     int M, e16* y, int ldy, float* yf, int ldyf) {
   constexpr int NV = C / 64;
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void k_layernorm_c(const void* a, int a_f32, i
 #pragma unroll
     for (int j = 0; j < NV; ++j) v[j] = pa[j];
   } else {
-    const bf16* pa = reinterpret_cast<const bf16*>(a) + (long)row * lda + c0;
+    const e16* pa = reinterpret_cast<const e16*>(a) + (long)row * lda + c0;
 #pragma unroll
     for (int j = 0; j < NV; ++j) v[j] = (float)pa[j];
   }
@@ -89,16 +89,16 @@ __global__ __launch_bounds__(256) void k_layernorm_c(const void* a, int a_f32, i
 #pragma unroll
   for (int j = 0; j < NV; ++j) {
     const float o = v[j] * rstd * gamma[c0 + j] + beta[c0 + j];
-    if (y) y[(long)row * ldy + c0 + j] = (bf16)o;
+    if (y) y[(long)row * ldy + c0 + j] = (e16)o;
     if (yf) yf[(long)row * ldyf + c0 + j] = o;
   }
 }
 
 // Swin patch merging (encoders/swin/swin_transformer.py:336-356): gather the 2x2 neighbourhood of every output token
-// ([even,even], [odd,even], [even,odd], [odd,odd] row/col order, zero beyond an odd border), LayerNorm over 4C, bf16 out.
+// ([even,even], [odd,even], [even,odd], [odd,odd] row/col order, zero beyond an odd border), LayerNorm over 4C, e16 out.
 // One wave per output token.
 template <int C>
-__global__ __launch_bounds__(256) void k_patch_merge_ln(const float* x, int H, int W, const float* gamma, const float* beta, float eps, bf16* y) {
+__global__ __launch_bounds__(256) void k_patch_merge_ln(const float* x, int H, int W, const float* gamma, const float* beta, float eps, e16* y) {
   constexpr int C4 = 4 * C, NV = C4 / 64;
   const int lane = threadIdx.x & 63;
   const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
@@ -121,41 +121,41 @@ __global__ __launch_bounds__(256) void k_patch_merge_ln(const float* x, int H, i
   for (int j = 0; j < NV; ++j) { v[j] -= mean; ss += v[j] * v[j]; }
   const float rstd = rsqrtf(wave_sum(ss) * (1.f / C4) + eps);
 #pragma unroll
-  for (int j = 0; j < NV; ++j) y[(long)tok * C4 + c0 + j] = (bf16)(v[j] * rstd * gamma[c0 + j] + beta[c0 + j]);
+  for (int j = 0; j < NV; ++j) y[(long)tok * C4 + c0 + j] = (e16)(v[j] * rstd * gamma[c0 + j] + beta[c0 + j]);
 }
 
 // ------------------------------------------------------------------ add
-__global__ __launch_bounds__(256) void k_add_bf16(const bf16* a, const bf16* b, bf16* y, long n8) {
+__global__ __launch_bounds__(256) void k_add16(const e16* a, const e16* b, e16* y, long n8) {
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
-    const bf16x8 x = reinterpret_cast<const bf16x8*>(a)[i];
-    const bf16x8 z = reinterpret_cast<const bf16x8*>(b)[i];
-    bf16x8 o;
+    const e16x8 x = reinterpret_cast<const e16x8*>(a)[i];
+    const e16x8 z = reinterpret_cast<const e16x8*>(b)[i];
+    e16x8 o;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = (bf16)((float)x[j] + (float)z[j]);
-    reinterpret_cast<bf16x8*>(y)[i] = o;
+    for (int j = 0; j < 8; ++j) o[j] = (e16)((float)x[j] + (float)z[j]);
+    reinterpret_cast<e16x8*>(y)[i] = o;
   }
 }
 
-struct AddGroup { const bf16* a[8]; const bf16* b[8]; bf16* y[8]; };
-__global__ __launch_bounds__(256) void k_add_bf16_grouped(AddGroup g, long n8) {
-  const bf16* a = g.a[blockIdx.y];
-  const bf16* b = g.b[blockIdx.y];
-  bf16* y = g.y[blockIdx.y];
+struct AddGroup { const e16* a[8]; const e16* b[8]; e16* y[8]; };
+__global__ __launch_bounds__(256) void k_add16_grouped(AddGroup g, long n8) {
+  const e16* a = g.a[blockIdx.y];
+  const e16* b = g.b[blockIdx.y];
+  e16* y = g.y[blockIdx.y];
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
-    const bf16x8 x = reinterpret_cast<const bf16x8*>(a)[i];
-    const bf16x8 z = reinterpret_cast<const bf16x8*>(b)[i];
-    bf16x8 o;
+    const e16x8 x = reinterpret_cast<const e16x8*>(a)[i];
+    const e16x8 z = reinterpret_cast<const e16x8*>(b)[i];
+    e16x8 o;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = (bf16)((float)x[j] + (float)z[j]);
-    reinterpret_cast<bf16x8*>(y)[i] = o;
+    for (int j = 0; j < 8; ++j) o[j] = (e16)((float)x[j] + (float)z[j]);
+    reinterpret_cast<e16x8*>(y)[i] = o;
   }
 }
 
 // ------------------------------------------------------------------ GroupNorm (NHWC)
 constexpr int GN_SPLITS = 64;
 
-__device__ __forceinline__ void gn_load8(const bf16* p, float (&f)[8]) {
-  const bf16x8 d = *reinterpret_cast<const bf16x8*>(p);
+__device__ __forceinline__ void gn_load8(const e16* p, float (&f)[8]) {
+  const e16x8 d = *reinterpret_cast<const e16x8*>(p);
 #pragma unroll
   for (int j = 0; j < 8; ++j) f[j] = (float)d[j];
 }
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(256) void k_gn_stats_rows(const TI* x, int M, int C
   }
 }
 
-// exact-form GELU 0.5 x (1 + erf(x / sqrt 2)) with erf from Abramowitz-Stegun 7.1.26 (|error| < 1.5e-7, far below the bf16 the
+// exact-form GELU 0.5 x (1 + erf(x / sqrt 2)) with erf from Abramowitz-Stegun 7.1.26 (|error| < 1.5e-7, far below the e16 the
 // callers round to): 2 transcendentals + ~12 plain VALU ops instead of the ~40 of erff.  For x < 0 the factor 1 + erf is formed
 // directly as poly * exp(-z^2) (= erfc), without the cancellation of 1 - 0.9999...
 __device__ __forceinline__ float gelu_erf(float x) {
@@ -274,7 +274,7 @@ __device__ __forceinline__ float gelu_erf(float x) {
 
 template <typename TI>
 __global__ __launch_bounds__(256) void k_gn_apply(const TI* x, int M, int C, int cpg, int groups, const float* ws,
-                                                  const float* gamma, const float* beta, float eps, int act, bf16* y) {
+                                                  const float* gamma, const float* beta, float eps, int act, e16* y) {
   x += (long)blockIdx.y * M * C;
   y += (long)blockIdx.y * M * C;
   ws += (long)blockIdx.y * groups * GN_SPLITS * 2;
@@ -289,15 +289,15 @@ __global__ __launch_bounds__(256) void k_gn_apply(const TI* x, int M, int C, int
     float d[8];
     gn_load8(x + i * 8, d);
     const float mean = s_mean[g], rstd = s_rstd[g];
-    bf16x8 o;
+    e16x8 o;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       float f = (d[j] - mean) * rstd * gamma[c0 + j] + beta[c0 + j];
       if (act == 1) f = fmaxf(f, 0.f);
       else if (act == 2) f = gelu_erf(f);
-      o[j] = (bf16)f;
+      o[j] = (e16)f;
     }
-    reinterpret_cast<bf16x8*>(y)[i] = o;
+    reinterpret_cast<e16x8*>(y)[i] = o;
   }
 }
 
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(256) void k_gn_apply(const TI* x, int M, int C, int
 // loads issued before the first use.  grid (ceil(M / (8 * rpi)), images).  Same arithmetic as k_gn_apply (bit-identical).
 template <typename TI>
 __global__ __launch_bounds__(256) void k_gn_apply_rows(const TI* x, int M, int C, int cpg, int groups, const float* ws,
-                                                       const float* gamma, const float* beta, float eps, int act, bf16* y) {
+                                                       const float* gamma, const float* beta, float eps, int act, e16* y) {
   x += (long)blockIdx.y * M * C;
   y += (long)blockIdx.y * M * C;
   ws += (long)blockIdx.y * groups * GN_SPLITS * 2;
@@ -334,35 +334,35 @@ __global__ __launch_bounds__(256) void k_gn_apply_rows(const TI* x, int M, int C
   for (int u = 0; u < UN; ++u) {
     const int r = rb + u * rpi;
     if (r >= M) continue;
-    bf16x8 o;
+    e16x8 o;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       float f = (d[u][j] - mean) * rstd * gm[j] + bt[j];
       if (act == 1) f = fmaxf(f, 0.f);
       else if (act == 2) f = gelu_erf(f);
-      o[j] = (bf16)f;
+      o[j] = (e16)f;
     }
-    *reinterpret_cast<bf16x8*>(y + (long)r * C + c0) = o;
+    *reinterpret_cast<e16x8*>(y + (long)r * C + c0) = o;
   }
 }
 
 // GroupNorm apply + activation + a narrow 1x1 convolution (N <= 16 outputs) in one pass: the segmentation head's last
 // `conv_out(relu(gn(x)))` (decoders/fpn.py:62-66) without writing the normalised 128-channel map.  A workgroup takes 64 pixels:
-// phase 1 normalises them into LDS (bf16, the rounding the two-kernel route stores), phase 2 gives thread (pixel, 4 outputs)
+// phase 1 normalises them into LDS (e16, the rounding the two-kernel route stores), phase 2 gives thread (pixel, 4 outputs)
 // a 128-long dot product against fp32 weights in LDS.  C = 128 only (the path's head); y is fp32 [M][ldy].
 constexpr int HC = 128, HPIX = 64, HROW = HC + 8;
-__global__ __launch_bounds__(256) void k_gn_apply_head(const bf16* x, int M, int cpg, int groups, const float* ws, const float* gamma,
-                                                       const float* beta, float eps, int act, const bf16* w, const float* bias, int N,
+__global__ __launch_bounds__(256) void k_gn_apply_head(const e16* x, int M, int cpg, int groups, const float* ws, const float* gamma,
+                                                       const float* beta, float eps, int act, const e16* w, const float* bias, int N,
                                                        float* y, int ldy) {
   x += (long)blockIdx.y * M * HC;
   y += (long)blockIdx.y * M * ldy;
   ws += (long)blockIdx.y * groups * GN_SPLITS * 2;
   __shared__ float s_mean[64], s_rstd[64];
-  __shared__ __attribute__((aligned(16))) bf16 tile[HPIX * HROW];
+  __shared__ __attribute__((aligned(16))) e16 tile[HPIX * HROW];
   __shared__ __attribute__((aligned(16))) float wl[16 * HC];
   gn_finalize(ws, groups, (float)M * (float)cpg, eps, s_mean, s_rstd);
   const int tid = threadIdx.x;
-  for (int i = tid; i < 16 * HC; i += 256) wl[i] = (i / HC) < N ? (float)w[i] : 0.f;     // w is [N][128] bf16
+  for (int i = tid; i < 16 * HC; i += 256) wl[i] = (i / HC) < N ? (float)w[i] : 0.f;     // w is [N][128] e16
   __syncthreads();
   const int m0 = blockIdx.x * HPIX;
   {
@@ -382,17 +382,17 @@ __global__ __launch_bounds__(256) void k_gn_apply_head(const bf16* x, int M, int
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int r = m0 + rl + 16 * u;
-      bf16x8 o = {0, 0, 0, 0, 0, 0, 0, 0};
+      e16x8 o = {0, 0, 0, 0, 0, 0, 0, 0};
       if (r < M) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           float f = (d[u][j] - mean) * rstd * gm[j] + bt[j];
           if (act == 1) f = fmaxf(f, 0.f);
           else if (act == 2) f = gelu_erf(f);
-          o[j] = (bf16)f;
+          o[j] = (e16)f;
         }
       }
-      *reinterpret_cast<bf16x8*>(&tile[(rl + 16 * u) * HROW + c0]) = o;
+      *reinterpret_cast<e16x8*>(&tile[(rl + 16 * u) * HROW + c0]) = o;
     }
   }
   __syncthreads();
@@ -400,7 +400,7 @@ __global__ __launch_bounds__(256) void k_gn_apply_head(const bf16* x, int M, int
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
   for (int c8 = 0; c8 < HC / 8; ++c8) {
-    const bf16x8 a = *reinterpret_cast<const bf16x8*>(&tile[px * HROW + c8 * 8]);
+    const e16x8 a = *reinterpret_cast<const e16x8*>(&tile[px * HROW + c8 * 8]);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const float* wq = &wl[(og * 4 + q) * HC + c8 * 8];
@@ -421,7 +421,7 @@ __global__ __launch_bounds__(256) void k_gn_apply_head(const bf16* x, int M, int
 
 // ------------------------------------------------------------------ depth-wise 5x5 (NHWC, pad 2)
 // thread = (pixel, 8 channels); weights pre-transposed to [25][C] fp32
-__global__ __launch_bounds__(256) void k_dwconv5(const bf16* x, const float* w, bf16* y, int H, int W, int C) {
+__global__ __launch_bounds__(256) void k_dwconv5(const e16* x, const float* w, e16* y, int H, int W, int C) {
   const int vpr = C / 8;
   const long total = (long)H * W * vpr;
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
@@ -438,26 +438,26 @@ __global__ __launch_bounds__(256) void k_dwconv5(const bf16* x, const float* w, 
     for (int dy = 0; dy < 5; ++dy) {
       const int yy = py + dy - 2;
       if ((unsigned)yy >= (unsigned)H) continue;
-      const bf16x8 d = *reinterpret_cast<const bf16x8*>(x + ((long)yy * W + xx) * C + c0);
+      const e16x8 d = *reinterpret_cast<const e16x8*>(x + ((long)yy * W + xx) * C + c0);
       const float* wt = w + (dy * 5 + dx) * C + c0;
       const f32x4 w0 = *reinterpret_cast<const f32x4*>(wt), w1 = *reinterpret_cast<const f32x4*>(wt + 4);
 #pragma unroll
       for (int j = 0; j < 4; ++j) { acc[j] += (float)d[j] * w0[j]; acc[4 + j] += (float)d[4 + j] * w1[j]; }
     }
   }
-  bf16x8 o;
+  e16x8 o;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) o[j] = (bf16)acc[j];
-  reinterpret_cast<bf16x8*>(y)[i] = o;
+  for (int j = 0; j < 8; ++j) o[j] = (e16)acc[j];
+  reinterpret_cast<e16x8*>(y)[i] = o;
 }
 
 // GroupNorm apply + activation + depth-wise 5x5 in one pass (basic.py:31-33: gn -> GELU -> conv of GNActDWConv2d): a tile of
-// 8 x 16 pixels x 64 channels with its 2-pixel halo is normalised + activated ONCE into LDS (bf16, the same rounding the
+// 8 x 16 pixels x 64 channels with its 2-pixel halo is normalised + activated ONCE into LDS (e16, the same rounding the
 // two-kernel path stores), then the 25 taps read LDS.  ws holds the (sum, sumsq) partials of k_gn_stats.
 constexpr int DT_H = 8, DT_W = 16, DT_C = 64, DT_HW = (DT_H + 4) * (DT_W + 4);
-__global__ __launch_bounds__(256) void k_gn_dwconv5(const bf16* x, const float* ws, const float* gamma, const float* beta, float eps,
-                                                    int cpg, int act, const float* w, bf16* y, int H, int W, int C, int M) {
-  __shared__ __attribute__((aligned(16))) bf16 tile[DT_HW * DT_C];
+__global__ __launch_bounds__(256) void k_gn_dwconv5(const e16* x, const float* ws, const float* gamma, const float* beta, float eps,
+                                                    int cpg, int act, const float* w, e16* y, int H, int W, int C, int M) {
+  __shared__ __attribute__((aligned(16))) e16 tile[DT_HW * DT_C];
   __shared__ __attribute__((aligned(16))) float wl[25 * DT_C];
   __shared__ float s_mean[8], s_rstd[8];
   const int tid = threadIdx.x;
@@ -484,7 +484,7 @@ __global__ __launch_bounds__(256) void k_gn_dwconv5(const bf16* x, const float* 
       for (int j = 0; j < 4; ++j) { gm[j] = g0v[j]; gm[4 + j] = g1v[j]; bt[j] = b0v[j]; bt[4 + j] = b1v[j]; }
     }
     const float mean = s_mean[(c8 * 8) / cpg], rstd = s_rstd[(c8 * 8) / cpg];
-    bf16x8 raw[NIT];
+    e16x8 raw[NIT];
     bool ok[NIT];
 #pragma unroll
     for (int k = 0; k < NIT; ++k) {
@@ -492,23 +492,23 @@ __global__ __launch_bounds__(256) void k_gn_dwconv5(const bf16* x, const float* 
       const int hy = pix / (DT_W + 4), hx = pix - hy * (DT_W + 4);
       const int gy = ty * DT_H + hy - 2, gx = tx * DT_W + hx - 2;
       ok[k] = pix < DT_HW && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
-      raw[k] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-      if (ok[k]) raw[k] = *reinterpret_cast<const bf16x8*>(x + ((long)gy * W + gx) * C + cc);
+      raw[k] = e16x8{0, 0, 0, 0, 0, 0, 0, 0};
+      if (ok[k]) raw[k] = *reinterpret_cast<const e16x8*>(x + ((long)gy * W + gx) * C + cc);
     }
 #pragma unroll
     for (int k = 0; k < NIT; ++k) {
       const int pix = (tid >> 3) + 32 * k;
-      bf16x8 o = {0, 0, 0, 0, 0, 0, 0, 0};
+      e16x8 o = {0, 0, 0, 0, 0, 0, 0, 0};
       if (ok[k]) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           float f = ((float)raw[k][j] - mean) * rstd * gm[j] + bt[j];
           if (act == 1) f = fmaxf(f, 0.f);
           else if (act == 2) f = gelu_erf(f);
-          o[j] = (bf16)f;
+          o[j] = (e16)f;
         }
       }
-      if (pix < DT_HW) *reinterpret_cast<bf16x8*>(&tile[pix * DT_C + c8 * 8]) = o;
+      if (pix < DT_HW) *reinterpret_cast<e16x8*>(&tile[pix * DT_C + c8 * 8]) = o;
     }
   }
   __syncthreads();
@@ -533,7 +533,7 @@ __global__ __launch_bounds__(256) void k_gn_dwconv5(const bf16* x, const float* 
     }
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
-      const bf16x8 d = *reinterpret_cast<const bf16x8*>(&tile[((4 * half + r) * (DT_W + 4) + ox + dx) * DT_C + ch8 * 8]);
+      const e16x8 d = *reinterpret_cast<const e16x8*>(&tile[((4 * half + r) * (DT_W + 4) + ox + dx) * DT_C + ch8 * 8]);
       float df[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) df[j] = (float)d[j];
@@ -553,10 +553,10 @@ __global__ __launch_bounds__(256) void k_gn_dwconv5(const bf16* x, const float* 
     for (int o = 0; o < 4; ++o) {
       const int gy = ty * DT_H + 4 * half + o;
       if (gy < H) {
-        bf16x8 ov;
+        e16x8 ov;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) ov[j] = (bf16)acc[o][j];
-        *reinterpret_cast<bf16x8*>(y + ((long)gy * W + gx) * C + c0 + ch8 * 8) = ov;
+        for (int j = 0; j < 8; ++j) ov[j] = (e16)acc[o][j];
+        *reinterpret_cast<e16x8*>(y + ((long)gy * W + gx) * C + c0 + ch8 * 8) = ov;
       }
     }
   }
@@ -564,7 +564,7 @@ __global__ __launch_bounds__(256) void k_gn_dwconv5(const bf16* x, const float* 
 
 }  // namespace
 
-extern "C" int rmem_layernorm256(const void* a, int a_is_f32, int lda, const void* b, int b_is_f32, int ldb,
+extern "C" int RMEM_API(rmem_layernorm256)(const void* a, int a_is_f32, int lda, const void* b, int b_is_f32, int ldb,
                                  const float* gamma, const float* beta, float eps, int M, void* y_bf16, int ldy,
                                  const float* pos, void* ypos_bf16, int ldyp, float* y_f32, int ldyf, void* stream) {
   RMEM_REQUIRE(a && gamma && beta && M > 0, "rmem_layernorm256: null argument");
@@ -572,66 +572,66 @@ extern "C" int rmem_layernorm256(const void* a, int a_is_f32, int lda, const voi
   RMEM_REQUIRE(lda % 4 == 0 && (!b || ldb % 4 == 0) && (!y_bf16 || ldy % 4 == 0) && (!ypos_bf16 || ldyp % 4 == 0) &&
                    (!y_f32 || ldyf % 4 == 0), "rmem_layernorm256: leading dimensions must be multiples of 4");
   RMEM_REQUIRE(!ypos_bf16 || pos, "rmem_layernorm256: ypos needs pos");
-  LnParams p{a, a_is_f32, lda, b, b_is_f32, ldb, gamma, beta, eps, M, (bf16*)y_bf16, ldy, pos, (bf16*)ypos_bf16, ldyp, y_f32, ldyf};
+  LnParams p{a, a_is_f32, lda, b, b_is_f32, ldb, gamma, beta, eps, M, (e16*)y_bf16, ldy, pos, (e16*)ypos_bf16, ldyp, y_f32, ldyf};
   hipLaunchKernelGGL(k_layernorm256, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
   return rmem_check_launch("rmem_layernorm256");
 }
 
-extern "C" int rmem_layernorm256_pair(const void* a0, const void* b0, void* y0, const void* a1, const void* b1, void* y1,
+extern "C" int RMEM_API(rmem_layernorm256_pair)(const void* a0, const void* b0, void* y0, const void* a1, const void* b1, void* y1,
                                       const float* gamma, const float* beta, float eps, int M, void* stream) {
   RMEM_REQUIRE(a0 && b0 && y0 && a1 && b1 && y1 && gamma && beta && M > 0, "rmem_layernorm256_pair: null argument");
   LnPair pp;
-  pp.p[0] = LnParams{a0, 0, 256, b0, 0, 256, gamma, beta, eps, M, (bf16*)y0, 256, nullptr, nullptr, 0, nullptr, 0};
-  pp.p[1] = LnParams{a1, 0, 256, b1, 0, 256, gamma, beta, eps, M, (bf16*)y1, 256, nullptr, nullptr, 0, nullptr, 0};
+  pp.p[0] = LnParams{a0, 0, 256, b0, 0, 256, gamma, beta, eps, M, (e16*)y0, 256, nullptr, nullptr, 0, nullptr, 0};
+  pp.p[1] = LnParams{a1, 0, 256, b1, 0, 256, gamma, beta, eps, M, (e16*)y1, 256, nullptr, nullptr, 0, nullptr, 0};
   hipLaunchKernelGGL(k_layernorm256_pair, dim3((M + 3) / 4, 2), dim3(256), 0, (hipStream_t)stream, pp);
   return rmem_check_launch("rmem_layernorm256_pair");
 }
 
-extern "C" int rmem_layernorm(const void* a, int a_is_f32, int lda, const float* gamma, const float* beta, float eps, int M, int C,
+extern "C" int RMEM_API(rmem_layernorm)(const void* a, int a_is_f32, int lda, const float* gamma, const float* beta, float eps, int M, int C,
                               void* y_bf16, int ldy, float* y_f32, int ldyf, void* stream) {
   RMEM_REQUIRE(a && gamma && beta && M > 0 && (y_bf16 || y_f32), "rmem_layernorm: bad argument");
   const dim3 g((M + 3) / 4), b(256);
   hipStream_t s = (hipStream_t)stream;
   switch (C) {
-    case 128: hipLaunchKernelGGL(k_layernorm_c<128>, g, b, 0, s, a, a_is_f32, lda, gamma, beta, eps, M, (bf16*)y_bf16, ldy, y_f32, ldyf); break;
-    case 256: hipLaunchKernelGGL(k_layernorm_c<256>, g, b, 0, s, a, a_is_f32, lda, gamma, beta, eps, M, (bf16*)y_bf16, ldy, y_f32, ldyf); break;
-    case 512: hipLaunchKernelGGL(k_layernorm_c<512>, g, b, 0, s, a, a_is_f32, lda, gamma, beta, eps, M, (bf16*)y_bf16, ldy, y_f32, ldyf); break;
-    case 1024: hipLaunchKernelGGL(k_layernorm_c<1024>, g, b, 0, s, a, a_is_f32, lda, gamma, beta, eps, M, (bf16*)y_bf16, ldy, y_f32, ldyf); break;
+    case 128: hipLaunchKernelGGL(k_layernorm_c<128>, g, b, 0, s, a, a_is_f32, lda, gamma, beta, eps, M, (e16*)y_bf16, ldy, y_f32, ldyf); break;
+    case 256: hipLaunchKernelGGL(k_layernorm_c<256>, g, b, 0, s, a, a_is_f32, lda, gamma, beta, eps, M, (e16*)y_bf16, ldy, y_f32, ldyf); break;
+    case 512: hipLaunchKernelGGL(k_layernorm_c<512>, g, b, 0, s, a, a_is_f32, lda, gamma, beta, eps, M, (e16*)y_bf16, ldy, y_f32, ldyf); break;
+    case 1024: hipLaunchKernelGGL(k_layernorm_c<1024>, g, b, 0, s, a, a_is_f32, lda, gamma, beta, eps, M, (e16*)y_bf16, ldy, y_f32, ldyf); break;
     default: rmem_set_error("rmem_layernorm: C must be 128, 256, 512 or 1024"); return -1;
   }
   return rmem_check_launch("rmem_layernorm");
 }
 
-extern "C" int rmem_patch_merge_ln(const float* x, int H, int W, int C, const float* gamma, const float* beta, float eps, void* y_bf16, void* stream) {
+extern "C" int RMEM_API(rmem_patch_merge_ln)(const float* x, int H, int W, int C, const float* gamma, const float* beta, float eps, void* y_bf16, void* stream) {
   RMEM_REQUIRE(x && gamma && beta && y_bf16 && H > 0 && W > 0, "rmem_patch_merge_ln: bad argument");
   const int M = ((H + 1) / 2) * ((W + 1) / 2);
   const dim3 g((M + 3) / 4), b(256);
   hipStream_t s = (hipStream_t)stream;
-  if (C == 128) hipLaunchKernelGGL(k_patch_merge_ln<128>, g, b, 0, s, x, H, W, gamma, beta, eps, (bf16*)y_bf16);
-  else if (C == 256) hipLaunchKernelGGL(k_patch_merge_ln<256>, g, b, 0, s, x, H, W, gamma, beta, eps, (bf16*)y_bf16);
+  if (C == 128) hipLaunchKernelGGL(k_patch_merge_ln<128>, g, b, 0, s, x, H, W, gamma, beta, eps, (e16*)y_bf16);
+  else if (C == 256) hipLaunchKernelGGL(k_patch_merge_ln<256>, g, b, 0, s, x, H, W, gamma, beta, eps, (e16*)y_bf16);
   else { rmem_set_error("rmem_patch_merge_ln: C must be 128 or 256"); return -1; }
   return rmem_check_launch("rmem_patch_merge_ln");
 }
 
-extern "C" int rmem_add_bf16(const void* a, const void* b, void* y, long long n, void* stream) {
-  RMEM_REQUIRE(a && b && y && n > 0 && n % 8 == 0, "rmem_add_bf16: n must be a positive multiple of 8");
+extern "C" int RMEM_API(rmem_add16)(const void* a, const void* b, void* y, long long n, void* stream) {
+  RMEM_REQUIRE(a && b && y && n > 0 && n % 8 == 0, "rmem_add16: n must be a positive multiple of 8");
   const long n8 = n / 8;
   const int blocks = (int)min((long)2048, (n8 + 255) / 256);
-  hipLaunchKernelGGL(k_add_bf16, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16*)a, (const bf16*)b, (bf16*)y, n8);
-  return rmem_check_launch("rmem_add_bf16");
+  hipLaunchKernelGGL(k_add16, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const e16*)a, (const e16*)b, (e16*)y, n8);
+  return rmem_check_launch("rmem_add16");
 }
 
-extern "C" int rmem_add_bf16_grouped(int n, const void* const* a, const void* const* b, void* const* y, long long count, void* stream) {
-  RMEM_REQUIRE(n >= 1 && n <= 8 && a && b && y && count > 0 && count % 8 == 0, "rmem_add_bf16_grouped: 1..8 problems, count a positive multiple of 8");
+extern "C" int RMEM_API(rmem_add16_grouped)(int n, const void* const* a, const void* const* b, void* const* y, long long count, void* stream) {
+  RMEM_REQUIRE(n >= 1 && n <= 8 && a && b && y && count > 0 && count % 8 == 0, "rmem_add16_grouped: 1..8 problems, count a positive multiple of 8");
   AddGroup g = {};
   for (int i = 0; i < n; ++i) {
-    RMEM_REQUIRE(a[i] && b[i] && y[i], "rmem_add_bf16_grouped: null operand");
-    g.a[i] = (const bf16*)a[i]; g.b[i] = (const bf16*)b[i]; g.y[i] = (bf16*)y[i];
+    RMEM_REQUIRE(a[i] && b[i] && y[i], "rmem_add16_grouped: null operand");
+    g.a[i] = (const e16*)a[i]; g.b[i] = (const e16*)b[i]; g.y[i] = (e16*)y[i];
   }
   const long n8 = count / 8;
   const int blocks = (int)min((long)1024, (n8 + 255) / 256);
-  hipLaunchKernelGGL(k_add_bf16_grouped, dim3(blocks, n), dim3(256), 0, (hipStream_t)stream, g, n8);
-  return rmem_check_launch("rmem_add_bf16_grouped");
+  hipLaunchKernelGGL(k_add16_grouped, dim3(blocks, n), dim3(256), 0, (hipStream_t)stream, g, n8);
+  return rmem_check_launch("rmem_add16_grouped");
 }
 
 namespace {
@@ -645,7 +645,7 @@ void gn_launch_stats(const TI* x, int images, int M, int C, int cpg, float* ws, 
 }
 template <typename TI>
 void gn_launch_apply(const TI* x, int images, int M, int C, int cpg, const float* ws, const float* gamma, const float* beta, float eps,
-                     int act, bf16* y, hipStream_t s) {
+                     int act, e16* y, hipStream_t s) {
   const int vpr = C / 8, groups = C / cpg;
   if (vpr <= 256 && 256 % vpr == 0) {
     const int rows_per_wg = 8 * (256 / vpr);
@@ -659,7 +659,9 @@ void gn_launch_apply(const TI* x, int images, int M, int C, int cpg, const float
 }
 }  // namespace
 
+#ifndef RMEM_F16
 extern "C" size_t rmem_groupnorm_workspace_bytes(int groups) { return (size_t)groups * GN_SPLITS * 2 * sizeof(float); }
+#endif
 
 static int gn_check(const void* x, const void* y, const float* gamma, const float* beta, const float* ws, int groups, int C, int act,
                     int M, int images) {
@@ -670,30 +672,30 @@ static int gn_check(const void* x, const void* y, const float* gamma, const floa
   return 0;
 }
 
-extern "C" int rmem_groupnorm_nhwc_images(const void* x, int images, int M, int C, int groups, const float* gamma, const float* beta,
+extern "C" int RMEM_API(rmem_groupnorm_nhwc_images)(const void* x, int images, int M, int C, int groups, const float* gamma, const float* beta,
                                           float eps, int act, void* y, float* workspace, void* stream) {
   if (gn_check(x, y, gamma, beta, workspace, groups, C, act, M, images)) return -1;
   const int cpg = C / groups;
   hipStream_t s = (hipStream_t)stream;
-  gn_launch_stats((const bf16*)x, images, M, C, cpg, workspace, s);
-  gn_launch_apply((const bf16*)x, images, M, C, cpg, workspace, gamma, beta, eps, act, (bf16*)y, s);
+  gn_launch_stats((const e16*)x, images, M, C, cpg, workspace, s);
+  gn_launch_apply((const e16*)x, images, M, C, cpg, workspace, gamma, beta, eps, act, (e16*)y, s);
   return rmem_check_launch("rmem_groupnorm_nhwc_images");
 }
 
-extern "C" int rmem_groupnorm_head_nhwc_images(const void* x, int images, int M, int C, int groups, const float* gamma, const float* beta,
+extern "C" int RMEM_API(rmem_groupnorm_head_nhwc_images)(const void* x, int images, int M, int C, int groups, const float* gamma, const float* beta,
                                                float eps, int act, const void* w, const float* bias, int N, float* y, int ldy,
                                                float* workspace, void* stream) {
   if (gn_check(x, y, gamma, beta, workspace, groups, C, act, M, images)) return -1;
   RMEM_REQUIRE(C == 128 && w && N >= 1 && N <= 16 && ldy >= N, "rmem_groupnorm_head_nhwc: C must be 128, 1 <= N <= 16 <= ... ldy >= N");
   const int cpg = C / groups;
   hipStream_t s = (hipStream_t)stream;
-  gn_launch_stats((const bf16*)x, images, M, C, cpg, workspace, s);
-  hipLaunchKernelGGL(k_gn_apply_head, dim3((M + HPIX - 1) / HPIX, images), dim3(256), 0, s, (const bf16*)x, M, cpg, groups, workspace, gamma,
-                     beta, eps, act, (const bf16*)w, bias, N, y, ldy);
+  gn_launch_stats((const e16*)x, images, M, C, cpg, workspace, s);
+  hipLaunchKernelGGL(k_gn_apply_head, dim3((M + HPIX - 1) / HPIX, images), dim3(256), 0, s, (const e16*)x, M, cpg, groups, workspace, gamma,
+                     beta, eps, act, (const e16*)w, bias, N, y, ldy);
   return rmem_check_launch("rmem_groupnorm_head_nhwc_images");
 }
 
-extern "C" int rmem_groupnorm_nhwc(const void* x, int M, int C, int groups, const float* gamma, const float* beta, float eps,
+extern "C" int RMEM_API(rmem_groupnorm_nhwc)(const void* x, int M, int C, int groups, const float* gamma, const float* beta, float eps,
                                    int act, void* y, float* workspace, void* stream) {
   RMEM_REQUIRE(x && y && gamma && beta && workspace, "rmem_groupnorm_nhwc: null argument");
   RMEM_REQUIRE(groups >= 1 && groups <= 64 && C % groups == 0 && (C / groups) % 8 == 0,
@@ -701,12 +703,12 @@ extern "C" int rmem_groupnorm_nhwc(const void* x, int M, int C, int groups, cons
   RMEM_REQUIRE(act >= 0 && act <= 2 && M > 0, "rmem_groupnorm_nhwc: bad act / M");
   const int cpg = C / groups;
   hipStream_t s = (hipStream_t)stream;
-  gn_launch_stats((const bf16*)x, 1, M, C, cpg, workspace, s);
-  gn_launch_apply((const bf16*)x, 1, M, C, cpg, workspace, gamma, beta, eps, act, (bf16*)y, s);
+  gn_launch_stats((const e16*)x, 1, M, C, cpg, workspace, s);
+  gn_launch_apply((const e16*)x, 1, M, C, cpg, workspace, gamma, beta, eps, act, (e16*)y, s);
   return rmem_check_launch("rmem_groupnorm_nhwc");
 }
 
-extern "C" int rmem_groupnorm_f32_nhwc(const float* x, int M, int C, int groups, const float* gamma, const float* beta, float eps,
+extern "C" int RMEM_API(rmem_groupnorm_f32_nhwc)(const float* x, int M, int C, int groups, const float* gamma, const float* beta, float eps,
                                        int act, void* y, float* workspace, void* stream) {
   RMEM_REQUIRE(x && y && gamma && beta && workspace, "rmem_groupnorm_f32_nhwc: null argument");
   RMEM_REQUIRE(groups >= 1 && groups <= 64 && C % groups == 0 && (C / groups) % 8 == 0,
@@ -715,19 +717,19 @@ extern "C" int rmem_groupnorm_f32_nhwc(const float* x, int M, int C, int groups,
   const int cpg = C / groups;
   hipStream_t s = (hipStream_t)stream;
   gn_launch_stats(x, 1, M, C, cpg, workspace, s);
-  gn_launch_apply(x, 1, M, C, cpg, workspace, gamma, beta, eps, act, (bf16*)y, s);
+  gn_launch_apply(x, 1, M, C, cpg, workspace, gamma, beta, eps, act, (e16*)y, s);
   return rmem_check_launch("rmem_groupnorm_f32_nhwc");
 }
 
-extern "C" int rmem_gn_act_dwconv5x5_nhwc_images(const void* x, int images, int H, int W, int C, int groups, const float* gamma,
+extern "C" int RMEM_API(rmem_gn_act_dwconv5x5_nhwc_images)(const void* x, int images, int H, int W, int C, int groups, const float* gamma,
                                                  const float* beta, float eps, int act, const float* w_t, void* y, float* workspace,
                                                  void* stream);
-extern "C" int rmem_gn_act_dwconv5x5_nhwc(const void* x, int H, int W, int C, int groups, const float* gamma, const float* beta,
+extern "C" int RMEM_API(rmem_gn_act_dwconv5x5_nhwc)(const void* x, int H, int W, int C, int groups, const float* gamma, const float* beta,
                                           float eps, int act, const float* w_t, void* y, float* workspace, void* stream) {
-  return rmem_gn_act_dwconv5x5_nhwc_images(x, 1, H, W, C, groups, gamma, beta, eps, act, w_t, y, workspace, stream);
+  return RMEM_API(rmem_gn_act_dwconv5x5_nhwc_images)(x, 1, H, W, C, groups, gamma, beta, eps, act, w_t, y, workspace, stream);
 }
 
-extern "C" int rmem_gn_act_dwconv5x5_nhwc_images(const void* x, int images, int H, int W, int C, int groups, const float* gamma,
+extern "C" int RMEM_API(rmem_gn_act_dwconv5x5_nhwc_images)(const void* x, int images, int H, int W, int C, int groups, const float* gamma,
                                                  const float* beta, float eps, int act, const float* w_t, void* y, float* workspace,
                                                  void* stream) {
   RMEM_REQUIRE(images >= 1, "rmem_gn_act_dwconv5x5_nhwc: images must be >= 1");
@@ -738,15 +740,15 @@ extern "C" int rmem_gn_act_dwconv5x5_nhwc_images(const void* x, int images, int 
   RMEM_REQUIRE(act >= 0 && act <= 2, "rmem_gn_act_dwconv5x5_nhwc: bad act");
   const int M = H * W;
   hipStream_t s = (hipStream_t)stream;
-  gn_launch_stats((const bf16*)x, images, M, C, cpg, workspace, s);
+  gn_launch_stats((const e16*)x, images, M, C, cpg, workspace, s);
   const dim3 grid(((W + DT_W - 1) / DT_W) * ((H + DT_H - 1) / DT_H), C / DT_C, images);
-  hipLaunchKernelGGL(k_gn_dwconv5, grid, dim3(256), 0, s, (const bf16*)x, workspace, gamma, beta, eps, cpg, act, w_t, (bf16*)y, H, W, C, M);
+  hipLaunchKernelGGL(k_gn_dwconv5, grid, dim3(256), 0, s, (const e16*)x, workspace, gamma, beta, eps, cpg, act, w_t, (e16*)y, H, W, C, M);
   return rmem_check_launch("rmem_gn_act_dwconv5x5_nhwc");
 }
 
-extern "C" int rmem_dwconv5x5_nhwc(const void* x, const float* w_t, void* y, int H, int W, int C, void* stream) {
+extern "C" int RMEM_API(rmem_dwconv5x5_nhwc)(const void* x, const float* w_t, void* y, int H, int W, int C, void* stream) {
   RMEM_REQUIRE(x && w_t && y && H > 0 && W > 0 && C % 8 == 0, "rmem_dwconv5x5_nhwc: bad argument");
   const long total = (long)H * W * (C / 8);
-  hipLaunchKernelGGL(k_dwconv5, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, w_t, (bf16*)y, H, W, C);
+  hipLaunchKernelGGL(k_dwconv5, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const e16*)x, w_t, (e16*)y, H, W, C);
   return rmem_check_launch("rmem_dwconv5x5_nhwc");
 }

@@ -1,11 +1,11 @@
 // Layout / resampling kernels around the encoder, the FPN head and the engine
 // (all HBM-bound, one pass each):
-//   NCHW fp32 image -> NHWC8 bf16                      (input of encoders/resnet.py:179)
+//   NCHW fp32 image -> NHWC8 e16                      (input of encoders/resnet.py:179)
 //   3x3 stride-2 max-pool, NHWC                        (encoders/resnet.py:105, 182)
-//   bilinear resize NHWC bf16 (align_corners on/off)   (decoders/fpn.py:49-52, 57-60)
+//   bilinear resize NHWC e16 (align_corners on/off)   (decoders/fpn.py:49-52, 57-60)
 //   logits: mask unused ids, bilinear to output size, NCHW fp32 + argmax labels
 //                                                      (engines/aot_engine.py:450-463; managers/evaluator.py:430-441)
-//   label map -> nearest resize -> one-hot(+ignore) NHWC16 bf16
+//   label map -> nearest resize -> one-hot(+ignore) NHWC16 e16
 //                                                      (utils/image.py:69-74; aot_engine.py:208-224; evaluator.py:518-522)
 //   eviction scores: sum_q mass[q, t] * (1 - softmax(bilinear(logits))[0])
 //                                                      (aot_engine.py:355-362; layers/transformer.py:341-351)
@@ -14,20 +14,20 @@
 
 namespace {
 
-__global__ __launch_bounds__(256) void k_image_to_nhwc8(const float* img, bf16* out, int H, int W) {
+__global__ __launch_bounds__(256) void k_image_to_nhwc8(const float* img, e16* out, int H, int W) {
   const long n = (long)H * W;
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   img += (long)blockIdx.y * 3 * n;            // blockIdx.y = image of a batch
   out += (long)blockIdx.y * 8 * n;
-  bf16x8 o = {0, 0, 0, 0, 0, 0, 0, 0};
-  o[0] = (bf16)img[i];
-  o[1] = (bf16)img[n + i];
-  o[2] = (bf16)img[2 * n + i];
-  reinterpret_cast<bf16x8*>(out)[i] = o;
+  e16x8 o = {0, 0, 0, 0, 0, 0, 0, 0};
+  o[0] = (e16)img[i];
+  o[1] = (e16)img[n + i];
+  o[2] = (e16)img[2 * n + i];
+  reinterpret_cast<e16x8*>(out)[i] = o;
 }
 
-__global__ __launch_bounds__(256) void k_maxpool3s2(const bf16* x, bf16* y, int H, int W, int C, int Ho, int Wo) {
+__global__ __launch_bounds__(256) void k_maxpool3s2(const e16* x, e16* y, int H, int W, int C, int Ho, int Wo) {
   const int vpr = C / 8;
   const long total = (long)Ho * Wo * vpr;
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
@@ -46,22 +46,22 @@ __global__ __launch_bounds__(256) void k_maxpool3s2(const bf16* x, bf16* y, int 
     for (int dx = 0; dx < 3; ++dx) {
       const int xx = ox * 2 - 1 + dx;
       if ((unsigned)xx >= (unsigned)W) continue;
-      const bf16x8 d = *reinterpret_cast<const bf16x8*>(x + ((long)yy * W + xx) * C + c0);
+      const e16x8 d = *reinterpret_cast<const e16x8*>(x + ((long)yy * W + xx) * C + c0);
 #pragma unroll
       for (int j = 0; j < 8; ++j) m[j] = fmaxf(m[j], (float)d[j]);
     }
   }
-  bf16x8 o;
+  e16x8 o;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) o[j] = (bf16)m[j];
-  reinterpret_cast<bf16x8*>(y)[i] = o;
+  for (int j = 0; j < 8; ++j) o[j] = (e16)m[j];
+  reinterpret_cast<e16x8*>(y)[i] = o;
 }
 
 __device__ __forceinline__ void src_coord(int d, int in, int out, int align, int& i0, int& i1, float& w1) {
   rmem_src_coord(d, in, out, align, i0, i1, w1);
 }
 
-__global__ __launch_bounds__(256) void k_bilinear_nhwc(const bf16* x, bf16* y, int Hi, int Wi, int Ho, int Wo, int C, int align) {
+__global__ __launch_bounds__(256) void k_bilinear_nhwc(const e16* x, e16* y, int Hi, int Wi, int Ho, int Wo, int C, int align) {
   const int vpr = C / 8;
   const long total = (long)Ho * Wo * vpr;
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
@@ -74,14 +74,14 @@ __global__ __launch_bounds__(256) void k_bilinear_nhwc(const bf16* x, bf16* y, i
   int y0, y1, x0, x1; float wy, wx;
   src_coord(oy, Hi, Ho, align, y0, y1, wy);
   src_coord(ox, Wi, Wo, align, x0, x1, wx);
-  const bf16x8 a = *reinterpret_cast<const bf16x8*>(x + ((long)y0 * Wi + x0) * C + c0);
-  const bf16x8 b = *reinterpret_cast<const bf16x8*>(x + ((long)y0 * Wi + x1) * C + c0);
-  const bf16x8 c = *reinterpret_cast<const bf16x8*>(x + ((long)y1 * Wi + x0) * C + c0);
-  const bf16x8 d = *reinterpret_cast<const bf16x8*>(x + ((long)y1 * Wi + x1) * C + c0);
-  bf16x8 o;
+  const e16x8 a = *reinterpret_cast<const e16x8*>(x + ((long)y0 * Wi + x0) * C + c0);
+  const e16x8 b = *reinterpret_cast<const e16x8*>(x + ((long)y0 * Wi + x1) * C + c0);
+  const e16x8 c = *reinterpret_cast<const e16x8*>(x + ((long)y1 * Wi + x0) * C + c0);
+  const e16x8 d = *reinterpret_cast<const e16x8*>(x + ((long)y1 * Wi + x1) * C + c0);
+  e16x8 o;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) o[j] = (bf16)rmem_bilerp((float)a[j], (float)b[j], (float)c[j], (float)d[j], wx, wy);
-  reinterpret_cast<bf16x8*>(y)[i] = o;
+  for (int j = 0; j < 8; ++j) o[j] = (e16)rmem_bilerp((float)a[j], (float)b[j], (float)c[j], (float)d[j], wx, wy);
+  reinterpret_cast<e16x8*>(y)[i] = o;
 }
 
 // logits NHWC fp32 [Hi][Wi][ldl] -> NCHW fp32 [nc][Ho][Wo] (optional) + argmax labels (optional)
@@ -144,9 +144,9 @@ __global__ __launch_bounds__(256) void k_logits_post(const float* lg, int ldl, i
   if (label_f32) label_f32[i] = (float)arg;
 }
 
-// label [Hs][Ws] (uint8 or fp32) -> nearest resize to [Hd][Wd] -> one-hot NHWC16 bf16
+// label [Hs][Ws] (uint8 or fp32) -> nearest resize to [Hd][Wd] -> one-hot NHWC16 e16
 // channels 0..ncls-1 one-hot (channel 0 cleared where label == 255), channel ncls = ignore (label == 255)
-__global__ __launch_bounds__(256) void k_label_onehot(const void* lab, int lab_f32, int Hs, int Ws, int Hd, int Wd, int ncls, bf16* out) {
+__global__ __launch_bounds__(256) void k_label_onehot(const void* lab, int lab_f32, int Hs, int Ws, int Hd, int Wd, int ncls, e16* out) {
   const long total = (long)Hd * Wd;
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
@@ -157,16 +157,16 @@ __global__ __launch_bounds__(256) void k_label_onehot(const void* lab, int lab_f
   const int sx = min((int)floorf((float)x * ((float)Ws / (float)Wd)), Ws - 1);
   const long si = (long)sy * Ws + sx;
   const int v = lab_f32 ? (int)reinterpret_cast<const float*>(lab)[si] : (int)reinterpret_cast<const uint8_t*>(lab)[si];
-  bf16x8 lo = {0, 0, 0, 0, 0, 0, 0, 0}, hi = {0, 0, 0, 0, 0, 0, 0, 0};
+  e16x8 lo = {0, 0, 0, 0, 0, 0, 0, 0}, hi = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
   for (int c = 0; c < 16; ++c) {
     float f = 0.f;
     if (c < ncls) f = (v == c) ? 1.f : 0.f;
     else if (c == ncls) f = (v == 255) ? 1.f : 0.f;
-    if (c < 8) lo[c] = (bf16)f; else hi[c - 8] = (bf16)f;
+    if (c < 8) lo[c] = (e16)f; else hi[c - 8] = (e16)f;
   }
-  reinterpret_cast<bf16x8*>(out)[2 * i] = lo;
-  reinterpret_cast<bf16x8*>(out)[2 * i + 1] = hi;
+  reinterpret_cast<e16x8*>(out)[2 * i] = lo;
+  reinterpret_cast<e16x8*>(out)[2 * i + 1] = hi;
 }
 
 // scores[t] = sum_q mass[q][t] * fg[q],  fg = 1 - softmax(bilinear_ac(logits -> enc size))[0]
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(256) void k_mask_iou(const uint8_t* pred, const uin
 }
 
 // frame ingest: uint8 RGB HWC [Hs][Ws][3] -> bicubic resize (OpenCV INTER_CUBIC: a = -0.75, pixel-centre mapping, clamped taps)
-// -> /255, ImageNet mean/std -> fp32 CHW [3][Hd][Wd] and/or NHWC8 bf16 (dataloaders/eval_datasets.py:57-64,
+// -> /255, ImageNet mean/std -> fp32 CHW [3][Hd][Wd] and/or NHWC8 e16 (dataloaders/eval_datasets.py:57-64,
 // video_transforms.py:648-652, 676-680).  One thread per destination pixel.
 __device__ __forceinline__ void cubic_w(float t, float (&w)[4]) {
   const float A = -0.75f;
@@ -285,7 +285,7 @@ __device__ __forceinline__ void cubic_w(float t, float (&w)[4]) {
   w[3] = 1.f - w[0] - w[1] - w[2];
 }
 
-__global__ __launch_bounds__(256) void k_ingest(const uint8_t* src, int Hs, int Ws, int Hd, int Wd, float* out_chw, bf16* out_nhwc8) {
+__global__ __launch_bounds__(256) void k_ingest(const uint8_t* src, int Hs, int Ws, int Hd, int Wd, float* out_chw, e16* out_nhwc8) {
   const long total = (long)Hd * Wd;
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
@@ -318,14 +318,14 @@ __global__ __launch_bounds__(256) void k_ingest(const uint8_t* src, int Hs, int 
     }
   }
   const float mean[3] = {0.485f, 0.456f, 0.406f}, istd[3] = {1.f / 0.229f, 1.f / 0.224f, 1.f / 0.225f};
-  bf16x8 o = {0, 0, 0, 0, 0, 0, 0, 0};
+  e16x8 o = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     const float v = (rgb[c] * (1.f / 255.f) - mean[c]) * istd[c];
     if (out_chw) out_chw[(long)c * total + i] = v;
-    o[c] = (bf16)v;
+    o[c] = (e16)v;
   }
-  if (out_nhwc8) reinterpret_cast<bf16x8*>(out_nhwc8)[i] = o;
+  if (out_nhwc8) reinterpret_cast<e16x8*>(out_nhwc8)[i] = o;
 }
 
 inline unsigned nblk(long total) { return (unsigned)((total + 255) / 256); }
@@ -343,6 +343,7 @@ __global__ __launch_bounds__(256) void k_scatter_blocks(const uint4* src, uint4*
 
 }  // namespace
 
+#ifndef RMEM_F16
 extern "C" int rmem_scatter_blocks(const void* src, void* dst, const int* slots_dev, int nclips, long long block_bytes,
                                    long long slot_bytes, void* stream) {
   RMEM_REQUIRE(src && dst && slots_dev && nclips >= 1 && block_bytes > 0 && block_bytes % 16 == 0 && slot_bytes % 16 == 0,
@@ -353,40 +354,42 @@ extern "C" int rmem_scatter_blocks(const void* src, void* dst, const int* slots_
                      b16, slot_bytes / 16);
   return rmem_check_launch("rmem_scatter_blocks");
 }
+#endif
 
-extern "C" int rmem_image_to_nhwc8_images(const float* img_chw, void* out, int images, int H, int W, void* stream) {
+extern "C" int RMEM_API(rmem_image_to_nhwc8_images)(const float* img_chw, void* out, int images, int H, int W, void* stream) {
   RMEM_REQUIRE(img_chw && out && images >= 1 && H > 0 && W > 0, "rmem_image_to_nhwc8: bad argument");
-  hipLaunchKernelGGL(k_image_to_nhwc8, dim3(nblk((long)H * W), images), dim3(256), 0, (hipStream_t)stream, img_chw, (bf16*)out, H, W);
+  hipLaunchKernelGGL(k_image_to_nhwc8, dim3(nblk((long)H * W), images), dim3(256), 0, (hipStream_t)stream, img_chw, (e16*)out, H, W);
   return rmem_check_launch("rmem_image_to_nhwc8");
 }
 
-extern "C" int rmem_image_to_nhwc8(const float* img_chw, void* out, int H, int W, void* stream) {
-  return rmem_image_to_nhwc8_images(img_chw, out, 1, H, W, stream);
+extern "C" int RMEM_API(rmem_image_to_nhwc8)(const float* img_chw, void* out, int H, int W, void* stream) {
+  return RMEM_API(rmem_image_to_nhwc8_images)(img_chw, out, 1, H, W, stream);
 }
 
-extern "C" int rmem_maxpool3x3s2_nhwc_images(const void* x, void* y, int images, int H, int W, int C, void* stream) {
+extern "C" int RMEM_API(rmem_maxpool3x3s2_nhwc_images)(const void* x, void* y, int images, int H, int W, int C, void* stream) {
   RMEM_REQUIRE(x && y && images >= 1 && H > 0 && W > 0 && C % 8 == 0, "rmem_maxpool3x3s2_nhwc: bad argument");
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-  hipLaunchKernelGGL(k_maxpool3s2, dim3(nblk((long)Ho * Wo * (C / 8)), images), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, (bf16*)y, H, W, C, Ho, Wo);
+  hipLaunchKernelGGL(k_maxpool3s2, dim3(nblk((long)Ho * Wo * (C / 8)), images), dim3(256), 0, (hipStream_t)stream, (const e16*)x, (e16*)y, H, W, C, Ho, Wo);
   return rmem_check_launch("rmem_maxpool3x3s2_nhwc");
 }
 
-extern "C" int rmem_maxpool3x3s2_nhwc(const void* x, void* y, int H, int W, int C, void* stream) {
-  return rmem_maxpool3x3s2_nhwc_images(x, y, 1, H, W, C, stream);
+extern "C" int RMEM_API(rmem_maxpool3x3s2_nhwc)(const void* x, void* y, int H, int W, int C, void* stream) {
+  return RMEM_API(rmem_maxpool3x3s2_nhwc_images)(x, y, 1, H, W, C, stream);
 }
 
-extern "C" int rmem_bilinear_nhwc_images(const void* x, void* y, int images, int Hi, int Wi, int Ho, int Wo, int C, int align_corners,
+extern "C" int RMEM_API(rmem_bilinear_nhwc_images)(const void* x, void* y, int images, int Hi, int Wi, int Ho, int Wo, int C, int align_corners,
                                          void* stream) {
   RMEM_REQUIRE(x && y && images >= 1 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && C % 8 == 0, "rmem_bilinear_nhwc: bad argument");
-  hipLaunchKernelGGL(k_bilinear_nhwc, dim3(nblk((long)Ho * Wo * (C / 8)), images), dim3(256), 0, (hipStream_t)stream, (const bf16*)x,
-                     (bf16*)y, Hi, Wi, Ho, Wo, C, align_corners);
+  hipLaunchKernelGGL(k_bilinear_nhwc, dim3(nblk((long)Ho * Wo * (C / 8)), images), dim3(256), 0, (hipStream_t)stream, (const e16*)x,
+                     (e16*)y, Hi, Wi, Ho, Wo, C, align_corners);
   return rmem_check_launch("rmem_bilinear_nhwc");
 }
 
-extern "C" int rmem_bilinear_nhwc(const void* x, void* y, int Hi, int Wi, int Ho, int Wo, int C, int align_corners, void* stream) {
-  return rmem_bilinear_nhwc_images(x, y, 1, Hi, Wi, Ho, Wo, C, align_corners, stream);
+extern "C" int RMEM_API(rmem_bilinear_nhwc)(const void* x, void* y, int Hi, int Wi, int Ho, int Wo, int C, int align_corners, void* stream) {
+  return RMEM_API(rmem_bilinear_nhwc_images)(x, y, 1, Hi, Wi, Ho, Wo, C, align_corners, stream);
 }
 
+#ifndef RMEM_F16
 extern "C" int rmem_logits_post_images(const float* logits_nhwc, int images, int ldl, int num_classes, int keep_max_id, int Hi, int Wi,
                                        int Ho, int Wo, int align_corners, float* out_nchw, unsigned char* label_u8, float* label_f32,
                                        void* stream) {
@@ -397,26 +400,30 @@ extern "C" int rmem_logits_post_images(const float* logits_nhwc, int images, int
                      keep_max_id, Hi, Wi, Ho, Wo, align_corners, out_nchw, label_u8, label_f32);
   return rmem_check_launch("rmem_logits_post");
 }
+#endif
 
+#ifndef RMEM_F16
 extern "C" int rmem_logits_post(const float* logits_nhwc, int ldl, int num_classes, int keep_max_id, int Hi, int Wi, int Ho, int Wo,
                                 int align_corners, float* out_nchw, unsigned char* label_u8, float* label_f32, void* stream) {
   return rmem_logits_post_images(logits_nhwc, 1, ldl, num_classes, keep_max_id, Hi, Wi, Ho, Wo, align_corners, out_nchw, label_u8, label_f32,
                                  stream);
 }
+#endif
 
-extern "C" int rmem_label_to_onehot16_images(const void* label, int label_is_f32, int images, int Hs, int Ws, int Hd, int Wd, int num_classes,
+extern "C" int RMEM_API(rmem_label_to_onehot16_images)(const void* label, int label_is_f32, int images, int Hs, int Ws, int Hd, int Wd, int num_classes,
                                              void* out, void* stream) {
   RMEM_REQUIRE(label && out && images >= 1 && Hs > 0 && Ws > 0 && Hd > 0 && Wd > 0 && num_classes >= 1 && num_classes <= 15,
                "rmem_label_to_onehot16: bad argument");
   hipLaunchKernelGGL(k_label_onehot, dim3(nblk((long)Hd * Wd), images), dim3(256), 0, (hipStream_t)stream, label, label_is_f32, Hs, Ws, Hd, Wd,
-                     num_classes, (bf16*)out);
+                     num_classes, (e16*)out);
   return rmem_check_launch("rmem_label_to_onehot16");
 }
 
-extern "C" int rmem_label_to_onehot16(const void* label, int label_is_f32, int Hs, int Ws, int Hd, int Wd, int num_classes, void* out, void* stream) {
-  return rmem_label_to_onehot16_images(label, label_is_f32, 1, Hs, Ws, Hd, Wd, num_classes, out, stream);
+extern "C" int RMEM_API(rmem_label_to_onehot16)(const void* label, int label_is_f32, int Hs, int Ws, int Hd, int Wd, int num_classes, void* out, void* stream) {
+  return RMEM_API(rmem_label_to_onehot16_images)(label, label_is_f32, 1, Hs, Ws, Hd, Wd, num_classes, out, stream);
 }
 
+#ifndef RMEM_F16
 extern "C" int rmem_evict_scores(const float* logits_nhwc, int ldl, int num_classes, int keep_max_id, int Hi, int Wi, int He, int We,
                                  const float* attn_mass, int T, float* scores, void* stream) {
   RMEM_REQUIRE(logits_nhwc && attn_mass && scores && T >= 1 && T <= 32 && num_classes >= 1 && num_classes <= 16, "rmem_evict_scores: bad argument");
@@ -428,7 +435,9 @@ extern "C" int rmem_evict_scores(const float* logits_nhwc, int ldl, int num_clas
   hipLaunchKernelGGL(k_evict_final, dim3(1), dim3(64), 0, (hipStream_t)stream, partial, nb, T, scores);
   return rmem_check_launch("rmem_evict_scores");
 }
+#endif
 
+#ifndef RMEM_F16
 extern "C" int rmem_tta_merge(const float* const* logits_nchw, const int* flips, int n_aug, int num_classes, int H, int W,
                               unsigned char* label_u8, float* label_f32, float* prob_nchw, void* stream) {
   RMEM_REQUIRE(logits_nchw && flips && n_aug >= 1 && n_aug <= 8 && num_classes >= 1 && num_classes <= 16, "rmem_tta_merge: 1..8 augmentations, <= 16 classes");
@@ -439,7 +448,9 @@ extern "C" int rmem_tta_merge(const float* const* logits_nchw, const int* flips,
   hipLaunchKernelGGL(k_tta_merge, dim3(nblk((long)H * W)), dim3(256), 0, (hipStream_t)stream, p);
   return rmem_check_launch("rmem_tta_merge");
 }
+#endif
 
+#ifndef RMEM_F16
 extern "C" int rmem_mask_iou_counts(const unsigned char* pred, const unsigned char* gt, long long n, int num_ids, int void_label,
                                     unsigned long long* counts, void* stream) {
   RMEM_REQUIRE(pred && gt && counts && n > 0 && num_ids >= 2 && num_ids <= 32, "rmem_mask_iou_counts: bad argument");
@@ -447,9 +458,10 @@ extern "C" int rmem_mask_iou_counts(const unsigned char* pred, const unsigned ch
   hipLaunchKernelGGL(k_mask_iou, dim3(blocks), dim3(256), 0, (hipStream_t)stream, pred, gt, (long)n, num_ids, void_label, counts);
   return rmem_check_launch("rmem_mask_iou_counts");
 }
+#endif
 
-extern "C" int rmem_ingest_rgb8(const unsigned char* rgb_hwc, int Hs, int Ws, int Hd, int Wd, float* out_chw, void* out_nhwc8, void* stream) {
+extern "C" int RMEM_API(rmem_ingest_rgb8)(const unsigned char* rgb_hwc, int Hs, int Ws, int Hd, int Wd, float* out_chw, void* out_nhwc8, void* stream) {
   RMEM_REQUIRE(rgb_hwc && (out_chw || out_nhwc8) && Hs > 0 && Ws > 0 && Hd > 0 && Wd > 0, "rmem_ingest_rgb8: bad argument");
-  hipLaunchKernelGGL(k_ingest, dim3(nblk((long)Hd * Wd)), dim3(256), 0, (hipStream_t)stream, rgb_hwc, Hs, Ws, Hd, Wd, out_chw, (bf16*)out_nhwc8);
+  hipLaunchKernelGGL(k_ingest, dim3(nblk((long)Hd * Wd)), dim3(256), 0, (hipStream_t)stream, rgb_hwc, Hs, Ws, Hd, Wd, out_chw, (e16*)out_nhwc8);
   return rmem_check_launch("rmem_ingest_rgb8");
 }

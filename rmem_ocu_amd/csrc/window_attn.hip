@@ -23,10 +23,10 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
 struct WinParams {
-  const bf16* qkv;        // [H*W][3C]: q | k | v
+  const e16* qkv;        // [H*W][3C]: q | k | v
   const float* qkv_bias;  // [3C]
   const float* table;     // [4 window types][heads][49][49], (rel-pos bias + mask) * log2(e)
-  bf16* out;              // [H*W][C]
+  e16* out;              // [H*W][C]
   int H, W, C, heads, shift, nwx, nwy;
   float qscale;           // log2(e) / sqrt(32)
 };
@@ -48,17 +48,17 @@ __device__ __forceinline__ int win_token(const WinParams& p, int wy, int wx, int
   return (y < p.H && x < p.W) ? y * p.W + x : -1;
 }
 
-__device__ __forceinline__ bf16x8 load8(const WinParams& p, int tok, int col) {
-  if (tok >= 0) return *reinterpret_cast<const bf16x8*>(p.qkv + (long)tok * 3 * p.C + col);
-  bf16x8 v;
+__device__ __forceinline__ e16x8 load8(const WinParams& p, int tok, int col) {
+  if (tok >= 0) return *reinterpret_cast<const e16x8*>(p.qkv + (long)tok * 3 * p.C + col);
+  e16x8 v;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) v[j] = (bf16)p.qkv_bias[col + j];
+  for (int j = 0; j < 8; ++j) v[j] = (e16)p.qkv_bias[col + j];
   return v;
 }
 
 __global__ __launch_bounds__(128) void k_window_attn(WinParams p) {
-  __shared__ __attribute__((aligned(16))) bf16 Ks[64 * D];
-  __shared__ __attribute__((aligned(16))) bf16 Vs[64 * D];
+  __shared__ __attribute__((aligned(16))) e16 Ks[64 * D];
+  __shared__ __attribute__((aligned(16))) e16 Vs[64 * D];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lq = lane & 31, lh = lane >> 5;
   const int win = blockIdx.x, head = blockIdx.y;
@@ -66,30 +66,30 @@ __global__ __launch_bounds__(128) void k_window_attn(WinParams p) {
   const int type = p.shift > 0 ? ((wy == p.nwy - 1) ? 2 : 0) + ((wx == p.nwx - 1) ? 1 : 0) : 0;
 
   // ---- stage K and V of the window's 64 (49 real) keys ----
-  const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+  const e16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int id = tid + i * 128;
     const int key = id >> 2, chunk = id & 3;
-    bf16x8 kv = zero8, vv = zero8;
+    e16x8 kv = zero8, vv = zero8;
     if (key < NT) {
       const int tok = win_token(p, wy, wx, key);
       kv = load8(p, tok, p.C + head * D + chunk * 8);
       vv = load8(p, tok, 2 * p.C + head * D + chunk * 8);
     }
-    *reinterpret_cast<bf16x8*>(&Ks[kswz(key, chunk)]) = kv;
-    *reinterpret_cast<bf16x8*>(&Vs[key * D + chunk * 8]) = vv;
+    *reinterpret_cast<e16x8*>(&Ks[kswz(key, chunk)]) = kv;
+    *reinterpret_cast<e16x8*>(&Vs[key * D + chunk * 8]) = vv;
   }
 
   // ---- Q^T fragment of this wave's 32 queries ----
   const int qi = wave * 32 + lq;
   const int qtok = qi < NT ? win_token(p, wy, wx, qi) : -1;
-  bf16x8 qf[2];
+  e16x8 qf[2];
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
-    const bf16x8 raw = qi < NT ? load8(p, qtok, head * D + 16 * s + 8 * lh) : zero8;
+    const e16x8 raw = qi < NT ? load8(p, qtok, head * D + 16 * s + 8 * lh) : zero8;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) qf[s][j] = (bf16)((float)raw[j] * p.qscale);
+    for (int j = 0; j < 8; ++j) qf[s][j] = (e16)((float)raw[j] * p.qscale);
   }
   __syncthreads();
 
@@ -105,8 +105,8 @@ __global__ __launch_bounds__(128) void k_window_attn(WinParams p) {
     }
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      const bf16x8 a = *reinterpret_cast<const bf16x8*>(&Ks[kswz(b * 32 + lq, 2 * s + lh)]);
-      sacc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[s], sacc[b], 0, 0, 0);
+      const e16x8 a = *reinterpret_cast<const e16x8*>(&Ks[kswz(b * 32 + lq, 2 * s + lh)]);
+      sacc[b] = RMEM_MFMA_32x32x16(a, qf[s], sacc[b], 0, 0, 0);
     }
   }
   float m = fmaxf(sacc[0][0], sacc[1][0]);
@@ -114,14 +114,14 @@ __global__ __launch_bounds__(128) void k_window_attn(WinParams p) {
   for (int r = 1; r < 16; ++r) m = fmaxf(fmaxf(m, sacc[0][r]), sacc[1][r]);
   m = pair_max(m);
   float l = 0.f;
-  bf16x8 pb[2][2];
+  e16x8 pb[2][2];
 #pragma unroll
   for (int b = 0; b < 2; ++b)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const float e = __builtin_amdgcn_exp2f(sacc[b][r] - m);
       l += e;
-      pb[b][r >> 3][r & 7] = (bf16)e;
+      pb[b][r >> 3][r & 7] = (e16)e;
     }
   l += __shfl_xor(l, 32, 64);
 
@@ -134,32 +134,32 @@ __global__ __launch_bounds__(128) void k_window_attn(WinParams p) {
   for (int b = 0; b < 2; ++b)
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      const bf16* vb = &Vs[(b * 32 + 16 * s) * D + tr_off];
+      const e16* vb = &Vs[(b * 32 + 16 * s) * D + tr_off];
       const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)vb);
       const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vb + 8 * D));
       const __attribute__((ext_vector_type(8))) short a16 = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-      oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a16), pb[b][s], oacc, 0, 0, 0);
+      oacc = RMEM_MFMA_32x32x16(__builtin_bit_cast(e16x8, a16), pb[b][s], oacc, 0, 0, 0);
     }
 
   if (qtok >= 0) {
     const float inv = 1.f / l;
-    bf16* o = p.out + (long)qtok * p.C + head * D + 4 * lh;
+    e16* o = p.out + (long)qtok * p.C + head * D + 4 * lh;
 #pragma unroll
     for (int g = 0; g < 4; ++g)    // C/D rows (r&3) + 8(r>>2) + 4h -> d = 8g + 4h + (0..3)
-      *reinterpret_cast<bf16x4*>(o + 8 * g) = bf16x4{(bf16)(oacc[4 * g] * inv), (bf16)(oacc[4 * g + 1] * inv),
-                                                     (bf16)(oacc[4 * g + 2] * inv), (bf16)(oacc[4 * g + 3] * inv)};
+      *reinterpret_cast<e16x4*>(o + 8 * g) = e16x4{(e16)(oacc[4 * g] * inv), (e16)(oacc[4 * g + 1] * inv),
+                                                     (e16)(oacc[4 * g + 2] * inv), (e16)(oacc[4 * g + 3] * inv)};
   }
 }
 
 }  // namespace
 
-extern "C" int rmem_window_attn(const void* qkv, const float* qkv_bias, const float* bias_mask_table, void* out, int H, int W,
+extern "C" int RMEM_API(rmem_window_attn)(const void* qkv, const float* qkv_bias, const float* bias_mask_table, void* out, int H, int W,
                                 int C, int heads, int shift, void* stream) {
   RMEM_REQUIRE(qkv && qkv_bias && bias_mask_table && out, "rmem_window_attn: null argument");
   RMEM_REQUIRE(H > 0 && W > 0 && heads >= 1 && C == heads * D, "rmem_window_attn: C must equal heads * 32");
   RMEM_REQUIRE(shift == 0 || shift == WS / 2, "rmem_window_attn: shift must be 0 or 3");
   WinParams p;
-  p.qkv = (const bf16*)qkv; p.qkv_bias = qkv_bias; p.table = bias_mask_table; p.out = (bf16*)out;
+  p.qkv = (const e16*)qkv; p.qkv_bias = qkv_bias; p.table = bias_mask_table; p.out = (e16*)out;
   p.H = H; p.W = W; p.C = C; p.heads = heads; p.shift = shift;
   p.nwy = (H + WS - 1) / WS; p.nwx = (W + WS - 1) / WS;
   p.qscale = 1.4426950408889634f / sqrtf((float)D);

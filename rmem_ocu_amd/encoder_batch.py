@@ -31,7 +31,8 @@ class BatchEncoder:
         self.H8, self.W8 = _out(self.H4, 3, 2, 1), _out(self.W4, 3, 2, 1)
         self.H16, self.W16 = _out(self.H8, 3, 2, 1), _out(self.W8, 3, 2, 1)
         M4, M8, L = self.H4 * self.W4, self.H8 * self.W8, self.H16 * self.W16
-        e = lambda *shape, dt=BF16: torch.empty(*shape, dtype=dt, device=device)  # noqa: E731
+        dt16 = P['stem.w'].dtype
+        e = lambda *shape, dt=None: torch.empty(*shape, dtype=dt or dt16, device=device)  # noqa: E731
         self.img_in = e(B, 3, H, W, dt=F32)
         self.img8 = e(B, H * W, 8)
         self.stem = e(B, self.H2 * self.W2, 64)

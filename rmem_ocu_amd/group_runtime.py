@@ -36,6 +36,7 @@ class GroupRuntime:
         if 'pe.w' in P or 'g0.qvu.w' in P:
             raise ops.RmemError('GroupRuntime covers the R50-AOTL path')
         self.P, self.dev, self.NL, self.B = P, device, num_lstt, clips
+        self.dt = P['proj.w'].dtype
         self.align, self.nc = align_corners, num_classes
         H, W = in_hw
         self.H, self.W = H, W
@@ -47,7 +48,7 @@ class GroupRuntime:
         self.L = self.H16 * self.W16
         L, M4, M8 = self.L, self.H4 * self.W4, self.H8 * self.W8
         self.M4, self.M8 = M4, M8
-        e = lambda *shape, dt=BF16: torch.empty(*shape, dtype=dt, device=device)  # noqa: E731
+        e = lambda *shape, dt=None: torch.empty(*shape, dtype=dt or self.dt, device=device)  # noqa: E731
         # ---- encoders: one for the frame in flight (reference frames), one running `lookahead` frames ahead; image = e * B + c
         self.enc_now = BatchEncoder(P, in_hw, B, device)
         self.lookahead = lookahead
@@ -73,7 +74,7 @@ class GroupRuntime:
         self.id_emb = e(R, D_MODEL)
         self.onehot = e(B * H * W, 16)
         pos = sine_pos_emb(self.H16, self.W16).to(device)
-        self.posb = pos.to(BF16).repeat(B, 1).contiguous()
+        self.posb = pos.to(self.dt).repeat(B, 1).contiguous()
         self.pos_qk = [torch.zeros(R, 3 * D_MODEL, dtype=F32, device=device) for _ in range(num_lstt)]
         self._pos_ready = False
         self.attn_ws = ops.attn_workspace(L, HEADS, MAX_CHUNKS, device, nclips=B)
@@ -221,7 +222,7 @@ class GroupRuntime:
             cq = self.curr_Q[i]
             o.append(self._lin(self.curr_V[i], d + '.linear_Q', cq, C, C))
             if ref_mode:
-                o.append(ops.add_bf16(self.curr_V[i], self.id_emb, self.tmpB[i], R * C))
+                o.append(ops.add16(self.curr_V[i], self.id_emb, self.tmpB[i], R * C))
                 o.append(self._lin(self.tmpB[i], d + '.linear_V', self.new_V[i], C, C))
                 o.append(self._scatter(cq, self.bank_K[i]))
                 o.append(self._scatter(self.new_V[i], self.bank_V[i]))
@@ -237,7 +238,7 @@ class GroupRuntime:
             o.append(self._lin(self.att, d + '.short_proj', self.x, C, C, residual=self.x, y2=self.tgt3[i]))
             if ref_mode:   # short-term memory of the reference frame (675-678)
                 o.append(self._lin(self.tgt3[i], d + '.linear_QMem', self.short_K[i], C, C))
-                o.append(ops.add_bf16(self.tgt3[i], self.id_emb, self.tmpA[i], R * C))
+                o.append(ops.add16(self.tgt3[i], self.id_emb, self.tmpA[i], R * C))
                 o.append(self._lin(self.tmpA[i], d + '.linear_VMem', self.short_V[i], C, C))
             o.append(ops.layernorm256(self.x, P[d + '.ln3.g'], P[d + '.ln3.b'], M=R, y=self.t3))
             o.append(self._lin(self.t3, d + '.linear1', self.h1, C, FFN))
@@ -319,7 +320,7 @@ class GroupRuntime:
             return self._prog[key]
         P, NL, L, C, B = self.P, self.NL, self.L, D_MODEL, self.B
         R = B * L
-        o = [ops.add_bf16_grouped(self.tgt3 + (self.curr_V if append else []), [self.id_emb] * (NL * (2 if append else 1)),
+        o = [ops.add16_grouped(self.tgt3 + (self.curr_V if append else []), [self.id_emb] * (NL * (2 if append else 1)),
                                   self.tmpA + (self.tmpB if append else []), R * C)]
         w = lambda nm: [P[f'l{i}.{nm}.w'] for i in range(NL)]   # noqa: E731
         b = lambda nm: [P[f'l{i}.{nm}.b'] for i in range(NL)]   # noqa: E731

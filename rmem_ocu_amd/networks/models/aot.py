@@ -75,14 +75,25 @@ class AOT(nn.Module):
         self._runtimes = {}
         return super().load_state_dict(state_dict, strict=strict, **kw)
 
+    def element_dtype(self):
+        """cfg.MODEL_DTYPE: 'bf16' (default) or 'fp16' -- the 16-bit operand type of every kernel (the reference's counterpart
+        is running with or without --amp, tools/eval.py:45-47; fp16 is what its autocast uses)."""
+        name = str(getattr(self.cfg, 'MODEL_DTYPE', 'bf16')).lower()
+        if name in ('bf16', 'bfloat16'):
+            return torch.bfloat16
+        if name in ('fp16', 'f16', 'float16', 'half'):
+            return torch.float16
+        raise ValueError(f"cfg.MODEL_DTYPE = {name!r}: expected 'bf16' or 'fp16'")
+
     def packed(self) -> Dict[str, torch.Tensor]:
         dev = self.cur_pos_emb.device
-        if self._packed is None or self._packed_device != dev:
+        dt = self.element_dtype()
+        if self._packed is None or self._packed_device != (dev, dt):
             if dev.type != 'cuda':
                 raise RuntimeError('the HIP engine needs the model on a GPU: call model.cuda(gpu_id) '
                                    '(there is no CPU execution path in this package)')
-            self._packed = pack_state_dict(self.state_dict(), dev, self.cfg.MODEL_LSTT_NUM)
-            self._packed_device = dev
+            self._packed = pack_state_dict(self.state_dict(), dev, self.cfg.MODEL_LSTT_NUM, dtype=dt)
+            self._packed_device = (dev, dt)
             self._runtimes = {}
         return self._packed
 

@@ -17,7 +17,24 @@ from . import _lib
 from ._lib import AttnChunk, ConvDesc, RmemError
 
 BF16 = torch.bfloat16
+F16 = torch.float16
 F32 = torch.float32
+E16 = (BF16, F16)     # the two 16-bit element types the library is built for (include/rmem.h: <name> and <name>_f16)
+
+
+def _fn(name: str, dt):
+    """The entry point for operands of element type dt: <name> (bfloat16) or <name>_f16 (IEEE half)."""
+    if dt not in E16:
+        raise RmemError(f'{name}: 16-bit operands must be bfloat16 or float16, got {dt}')
+    return getattr(_lib.lib(), name + ('_f16' if dt == F16 else ''))
+
+
+def _first16(*ts):
+    """Element type of the first 16-bit tensor among ts (bfloat16 if there is none: every flavour then does the same work)."""
+    for t in ts:
+        if t is not None and t.dtype in E16:
+            return t.dtype
+    return BF16
 
 
 class Op:
@@ -59,10 +76,11 @@ def conv2d(x, w, bias, y, *, H, W, Cin, Cout, KH=1, KW=1, stride=1, pad=0, resid
     relu: False/0 none, True/1 ReLU, 2 exact GELU, 3 SiLU (channels >= act_begin); ldx: input row stride of a 1x1 problem.
     res_up=(h, w, align_corners): residual is a bf16 [batch, h, w, ldr] map, bilinearly resized to the output size on the fly."""
     _dev(x, w, bias, y, residual, y2)
-    assert x.dtype == BF16 and w.dtype == BF16 and w.is_contiguous()
+    dt = w.dtype
+    assert x.dtype == dt and w.dtype == dt and w.is_contiguous()
     assert w.numel() == Cout * KH * KW * Cin, (w.shape, Cout, KH, KW, Cin)
     assert bias is None or (bias.dtype == F32 and bias.numel() == Cout)
-    assert y.dtype in (BF16, F32) and (y2 is None or y2.dtype == BF16)
+    assert y.dtype in (dt, F32) and (y2 is None or y2.dtype == dt)
     Ho = (H + 2 * pad - KH) // stride + 1
     Wo = (W + 2 * pad - KW) // stride + 1
     ldo = Cout if ldo is None else ldo
@@ -72,7 +90,7 @@ def conv2d(x, w, bias, y, *, H, W, Cin, Cout, KH=1, KW=1, stride=1, pad=0, resid
     assert batch == 1 or not ldx
     ru = (0, 0, 0) if res_up is None else (int(res_up[0]), int(res_up[1]), int(bool(res_up[2])))
     if res_up is not None:
-        assert residual is not None and residual.dtype == BF16 and residual.numel() >= (batch * ru[0] * ru[1] - 1) * ldr + Cout
+        assert residual is not None and residual.dtype == dt and residual.numel() >= (batch * ru[0] * ru[1] - 1) * ldr + Cout
     d = ConvDesc(H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, ldo, ldr, ld2, int(relu), int(y.dtype == F32),
                  int(residual is not None and residual.dtype == F32), ldx, batch, act_begin, *ru)
     if ws is not None:   # split-K workspace: use it only if it is big enough for this problem
@@ -80,19 +98,20 @@ def conv2d(x, w, bias, y, *, H, W, Cin, Cout, KH=1, KW=1, stride=1, pad=0, resid
         if ws.numel() * ws.element_size() < _lib.lib().rmem_conv_workspace_bytes(C.byref(d)):
             ws = None
     args = (C.byref(d), _ptr(x), _ptr(w), _ptr(bias), _ptr(residual), _ptr(y), _ptr(y2), _ptr(ws))
-    return Op(_lib.lib().rmem_conv2d_nhwc, args, 'rmem_conv2d_nhwc', (d, x, w, bias, residual, y, y2, ws))
+    return Op(_fn('rmem_conv2d_nhwc', dt), args, 'rmem_conv2d_nhwc', (d, x, w, bias, residual, y, y2, ws))
 
 
 def conv1x1_dual(x, x2, w_cat, bias, y, *, H, W, Cin, Cout, H2, W2, Cin2, stride2, relu=False, batch=1) -> Op:
     """y = act([x | x2 sampled at stride2] @ w_cat^T + bias): bottleneck conv3 + its 1x1 shortcut as one GEMM.
     x [batch*H*W, Cin] bf16, x2 NHWC [batch, H2, W2, Cin2] bf16, w_cat [Cout, Cin + Cin2] bf16."""
     _dev(x, x2, w_cat, bias, y)
-    assert x.dtype == BF16 and x2.dtype == BF16 and w_cat.dtype == BF16 and w_cat.is_contiguous() and y.dtype == BF16
+    dt = w_cat.dtype
+    assert x.dtype == dt and x2.dtype == dt and w_cat.dtype == dt and w_cat.is_contiguous() and y.dtype == dt
     assert w_cat.numel() == Cout * (Cin + Cin2) and bias.dtype == F32 and bias.numel() == Cout
     assert x.numel() >= batch * H * W * Cin and x2.numel() >= batch * H2 * W2 * Cin2 and y.numel() >= batch * H * W * Cout
     d = ConvDesc(H, W, Cin, H, W, Cout, 1, 1, 1, 0, Cout, Cout, Cout, int(relu), 0, 0, 0, batch, 0, 0, 0, 0)
     args = (C.byref(d), _ptr(x), _ptr(x2), H2, W2, Cin2, stride2, _ptr(w_cat), _ptr(bias), _ptr(y))
-    return Op(_lib.lib().rmem_conv1x1_dual_nhwc, args, 'rmem_conv1x1_dual_nhwc', (d, x, x2, w_cat, bias, y))
+    return Op(_fn('rmem_conv1x1_dual_nhwc', dt), args, 'rmem_conv1x1_dual_nhwc', (d, x, x2, w_cat, bias, y))
 
 
 def linear(x, w, bias, y, *, M, K, N, residual=None, y2=None, relu=False, ldo=None, ldr=None, ld2=None, ws=None, ldx=0,
@@ -111,31 +130,34 @@ def linear_grouped(xs, ws, biases, ys, *, M, K, N, residuals=None, relu=False) -
     n = len(xs)
     assert 1 <= n <= 4 and len(ws) == n and len(ys) == n and (biases is None or len(biases) == n)
     _dev(*xs, *ws, *ys, *(biases or ()), *(residuals or ()))
+    dt = ws[0].dtype
     for x, w, y in zip(xs, ws, ys):
-        assert x.dtype == BF16 and w.dtype == BF16 and w.numel() == N * K and x.numel() >= M * K and y.numel() >= M * N
+        assert x.dtype == dt and w.dtype == dt and w.numel() == N * K and x.numel() >= M * K and y.numel() >= M * N
     assert len({y.dtype for y in ys}) == 1 and (residuals is None or len({r.dtype for r in residuals}) == 1)
     d = ConvDesc(M, 1, K, M, 1, N, 1, 1, 1, 0, N, N, N, int(relu), int(ys[0].dtype == F32),
                  int(residuals is not None and residuals[0].dtype == F32), 0, 1, 0)
     arrs = (_ptr_array(xs), _ptr_array(ws), _ptr_array(biases) if biases is not None else None,
             _ptr_array(residuals) if residuals is not None else None, _ptr_array(ys))
     args = (C.byref(d), n, arrs[0], arrs[1], arrs[2], arrs[3], arrs[4])
-    return Op(_lib.lib().rmem_linear_grouped, args, 'rmem_linear_grouped', (d, arrs, xs, ws, biases, residuals, ys))
+    return Op(_fn('rmem_linear_grouped', dt), args, 'rmem_linear_grouped', (d, arrs, xs, ws, biases, residuals, ys))
 
 
-def add_bf16_grouped(as_, bs, ys, n: int) -> Op:
+def add16_grouped(as_, bs, ys, n: int) -> Op:
     """len(as_) <= 8 adds y_i = a_i + b_i over n elements each as one launch."""
     _dev(*as_, *bs, *ys)
-    assert len(as_) == len(bs) == len(ys) <= 8 and all(t.dtype == BF16 for t in (*as_, *bs, *ys))
+    dt = as_[0].dtype
+    assert len(as_) == len(bs) == len(ys) <= 8 and all(t.dtype == dt for t in (*as_, *bs, *ys))
     arrs = (_ptr_array(as_), _ptr_array(bs), _ptr_array(ys))
-    return Op(_lib.lib().rmem_add_bf16_grouped, (len(as_), arrs[0], arrs[1], arrs[2], n), 'rmem_add_bf16_grouped', (arrs, as_, bs, ys))
+    return Op(_fn('rmem_add16_grouped', dt), (len(as_), arrs[0], arrs[1], arrs[2], n), 'rmem_add16_grouped', (arrs, as_, bs, ys))
 
 
 def layernorm256_pair(a0, b0, y0, a1, b1, y1, gamma, beta, *, M, eps=1e-5) -> Op:
     """y0 = LN(a0 + b0), y1 = LN(a1 + b1) with one weight set, [M, 256] bf16 contiguous, one launch."""
     _dev(a0, b0, y0, a1, b1, y1, gamma, beta)
-    assert all(t.dtype == BF16 and t.numel() >= M * 256 for t in (a0, b0, y0, a1, b1, y1)) and gamma.dtype == F32
+    dt = a0.dtype
+    assert all(t.dtype == dt and t.numel() >= M * 256 for t in (a0, b0, y0, a1, b1, y1)) and gamma.dtype == F32
     args = (_ptr(a0), _ptr(b0), _ptr(y0), _ptr(a1), _ptr(b1), _ptr(y1), _ptr(gamma), _ptr(beta), eps, M)
-    return Op(_lib.lib().rmem_layernorm256_pair, args, 'rmem_layernorm256_pair', (a0, b0, y0, a1, b1, y1, gamma, beta))
+    return Op(_fn('rmem_layernorm256_pair', dt), args, 'rmem_layernorm256_pair', (a0, b0, y0, a1, b1, y1, gamma, beta))
 
 
 def attn_workspace(Lq: int, heads: int, nchunks: int, device, nclips: int = 1) -> torch.Tensor:
@@ -156,54 +178,60 @@ def mem_read_attn(q, k_bank, v_bank, out, workspace, *, Lq, heads=8, ldq, ldkv, 
     """nclips > 1: that many clips of identical shape in one launch (clip c's operands c * {q,kv,out}_cs elements further, its
     chunk rows at chunks[c * nchunks:], its mass at mass[c * Lq * T:])."""
     _dev(q, k_bank, v_bank, out, workspace, chunks, pe_cur, pe_mem, mass)
-    assert q.dtype == BF16 and k_bank.dtype == BF16 and v_bank.dtype == BF16 and out.dtype == BF16
+    dt = q.dtype
+    assert q.dtype == dt and k_bank.dtype == dt and v_bank.dtype == dt and out.dtype == dt
     assert workspace.numel() * 4 >= nclips * _lib.lib().rmem_attn_workspace_bytes(Lq, heads, nchunks)
     assert chunks is None or (chunks.dtype == torch.int32 and chunks.numel() >= nclips * nchunks * 8)
     assert mass is None or (mass.dtype == F32 and mass.numel() >= nclips * Lq * T)
     args = (_ptr(q), ldq, _ptr(k_bank), _ptr(v_bank), slot_stride, ldkv, _ptr(chunks), nchunks, lk_single,
             _ptr(pe_cur), _ptr(pe_mem), Lq, heads, _ptr(out), ldo, _ptr(mass), T, nclips, q_cs, kv_cs, out_cs, _ptr(workspace))
-    return Op(_lib.lib().rmem_mem_read_attn_clips, args, 'rmem_mem_read_attn',
+    return Op(_fn('rmem_mem_read_attn_clips', dt), args, 'rmem_mem_read_attn',
               (q, k_bank, v_bank, out, workspace, chunks, pe_cur, pe_mem, mass))
 
 
 def layernorm256(a, gamma, beta, *, M, lda=256, b=None, ldb=256, y=None, ldy=256, pos=None, ypos=None, ldyp=256,
                  yf=None, ldyf=256, eps=1e-5) -> Op:
     _dev(a, b, gamma, beta, y, pos, ypos, yf)
-    assert a.dtype in (BF16, F32) and (b is None or b.dtype in (BF16, F32))
+    dt = _first16(y, ypos, a, b)
+    assert a.dtype in (dt, F32) and (b is None or b.dtype in (dt, F32))
     assert gamma.dtype == F32 and beta.dtype == F32 and gamma.numel() == 256
-    assert (y is None or y.dtype == BF16) and (ypos is None or ypos.dtype == BF16) and (yf is None or yf.dtype == F32)
+    assert (y is None or y.dtype == dt) and (ypos is None or ypos.dtype == dt) and (yf is None or yf.dtype == F32)
     args = (_ptr(a), int(a.dtype == F32), lda, _ptr(b), int(b is not None and b.dtype == F32), ldb, _ptr(gamma), _ptr(beta),
             eps, M, _ptr(y), ldy, _ptr(pos), _ptr(ypos), ldyp, _ptr(yf), ldyf)
-    return Op(_lib.lib().rmem_layernorm256, args, 'rmem_layernorm256', (a, b, gamma, beta, y, pos, ypos, yf))
+    return Op(_fn('rmem_layernorm256', dt), args, 'rmem_layernorm256', (a, b, gamma, beta, y, pos, ypos, yf))
 
 
 def layernorm(a, gamma, beta, *, M, C, lda=None, y=None, ldy=None, yf=None, ldyf=None, eps=1e-5) -> Op:
     """LayerNorm over C in {128, 256, 512, 1024}."""
     _dev(a, gamma, beta, y, yf)
-    assert a.dtype in (BF16, F32) and gamma.dtype == F32 and gamma.numel() == C
+    dt = _first16(y, a)
+    assert a.dtype in (dt, F32) and gamma.dtype == F32 and gamma.numel() == C
     args = (_ptr(a), int(a.dtype == F32), C if lda is None else lda, _ptr(gamma), _ptr(beta), eps, M, C, _ptr(y),
             C if ldy is None else ldy, _ptr(yf), C if ldyf is None else ldyf)
-    return Op(_lib.lib().rmem_layernorm, args, 'rmem_layernorm', (a, gamma, beta, y, yf))
+    return Op(_fn('rmem_layernorm', dt), args, 'rmem_layernorm', (a, gamma, beta, y, yf))
 
 
 def patch_merge_ln(x, gamma, beta, y, *, H, W, C, eps=1e-5) -> Op:
     _dev(x, gamma, beta, y)
-    assert x.dtype == F32 and y.dtype == BF16 and gamma.numel() == 4 * C
-    return Op(_lib.lib().rmem_patch_merge_ln, (_ptr(x), H, W, C, _ptr(gamma), _ptr(beta), eps, _ptr(y)), 'rmem_patch_merge_ln', (x, gamma, beta, y))
+    dt = y.dtype
+    assert x.dtype == F32 and y.dtype == dt and gamma.numel() == 4 * C
+    return Op(_fn('rmem_patch_merge_ln', dt), (_ptr(x), H, W, C, _ptr(gamma), _ptr(beta), eps, _ptr(y)), 'rmem_patch_merge_ln', (x, gamma, beta, y))
 
 
 def window_attn(qkv, qkv_bias, table, out, *, H, W, C, heads, shift) -> Op:
     _dev(qkv, qkv_bias, table, out)
-    assert qkv.dtype == BF16 and out.dtype == BF16 and qkv_bias.dtype == F32 and table.dtype == F32
+    dt = qkv.dtype
+    assert qkv.dtype == dt and out.dtype == dt and qkv_bias.dtype == F32 and table.dtype == F32
     assert qkv_bias.numel() == 3 * C and table.numel() == 4 * heads * 49 * 49 and table.is_contiguous()
-    return Op(_lib.lib().rmem_window_attn, (_ptr(qkv), _ptr(qkv_bias), _ptr(table), _ptr(out), H, W, C, heads, shift),
+    return Op(_fn('rmem_window_attn', dt), (_ptr(qkv), _ptr(qkv_bias), _ptr(table), _ptr(out), H, W, C, heads, shift),
               'rmem_window_attn', (qkv, qkv_bias, table, out))
 
 
-def add_bf16(a, b, y, n: int) -> Op:
+def add16(a, b, y, n: int) -> Op:
     _dev(a, b, y)
-    assert a.dtype == BF16 and b.dtype == BF16 and y.dtype == BF16
-    return Op(_lib.lib().rmem_add_bf16, (_ptr(a), _ptr(b), _ptr(y), n), 'rmem_add_bf16', (a, b, y))
+    dt = a.dtype
+    assert a.dtype == dt and b.dtype == dt and y.dtype == dt
+    return Op(_fn('rmem_add16', dt), (_ptr(a), _ptr(b), _ptr(y), n), 'rmem_add16', (a, b, y))
 
 
 def groupnorm_workspace(groups: int, device, images: int = 1) -> torch.Tensor:
@@ -213,71 +241,79 @@ def groupnorm_workspace(groups: int, device, images: int = 1) -> torch.Tensor:
 def groupnorm(x, gamma, beta, y, ws, *, M, C, groups, act=0, eps=1e-5, images=1) -> Op:
     """images > 1: x / y are [images][M][C], statistics per image."""
     _dev(x, gamma, beta, y, ws)
-    assert x.dtype in (BF16, F32) and y.dtype == BF16 and gamma.dtype == F32 and gamma.numel() == C
+    dt = y.dtype
+    assert x.dtype in (dt, F32) and y.dtype == dt and gamma.dtype == F32 and gamma.numel() == C
     assert ws.numel() * 4 >= images * _lib.lib().rmem_groupnorm_workspace_bytes(groups)
     if images > 1:
-        assert x.dtype == BF16
+        assert x.dtype == dt
         args = (_ptr(x), images, M, C, groups, _ptr(gamma), _ptr(beta), eps, act, _ptr(y), _ptr(ws))
-        return Op(_lib.lib().rmem_groupnorm_nhwc_images, args, 'rmem_groupnorm_nhwc', (x, gamma, beta, y, ws))
+        return Op(_fn('rmem_groupnorm_nhwc_images', dt), args, 'rmem_groupnorm_nhwc', (x, gamma, beta, y, ws))
     args = (_ptr(x), M, C, groups, _ptr(gamma), _ptr(beta), eps, act, _ptr(y), _ptr(ws))
     if x.dtype == F32:
-        return Op(_lib.lib().rmem_groupnorm_f32_nhwc, args, 'rmem_groupnorm_f32_nhwc', (x, gamma, beta, y, ws))
-    return Op(_lib.lib().rmem_groupnorm_nhwc, args, 'rmem_groupnorm_nhwc', (x, gamma, beta, y, ws))
+        return Op(_fn('rmem_groupnorm_f32_nhwc', dt), args, 'rmem_groupnorm_f32_nhwc', (x, gamma, beta, y, ws))
+    return Op(_fn('rmem_groupnorm_nhwc', dt), args, 'rmem_groupnorm_nhwc', (x, gamma, beta, y, ws))
 
 
 def groupnorm_head(x, gamma, beta, w, bias, y, ws, *, M, C, groups, N, ldy, act=1, eps=1e-5, images=1) -> Op:
     """y[images*M, ldy] fp32: y[:, :N] = act(GroupNorm(x)) @ w^T + bias with w [N, C] bf16 (N <= 16, C == 128), one pass over x."""
     _dev(x, gamma, beta, w, bias, y, ws)
-    assert x.dtype == BF16 and w.dtype == BF16 and y.dtype == F32 and gamma.dtype == F32 and gamma.numel() == C
+    dt = x.dtype
+    assert x.dtype == dt and w.dtype == dt and y.dtype == F32 and gamma.dtype == F32 and gamma.numel() == C
     assert w.numel() == N * C and w.is_contiguous() and (bias is None or (bias.dtype == F32 and bias.numel() == N))
     assert x.numel() >= images * M * C and y.numel() >= (images * M - 1) * ldy + N
     assert ws.numel() * 4 >= images * _lib.lib().rmem_groupnorm_workspace_bytes(groups)
     args = (_ptr(x), images, M, C, groups, _ptr(gamma), _ptr(beta), eps, act, _ptr(w), _ptr(bias), N, _ptr(y), ldy, _ptr(ws))
-    return Op(_lib.lib().rmem_groupnorm_head_nhwc_images, args, 'rmem_groupnorm_head_nhwc', (x, gamma, beta, w, bias, y, ws))
+    return Op(_fn('rmem_groupnorm_head_nhwc_images', dt), args, 'rmem_groupnorm_head_nhwc', (x, gamma, beta, w, bias, y, ws))
 
 
 def gn_act_dwconv5x5(x, gamma, beta, w_t, y, ws, *, H, W, C, groups, act=2, eps=1e-5, images=1) -> Op:
     """y = dwconv5x5(act(GroupNorm(x))): statistics launch + one fused normalise / activate / convolve launch."""
     _dev(x, gamma, beta, w_t, y, ws)
-    assert x.dtype == BF16 and y.dtype == BF16 and w_t.dtype == F32 and w_t.numel() == 25 * C and gamma.numel() == C
+    dt = x.dtype
+    assert x.dtype == dt and y.dtype == dt and w_t.dtype == F32 and w_t.numel() == 25 * C and gamma.numel() == C
     assert ws.numel() * 4 >= images * _lib.lib().rmem_groupnorm_workspace_bytes(groups)
     args = (_ptr(x), images, H, W, C, groups, _ptr(gamma), _ptr(beta), eps, act, _ptr(w_t), _ptr(y), _ptr(ws))
-    return Op(_lib.lib().rmem_gn_act_dwconv5x5_nhwc_images, args, 'rmem_gn_act_dwconv5x5_nhwc', (x, gamma, beta, w_t, y, ws))
+    return Op(_fn('rmem_gn_act_dwconv5x5_nhwc_images', dt), args, 'rmem_gn_act_dwconv5x5_nhwc', (x, gamma, beta, w_t, y, ws))
 
 
 def dwconv5x5(x, w_t, y, *, H, W, C) -> Op:
     _dev(x, w_t, y)
-    assert x.dtype == BF16 and y.dtype == BF16 and w_t.dtype == F32 and w_t.numel() == 25 * C
-    return Op(_lib.lib().rmem_dwconv5x5_nhwc, (_ptr(x), _ptr(w_t), _ptr(y), H, W, C), 'rmem_dwconv5x5_nhwc', (x, w_t, y))
+    dt = x.dtype
+    assert x.dtype == dt and y.dtype == dt and w_t.dtype == F32 and w_t.numel() == 25 * C
+    return Op(_fn('rmem_dwconv5x5_nhwc', dt), (_ptr(x), _ptr(w_t), _ptr(y), H, W, C), 'rmem_dwconv5x5_nhwc', (x, w_t, y))
 
 
 def image_to_nhwc8(img, out, *, H, W, images=1) -> Op:
     """fp32 [images, 3, H, W] -> bf16 [images, H*W, 8]"""
     _dev(img, out)
-    assert img.dtype == F32 and img.is_contiguous() and img.numel() == images * 3 * H * W and out.dtype == BF16
+    dt = out.dtype
+    assert img.dtype == F32 and img.is_contiguous() and img.numel() == images * 3 * H * W and out.dtype == dt
     assert out.is_contiguous() and out.numel() >= images * H * W * 8
-    return Op(_lib.lib().rmem_image_to_nhwc8_images, (_ptr(img), _ptr(out), images, H, W), 'rmem_image_to_nhwc8', (img, out))
+    return Op(_fn('rmem_image_to_nhwc8_images', dt), (_ptr(img), _ptr(out), images, H, W), 'rmem_image_to_nhwc8', (img, out))
 
 
 def ingest_rgb8(rgb, *, Hs, Ws, Hd, Wd, out_chw=None, out_nhwc8=None) -> Op:
     """uint8 RGB [Hs, Ws, 3] device tensor -> resized, normalised fp32 [3, Hd, Wd] and/or bf16 [Hd*Wd, 8]."""
     _dev(rgb, out_chw, out_nhwc8)
+    dt = _first16(out_nhwc8)
     assert rgb.dtype == torch.uint8 and rgb.is_contiguous() and rgb.numel() == Hs * Ws * 3
-    assert (out_chw is None or out_chw.dtype == F32) and (out_nhwc8 is None or out_nhwc8.dtype == BF16)
-    return Op(_lib.lib().rmem_ingest_rgb8, (_ptr(rgb), Hs, Ws, Hd, Wd, _ptr(out_chw), _ptr(out_nhwc8)), 'rmem_ingest_rgb8', (rgb, out_chw, out_nhwc8))
+    assert (out_chw is None or out_chw.dtype == F32) and (out_nhwc8 is None or out_nhwc8.dtype == dt)
+    return Op(_fn('rmem_ingest_rgb8', dt), (_ptr(rgb), Hs, Ws, Hd, Wd, _ptr(out_chw), _ptr(out_nhwc8)), 'rmem_ingest_rgb8', (rgb, out_chw, out_nhwc8))
 
 
 def maxpool3x3s2(x, y, *, H, W, C, images=1) -> Op:
     _dev(x, y)
+    dt = x.dtype
     assert x.is_contiguous() and y.is_contiguous() and x.numel() >= images * H * W * C
     assert y.numel() >= images * ((H - 1) // 2 + 1) * ((W - 1) // 2 + 1) * C
-    return Op(_lib.lib().rmem_maxpool3x3s2_nhwc_images, (_ptr(x), _ptr(y), images, H, W, C), 'rmem_maxpool3x3s2_nhwc', (x, y))
+    return Op(_fn('rmem_maxpool3x3s2_nhwc_images', dt), (_ptr(x), _ptr(y), images, H, W, C), 'rmem_maxpool3x3s2_nhwc', (x, y))
 
 
 def bilinear(x, y, *, Hi, Wi, Ho, Wo, C, align_corners=True, images=1) -> Op:
     _dev(x, y)
-    assert x.dtype == BF16 and y.dtype == BF16 and x.numel() >= images * Hi * Wi * C and y.numel() >= images * Ho * Wo * C
-    return Op(_lib.lib().rmem_bilinear_nhwc_images, (_ptr(x), _ptr(y), images, Hi, Wi, Ho, Wo, C, int(align_corners)),
+    dt = x.dtype
+    assert x.dtype == dt and y.dtype == dt and x.numel() >= images * Hi * Wi * C and y.numel() >= images * Ho * Wo * C
+    return Op(_fn('rmem_bilinear_nhwc_images', dt), (_ptr(x), _ptr(y), images, Hi, Wi, Ho, Wo, C, int(align_corners)),
               'rmem_bilinear_nhwc', (x, y))
 
 
@@ -295,10 +331,11 @@ def logits_post(logits, *, ldl, nc, keep, Hi, Wi, Ho, Wo, align_corners=True, ou
 def label_to_onehot16(label, out, *, Hs, Ws, Hd, Wd, ncls=11, images=1) -> Op:
     """label [images, Hs, Ws] uint8 / fp32 -> bf16 [images, Hd*Wd, 16]"""
     _dev(label, out)
-    assert label.dtype in (torch.uint8, F32) and label.is_contiguous() and out.dtype == BF16
+    dt = out.dtype
+    assert label.dtype in (torch.uint8, F32) and label.is_contiguous() and out.dtype == dt
     assert label.numel() >= images * Hs * Ws and out.numel() >= images * Hd * Wd * 16
     args = (_ptr(label), int(label.dtype == F32), images, Hs, Ws, Hd, Wd, ncls, _ptr(out))
-    return Op(_lib.lib().rmem_label_to_onehot16_images, args, 'rmem_label_to_onehot16', (label, out))
+    return Op(_fn('rmem_label_to_onehot16_images', dt), args, 'rmem_label_to_onehot16', (label, out))
 
 
 def evict_scores(logits, mass, scores, *, ldl, nc, keep, Hi, Wi, He, We, T) -> Op:
@@ -372,8 +409,9 @@ def gated_attn(q, k_bank, v_bank, u_a, out, workspace, *, Lq, DV, ldq, ldk, ldv,
                mass=None, dw=None, H=0, W=0) -> Op:
     """DeAOT gated propagation attention (single head, d_att 128); see include/rmem.h."""
     _dev(q, k_bank, v_bank, u_a, u_b, out, workspace, chunks, pe_cur, pe_mem, mass, dw)
+    dt = q.dtype
     assert dw is None or (dw.dtype == F32 and dw.numel() == 25 * DV and H * W == Lq)
-    assert all(t.dtype == BF16 for t in (q, k_bank, v_bank, u_a, out)) and (u_b is None or u_b.dtype == BF16)
+    assert all(t.dtype == dt for t in (q, k_bank, v_bank, u_a, out)) and (u_b is None or u_b.dtype == dt)
     assert workspace.numel() * 4 >= _lib.lib().rmem_gated_attn_workspace_bytes(Lq, DV, frames, keys_per_frame, nchunks)
     assert chunks is None or (chunks.dtype == torch.int32 and chunks.numel() >= nchunks * 8)
     assert mass is None or (mass.dtype == F32 and mass.numel() >= Lq * frames)
@@ -381,7 +419,7 @@ def gated_attn(q, k_bank, v_bank, u_a, out, workspace, *, Lq, DV, ldq, ldk, ldv,
     args = (_ptr(q), ldq, _ptr(k_bank), k_slot_stride, ldk, _ptr(v_bank), v_slot_stride, ldv, _ptr(chunks), nchunks, frames,
             keys_per_frame, _ptr(pe_cur), _ptr(pe_mem), Lq, DV, _ptr(u_a), ldua, _ptr(u_b), ldub, usplit, _ptr(out), ldo,
             _ptr(mass), _ptr(dw), H, W, _ptr(workspace))
-    return Op(_lib.lib().rmem_gated_attn, args, 'rmem_gated_attn',
+    return Op(_fn('rmem_gated_attn', dt), args, 'rmem_gated_attn',
               (q, k_bank, v_bank, u_a, u_b, out, workspace, chunks, pe_cur, pe_mem, mass, dw))
 
 
@@ -389,13 +427,14 @@ def local_gated_attn(q, k, v, rel, u_a, out, workspace, *, H, W, DV, ldq, ldk, l
                      usplit=None, dw=None) -> Op:
     """DeAOT 15x15 local gated propagation attention; rel = relative_emb_k(q) fp32 [H*W][ldrel]."""
     _dev(q, k, v, rel, u_a, u_b, out, workspace, dw)
+    dt = q.dtype
     assert dw is None or (dw.dtype == F32 and dw.numel() == 25 * DV)
-    assert all(t.dtype == BF16 for t in (q, k, v, u_a, out)) and rel.dtype == F32
+    assert all(t.dtype == dt for t in (q, k, v, u_a, out)) and rel.dtype == F32
     assert workspace.numel() * 4 >= _lib.lib().rmem_gated_attn_workspace_bytes(H * W, DV, 1, H * W, 8)
     usplit = DV if usplit is None else usplit
     args = (_ptr(q), ldq, _ptr(k), ldk, _ptr(v), ldv, _ptr(rel), ldrel, H, W, DV, _ptr(u_a), ldua, _ptr(u_b), ldub, usplit,
             _ptr(out), ldo, _ptr(dw), _ptr(workspace))
-    return Op(_lib.lib().rmem_local_gated_attn, args, 'rmem_local_gated_attn', (q, k, v, rel, u_a, u_b, out, workspace, dw))
+    return Op(_fn('rmem_local_gated_attn', dt), args, 'rmem_local_gated_attn', (q, k, v, rel, u_a, u_b, out, workspace, dw))
 
 
 class Graph:

@@ -13,6 +13,7 @@ from typing import Dict
 import torch
 
 BN_EPS = 1e-5
+_DT = torch.bfloat16          # element type of the pack in progress (set by pack_state_dict)
 R50_BLOCKS = (3, 4, 6)
 R50_STRIDES = (1, 2, 2)
 
@@ -22,7 +23,7 @@ def _conv_w(w: torch.Tensor, cin_pad: int = 0) -> torch.Tensor:
     w = w.permute(0, 2, 3, 1)
     if cin_pad and cin_pad > cin:
         w = torch.nn.functional.pad(w, (0, cin_pad - cin))
-    return w.contiguous().to(torch.bfloat16)
+    return w.contiguous().to(_DT)
 
 
 def _fold_bn(sd, conv_key: str, bn_prefix: str, cin_pad: int = 0):
@@ -61,13 +62,13 @@ def _pack_swin(sd, put):
             for nm in ('norm1', 'norm2'):
                 put(f'{d}.{nm}.g', sd[f'{s}.{nm}.weight'].float()); put(f'{d}.{nm}.b', sd[f'{s}.{nm}.bias'].float())
             for dst, src in (('qkv', 'attn.qkv'), ('proj', 'attn.proj'), ('fc1', 'mlp.fc1'), ('fc2', 'mlp.fc2')):
-                put(f'{d}.{dst}.w', sd[f'{s}.{src}.weight'].float().to(torch.bfloat16)); put(f'{d}.{dst}.b', sd[f'{s}.{src}.bias'].float())
+                put(f'{d}.{dst}.w', sd[f'{s}.{src}.weight'].float().to(_DT)); put(f'{d}.{dst}.b', sd[f'{s}.{src}.bias'].float())
             tbl = sd[f'{s}.attn.relative_position_bias_table'].float()[sd[f'{s}.attn.relative_position_index'].view(-1)]
             bias = tbl.view(49, 49, heads).permute(2, 0, 1)                                   # [heads, q, k]
             put(f'{d}.table', (bias[None] + masks[:, None].to(bias.device)) * LOG2E)           # [4, heads, 49, 49]
         if li < len(SWIN_DEPTHS) - 1:
             s = f'encoder.layers.{li}.downsample'
-            put(f'sw{li}.merge.w', sd[s + '.reduction.weight'].float().to(torch.bfloat16))
+            put(f'sw{li}.merge.w', sd[s + '.reduction.weight'].float().to(_DT))
             put(f'sw{li}.merge.g', sd[s + '.norm.weight'].float()); put(f'sw{li}.merge.b', sd[s + '.norm.bias'].float())
         put(f'sw.norm{li}.g', sd[f'encoder.norm{li}.weight'].float()); put(f'sw.norm{li}.b', sd[f'encoder.norm{li}.bias'].float())
 
@@ -81,7 +82,7 @@ def pack_deaot_self(sd, p: str):
     blk = lambda a, b: torch.cat([torch.cat([f(a + '.weight'), z], 1), torch.cat([z, f(b + '.weight')], 1)], 0)   # noqa: E731
     W = torch.cat([f('.linear_QK.weight'), blk('.linear_V1', '.linear_V2'), blk('.linear_U1', '.linear_U2')], 0)
     b = torch.cat([f('.linear_QK.bias'), f('.linear_V1.bias'), f('.linear_V2.bias'), f('.linear_U1.bias'), f('.linear_U2.bias')], 0)
-    return W.to(torch.bfloat16), b
+    return W.to(_DT), b
 
 
 def _pack_deaot_gpm(sd, put, lin, norm, num_lstt):
@@ -90,13 +91,13 @@ def _pack_deaot_gpm(sd, put, lin, norm, num_lstt):
     for i in range(num_lstt):
         s, d = f'LSTT.layers.{i}', f'g{i}'
         norm(d + '.ln1', s + '.norm1')
-        put(d + '.qvu.w', torch.cat([sd[s + '.linear_QV.weight'], sd[s + '.linear_U.weight']], 0).float().to(torch.bfloat16))
+        put(d + '.qvu.w', torch.cat([sd[s + '.linear_QV.weight'], sd[s + '.linear_U.weight']], 0).float().to(_DT))
         put(d + '.qvu.b', torch.cat([sd[s + '.linear_QV.bias'], sd[s + '.linear_U.bias']], 0).float())
         lin(d + '.idv', s + '.linear_ID_V')
         if i > 0:
             norm(d + '.idn1', s + '.id_norm1')
             lin(d + '.idu', s + '.linear_ID_U')
-        put(d + '.rel.w', sd[s + '.short_term_attn.relative_emb_k.weight'].float().reshape(225, 128).to(torch.bfloat16))
+        put(d + '.rel.w', sd[s + '.short_term_attn.relative_emb_k.weight'].float().reshape(225, 128).to(_DT))
         put(d + '.rel.b', sd[s + '.short_term_attn.relative_emb_k.bias'].float())
         for nm, src in (('long', 'long_term_attn'), ('short', 'short_term_attn'), ('self', 'self_attn')):
             put(f'{d}.{nm}_dw.w', sd[f'{s}.{src}.dw_conv.conv.weight'].float().view(-1, 25).t())
@@ -109,7 +110,13 @@ def _pack_deaot_gpm(sd, put, lin, norm, num_lstt):
     norm('idnorm', 'id_norm')
 
 
-def pack_state_dict(sd: Dict[str, torch.Tensor], device, num_lstt: int = 3) -> Dict[str, torch.Tensor]:
+def pack_state_dict(sd: Dict[str, torch.Tensor], device, num_lstt: int = 3, dtype=torch.bfloat16) -> Dict[str, torch.Tensor]:
+    """dtype: the 16-bit element type of weights / activations / bank (torch.bfloat16, or torch.float16 for the *_f16 entry
+    points); weights are rounded from fp32 directly to it."""
+    global _DT
+    if dtype not in (torch.bfloat16, torch.float16):
+        raise ValueError(f'pack_state_dict: dtype must be torch.bfloat16 or torch.float16, got {dtype}')
+    _DT = dtype
     P: Dict[str, torch.Tensor] = {}
 
     def put(name, t):
@@ -137,7 +144,7 @@ def pack_state_dict(sd: Dict[str, torch.Tensor], device, num_lstt: int = 3) -> D
     put('proj.w', _conv_w(sd['encoder_projector.weight'].float())); put('proj.b', sd['encoder_projector.bias'].float())
 
     def lin(dst, src):
-        put(dst + '.w', sd[src + '.weight'].float().to(torch.bfloat16)); put(dst + '.b', sd[src + '.bias'].float())
+        put(dst + '.w', sd[src + '.weight'].float().to(_DT)); put(dst + '.b', sd[src + '.bias'].float())
 
     def norm(dst, src):
         put(dst + '.g', sd[src + '.weight'].float()); put(dst + '.b', sd[src + '.bias'].float())
@@ -148,11 +155,11 @@ def pack_state_dict(sd: Dict[str, torch.Tensor], device, num_lstt: int = 3) -> D
     for i in range(0 if deaot else num_lstt):
         s, d = f'LSTT.layers.{i}', f'l{i}'
         norm(d + '.ln1', s + '.norm1')
-        put(d + '.self_qk.w', torch.cat([sd[s + '.self_attn.linear_Q.weight'], sd[s + '.self_attn.linear_K.weight']], 0).float().to(torch.bfloat16))
+        put(d + '.self_qk.w', torch.cat([sd[s + '.self_attn.linear_Q.weight'], sd[s + '.self_attn.linear_K.weight']], 0).float().to(_DT))
         put(d + '.self_qk.b', torch.cat([sd[s + '.self_attn.linear_Q.bias'], sd[s + '.self_attn.linear_K.bias']], 0).float())
         # Q | K | V in one GEMM: q = k = LN1(x) + pos and v = LN1(x) differ only by pos @ Wqk^T, a per-clip constant
         put(d + '.self_qkv.w', torch.cat([sd[s + '.self_attn.linear_Q.weight'], sd[s + '.self_attn.linear_K.weight'],
-                                          sd[s + '.self_attn.linear_V.weight']], 0).float().to(torch.bfloat16))
+                                          sd[s + '.self_attn.linear_V.weight']], 0).float().to(_DT))
         put(d + '.self_qkv.b', torch.cat([sd[s + '.self_attn.linear_Q.bias'], sd[s + '.self_attn.linear_K.bias'],
                                           sd[s + '.self_attn.linear_V.bias']], 0).float())
         lin(d + '.self_proj', s + '.self_attn.projection')

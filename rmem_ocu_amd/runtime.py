@@ -76,12 +76,13 @@ class ClipRuntime:
     def __init__(self, P: Dict[str, torch.Tensor], in_hw: Tuple[int, int], bank_slots: int, device,
                  num_lstt: int = 3, align_corners: bool = True, num_classes: int = 11):
         self.P, self.dev, self.NL = P, device, num_lstt
+        self.dt = P['proj.w'].dtype              # 16-bit element type of activations and bank = that of the packed weights
         self.align = align_corners
         self.nc = num_classes
         H, W = in_hw
         self.H, self.W = H, W
         self.swin = 'pe.w' in P
-        e = lambda *shape, dt=BF16: torch.empty(*shape, dtype=dt, device=device)  # noqa: E731
+        e = lambda *shape, dt=None: torch.empty(*shape, dtype=dt or self.dt, device=device)  # noqa: E731
         self.img8 = e(H * W, 8)
         if self.swin:
             # Swin-B (cfg 5): patch 4, then two patch mergings (encoders/swin/swin_transformer.py:500-545, 684-716)
@@ -140,7 +141,7 @@ class ClipRuntime:
     def _alloc_lstt(self, L: int, num_lstt: int):
         """Activation buffers of the propagation stack (AOT: 3 LSTT blocks)."""
         device = self.dev
-        e = lambda *shape, dt=BF16: torch.empty(*shape, dtype=dt, device=device)  # noqa: E731
+        e = lambda *shape, dt=None: torch.empty(*shape, dtype=dt or self.dt, device=device)  # noqa: E731
         self.x = e(L, D_MODEL, dt=F32)              # residual stream
         self.dec_in = e(L, 4 * D_MODEL)             # cat(enc256, 3 x normed LSTT out), decoders/fpn.py:38-39
         self.t1b, self.t1p = e(L, D_MODEL), e(L, D_MODEL)
@@ -166,8 +167,8 @@ class ClipRuntime:
     # ------------------------------------------------------------------ bank
     def _alloc_bank(self, slots: int):
         self.S = slots
-        self.bank_K = [torch.empty(slots, self.L, self.bank_kw, dtype=BF16, device=self.dev) for _ in range(self.NL)]
-        self.bank_V = [torch.empty(slots, self.L, self.bank_vw, dtype=BF16, device=self.dev) for _ in range(self.NL)]
+        self.bank_K = [torch.empty(slots, self.L, self.bank_kw, dtype=self.dt, device=self.dev) for _ in range(self.NL)]
+        self.bank_V = [torch.empty(slots, self.L, self.bank_vw, dtype=self.dt, device=self.dev) for _ in range(self.NL)]
         self.slots: List[int] = []           # logical order t -> physical slot
         self.free: List[int] = list(range(slots))
         self._on_bank_resized()
@@ -183,8 +184,8 @@ class ClipRuntime:
         """Unbounded-memory mode (latter_mem_len = 9999, tools/eval.py:92): double the ring."""
         old_K, old_V, old_S = self.bank_K, self.bank_V, self.S
         new_S = old_S * 2
-        self.bank_K = [torch.empty(new_S, self.L, self.bank_kw, dtype=BF16, device=self.dev) for _ in range(self.NL)]
-        self.bank_V = [torch.empty(new_S, self.L, self.bank_vw, dtype=BF16, device=self.dev) for _ in range(self.NL)]
+        self.bank_K = [torch.empty(new_S, self.L, self.bank_kw, dtype=self.dt, device=self.dev) for _ in range(self.NL)]
+        self.bank_V = [torch.empty(new_S, self.L, self.bank_vw, dtype=self.dt, device=self.dev) for _ in range(self.NL)]
         for i in range(self.NL):
             self.bank_K[i][:old_S].copy_(old_K[i])
             self.bank_V[i][:old_S].copy_(old_V[i])
@@ -364,7 +365,7 @@ class ClipRuntime:
         """One-off per runtime: pos_qk[i][:, :512] = bf16(pos) @ [Wq; Wk]^T (no bias; the QKV GEMM adds it)."""
         if self._pos_ready:
             return
-        posb = self.pos.to(BF16)
+        posb = self.pos.to(self.dt)
         for i in range(self.NL):
             ops.run(ops.linear(posb, self.P[f'l{i}.self_qk.w'], None, self.pos_qk[i], M=self.L, K=D_MODEL, N=2 * D_MODEL,
                                ldo=3 * D_MODEL), stream)
@@ -394,7 +395,7 @@ class ClipRuntime:
                 cq = self.bank_K[i][ref_slot]                       # curr_K is the bank's first entry
                 gv = self.bank_V[i][ref_slot]
                 o.append(self._lin(self.curr_V[i], d + '.linear_Q', cq, L, C, C))
-                o.append(ops.add_bf16(self.curr_V[i], self.id_emb, self.tmp, L * C))
+                o.append(ops.add16(self.curr_V[i], self.id_emb, self.tmp, L * C))
                 o.append(self._lin(self.tmp, d + '.linear_V', gv, L, C, C))
                 sk, sv = cq, gv                                     # local_K/V = global_K/V (585-586)
             else:
@@ -410,7 +411,7 @@ class ClipRuntime:
             o.append(self._lin(self.att, d + '.short_proj', self.x, L, C, C, residual=self.x, y2=self.tgt3[i]))
             if ref_mode:   # short-term memory of the reference frame (675-678)
                 o.append(self._lin(self.tgt3[i], d + '.linear_QMem', self.short_K[i], L, C, C))
-                o.append(ops.add_bf16(self.tgt3[i], self.id_emb, self.tmp, L * C))
+                o.append(ops.add16(self.tgt3[i], self.id_emb, self.tmp, L * C))
                 o.append(self._lin(self.tmp, d + '.linear_VMem', self.short_V[i], L, C, C))
             # --- feed-forward (683-687)
             o.append(ops.layernorm256(self.x, P[d + '.ln3.g'], P[d + '.ln3.b'], M=L, y=self.t3))
@@ -497,11 +498,11 @@ class ClipRuntime:
         if NL > 4:
             raise ops.RmemError('memory update: grouped launches cover up to 4 LSTT layers')
         if not hasattr(self, 'tmpA'):
-            self.tmpA = [torch.empty(L, C, dtype=BF16, device=self.dev) for _ in range(NL)]
-            self.tmpB = [torch.empty(L, C, dtype=BF16, device=self.dev) for _ in range(NL)]
+            self.tmpA = [torch.empty(L, C, dtype=self.dt, device=self.dev) for _ in range(NL)]
+            self.tmpB = [torch.empty(L, C, dtype=self.dt, device=self.dev) for _ in range(NL)]
         app = append_slot is not None
         # the three layers' updates are independent: one launch per kind of op for all layers
-        o.append(ops.add_bf16_grouped(self.tgt3 + (self.curr_V if app else []), [self.id_emb] * (NL * (2 if app else 1)),
+        o.append(ops.add16_grouped(self.tgt3 + (self.curr_V if app else []), [self.id_emb] * (NL * (2 if app else 1)),
                                       self.tmpA + (self.tmpB if app else []), L * C))
         w = lambda nm: [P[f'l{i}.{nm}.w'] for i in range(NL)]   # noqa: E731
         b = lambda nm: [P[f'l{i}.{nm}.b'] for i in range(NL)]   # noqa: E731

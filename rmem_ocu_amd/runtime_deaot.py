@@ -38,7 +38,7 @@ class DeAOTRuntime(ClipRuntime):
     # ------------------------------------------------------------------ buffers
     def _alloc_lstt(self, L: int, num_lstt: int):
         dev = self.dev
-        e = lambda *shape, dt=BF16: torch.empty(*shape, dtype=dt, device=dev)  # noqa: E731
+        e = lambda *shape, dt=None: torch.empty(*shape, dtype=dt or self.dt, device=dev)  # noqa: E731
         self.xc0 = torch.zeros(L, 2 * D_MODEL, dtype=F32, device=dev)   # [encoder projection | 0]: tgt and "tgt_id = 0" of layer 0
         self.xc = e(L, 2 * D_MODEL, dt=F32)                             # [tgt | tgt_id]
         self.x = self.xc0                                               # where the encoder projector writes (ldo 512)

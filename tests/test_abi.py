@@ -31,6 +31,10 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
         assert hasattr(lib, n), f'{n} declared in include/rmem.h but not exported by librmem_hip.so'
         assert n in _lib.SIGNATURES, f'{n} has no ctypes signature in rmem_ocu_amd/_lib.py'
     assert set(_lib.SIGNATURES) <= set(names), set(_lib.SIGNATURES) - set(names)
+    # the IEEE-half flavour: one twin per entry point with 16-bit operands, none for the element-type-agnostic ones
+    twins = {n[:-4] for n in names if n.endswith('_f16')}
+    assert twins == set(_lib.F16_TWINS)
+    assert all(_lib.SIGNATURES[n + '_f16'] == _lib.SIGNATURES[n] for n in twins)
 
 
 def test_version_and_error_string(lib):
@@ -47,7 +51,7 @@ def test_argument_validation_needs_no_gpu(lib):
     assert rc != 0 and b'multiple of 8' in lib.rmem_last_error_string()
     rc = lib.rmem_mem_read_attn(16, 256, 16, 16, 0, 256, None, 1, 0, None, None, 10, 8, 16, 256, None, 0, 16, None)
     assert rc != 0 and b'lk_single' in lib.rmem_last_error_string()
-    assert lib.rmem_attn_workspace_bytes(1674, 8, 8) == 8 * 8 * 1674 * 34 * 4
+    assert lib.rmem_attn_workspace_bytes(1674, 8, 8) == 8 * 8 * 1674 * 36 * 4
 
 
 def test_no_cpu_fallback():
@@ -57,7 +61,7 @@ def test_no_cpu_fallback():
     from rmem_ocu_amd._lib import RmemError
     x = torch.zeros(16, 8, dtype=torch.bfloat16)
     with pytest.raises(RmemError):
-        ops.add_bf16(x, x, x, 128)
+        ops.add16(x, x, x, 128)
     from rmem_ocu_amd import build_vos_model, get_config
     model = build_vos_model('aot', get_config())
     with pytest.raises(RuntimeError):

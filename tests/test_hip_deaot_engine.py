@@ -16,7 +16,7 @@ def test_deaot_small_clip_teacher_forced():
     ref = g['logit_samples']
     err = np.abs(samples - ref).max()
     print('deaot teacher-forced: max |dlogit| =', err, ' logit std =', ref.std(), ' label agreement =', (labels == g['labels']).mean())
-    assert err < 0.08 * ref.std() + 0.05, err
+    assert err < 0.065 * ref.std(), err      # measured 0.027-0.043 std on MI355X (bf16 stores): 1.5x
     assert (_trace_matrix(trace, g['indexes']) == g['indexes']).all()
     assert (labels == g['labels']).mean() > 0.97
 
@@ -42,7 +42,7 @@ def test_deaot_full_clip_cfg2_geometry():
     ref = g['logit_samples']
     err = np.abs(samples - ref).max()
     print('deaot full clip: max |dlogit| =', err, ' logit std =', ref.std(), ' agreement =', (labels == g['labels']).mean())
-    assert err < 0.08 * ref.std() + 0.05
+    assert err < 0.065 * ref.std()      # measured <= 0.043 std on MI355X: 1.5x
     assert (_trace_matrix(trace, g['indexes']) == g['indexes']).all()
     assert (labels == g['labels']).mean() > 0.97
 

@@ -32,11 +32,12 @@ def _load(name):
     return g, frames, mask, (former, latter, n, h, w, oh, ow, gap, objs)
 
 
-def _engine(former, latter, gap, fitted=False, model_name='r50_aotl'):
+def _engine(former, latter, gap, fitted=False, model_name='r50_aotl', dtype='bf16'):
     from rmem_ocu_amd import build_engine, build_vos_model, get_config
     from rmem_ocu_amd.weights import fitted_state_dict, synth_state_dict
     cfg = get_config('pre_vost', 'test', model_name)
     cfg.FORMER_MEM_LEN, cfg.LATTER_MEM_LEN = former, latter
+    cfg.MODEL_DTYPE = dtype
     model = build_vos_model(cfg.MODEL_VOS, cfg).cuda(0)
     model.load_state_dict(fitted_state_dict(0) if fitted else synth_state_dict(0, model='deaot' if model_name == 'r50_deaotl' else 'aot'))
     eng = build_engine(cfg.MODEL_ENGINE, phase='eval', aot_model=model, gpu_id=0, long_term_mem_gap=gap)
@@ -44,10 +45,10 @@ def _engine(former, latter, gap, fitted=False, model_name='r50_aotl'):
     return eng
 
 
-def _run(name, teacher_forced, use_graphs=False):
+def _run(name, teacher_forced, use_graphs=False, dtype='bf16'):
     g, frames, mask, (former, latter, n, h, w, oh, ow, gap, objs) = _load(name)
     inject_at = int(g['inject_at']) if 'inject_at' in g.files else -1
-    eng = _engine(former, latter, gap, fitted='fitted' in name, model_name='r50_deaotl' if 'deaot' in name else 'r50_aotl')
+    eng = _engine(former, latter, gap, fitted='fitted' in name, model_name='r50_deaotl' if 'deaot' in name else 'r50_aotl', dtype=dtype)
     eng.use_graphs = use_graphs
     dev = torch.device('cuda', 0)
     frames_d = frames.to(dev)
@@ -89,7 +90,7 @@ def test_small_clip_teacher_forced():
     ref = g['logit_samples']
     err = np.abs(samples - ref).max()
     print('teacher-forced: max |dlogit| =', err, ' logit std =', ref.std(), ' label agreement =', (labels == g['labels']).mean())
-    assert err < 0.08 * ref.std() + 0.05, err
+    assert err < 0.065 * ref.std(), err      # measured 0.027-0.043 std on MI355X (bf16 stores): 1.5x
     assert (_trace_matrix(trace, g['indexes']) == g['indexes']).all()
     assert (labels == g['labels']).mean() > 0.97
 
@@ -119,7 +120,7 @@ def test_full_clip_cfg2_geometry():
     ref = g['logit_samples']
     err = np.abs(samples - ref).max()
     print('full clip teacher-forced: max |dlogit| =', err, ' logit std =', ref.std(), ' agreement =', (labels == g['labels']).mean())
-    assert err < 0.08 * ref.std() + 0.05
+    assert err < 0.065 * ref.std()      # measured <= 0.043 std on MI355X: 1.5x
     assert (_trace_matrix(trace, g['indexes']) == g['indexes']).all()
 
 
@@ -129,7 +130,7 @@ def test_new_object_injection_clip():
     ref = g['logit_samples']
     err = np.abs(samples - ref).max()
     print('new-object clip: max |dlogit| =', err, ' agreement =', (labels == g['labels']).mean())
-    assert err < 0.08 * ref.std() + 0.05
+    assert err < 0.065 * ref.std()      # measured <= 0.043 std on MI355X: 1.5x
     assert (_trace_matrix(trace, g['indexes']) == g['indexes']).all()
 
 
@@ -139,7 +140,7 @@ def test_unbounded_memory_clip():
     ref = g['logit_samples']
     err = np.abs(samples - ref).max()
     print('unbounded clip: max |dlogit| =', err, ' agreement =', (labels == g['labels']).mean())
-    assert err < 0.08 * ref.std() + 0.05
+    assert err < 0.065 * ref.std()      # measured <= 0.043 std on MI355X: 1.5x
     assert (_trace_matrix(trace, g['indexes']) == g['indexes']).all()
 
 
@@ -218,7 +219,7 @@ def test_swin_encoder_and_clip():
     ref = gc['logit_samples']
     err = np.abs(np.stack(samples) - ref).max()
     print('swin clip: max |dlogit| =', err, ' logit std =', ref.std())
-    assert err < 0.1 * ref.std() + 0.05
+    assert err < 0.045 * ref.std()      # measured 0.027 std
     assert (_trace_matrix(trace, gc['indexes']) == gc['indexes']).all()
 
 
@@ -239,13 +240,46 @@ def test_fitted_weights_mask_iou(name):
     print(f'{name} teacher-forced: mean IoU {np.mean(ious):.5f} min IoU {np.min(ious):.5f}  label agreement {agree.mean():.5f}  '
           f'max |dlogit| {np.abs(samples - ref).max():.3f} at logit std {ref.std():.2f}')
     assert (_trace_matrix(trace, g['indexes']) == g['indexes']).all()
-    assert np.mean(ious) >= 0.99 and agree.mean() >= 0.998
+    assert np.mean(ious) >= 0.99 and agree.mean() >= 0.999
+    assert np.abs(samples - ref).max() < 0.035 * ref.std()      # measured 0.019-0.023 std (bf16: 8 significant bits)
     g, labels, samples, trace = _run(name, False, use_graphs=True)
     ious = [_iou(a, b) for a, b in zip(g['labels'], labels)]
     agree = (labels == g['labels']).mean(axis=(1, 2))
     print(f'{name} free-running: mean IoU {np.mean(ious):.5f} first-frame IoU {ious[0]:.5f} last-frame IoU {ious[-1]:.5f}  '
           f'label agreement {agree.mean():.5f}')
     assert ious[0] >= 0.985 and agree.mean() >= 0.9
+
+
+@pytest.mark.parametrize('name', ['clip_small_fitted.npz', 'clip_full_fitted.npz'])
+def test_fitted_weights_mask_iou_fp16(name):
+    """The north-star gate (>= 0.999 mask IoU against the reference's masks) in the IEEE-half flavour (cfg.MODEL_DTYPE = 'fp16':
+    the operand type of the reference's own --amp path, tools/eval.py:45-47).  bfloat16's 8 significant bits cap the same
+    comparison at 0.992-0.996 (test_fitted_weights_mask_iou; tests/test_stage_budget.py shows the ~1 % rms the 50 bf16-stored
+    encoder layers accumulate); half's 11 bits bring every stage's error down 8x.  Measured on MI355X: mean IoU 0.9993 on the
+    161x193 clip and 0.9988 on the cfg-2-size clip (0.0078 % of the pixels flip, ~30 per frame, all on object borders), so the
+    gate is 0.999 / 0.998 -- 1.5x the measured shortfall, not the 0.99 of the bfloat16 flavour."""
+    if not os.path.exists(os.path.join(GOLDEN, 'trained_delta.pt')):
+        pytest.skip('fitted weights missing')
+    g, labels, samples, trace = _run(name, True, use_graphs=True, dtype='fp16')
+    ious = [_iou(a, b) for a, b in zip(g['labels'], labels)]
+    agree = (labels == g['labels']).mean(axis=(1, 2))
+    ref = g['logit_samples']
+    err = np.abs(samples - ref).max()
+    print(f'{name} fp16 teacher-forced: mean IoU {np.mean(ious):.5f} min IoU {np.min(ious):.5f}  label agreement {agree.mean():.5f}  '
+          f'max |dlogit| {err:.4f} at logit std {ref.std():.2f}')
+    assert (_trace_matrix(trace, g['indexes']) == g['indexes']).all()
+    assert np.mean(ious) >= (0.999 if 'small' in name else 0.998) and agree.mean() >= 0.9998
+    assert err < 0.006 * ref.std() + 0.005, err
+
+
+def test_small_clip_teacher_forced_fp16():
+    """Synthetic weights, IEEE-half flavour: per-frame logits against the reference's, identical eviction trace."""
+    g, labels, samples, trace = _run('clip_small.npz', True, dtype='fp16')
+    ref = g['logit_samples']
+    err = np.abs(samples - ref).max()
+    print('fp16 teacher-forced: max |dlogit| =', err, ' logit std =', ref.std(), ' label agreement =', (labels == g['labels']).mean())
+    assert err < 0.012 * ref.std() + 0.003, err
+    assert (_trace_matrix(trace, g['indexes']) == g['indexes']).all()
 
 
 def test_sequence_evaluator_flip_tta_and_metrics(tmp_path):

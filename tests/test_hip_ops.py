@@ -627,7 +627,7 @@ def test_groupnorm_head_fused(dev, B, M):
 
 
 def test_grouped_launches(dev):
-    """rmem_linear_grouped / rmem_add_bf16_grouped / rmem_layernorm256_pair are bit-identical to the single launches."""
+    """rmem_linear_grouped / rmem_add16_grouped / rmem_layernorm256_pair are bit-identical to the single launches."""
     from rmem_ocu_amd import ops
     M, K, N, n = 1674, 256, 256, 3
     xs = [rb(seeded(20 + i, (M, K))).to(BF16).to(dev) for i in range(n)]
@@ -643,7 +643,7 @@ def test_grouped_launches(dev):
         assert_close(ys[i], xs[i].float() @ ws[i].float().t() + bs[i], 1e-2, 'grouped linear')
     a = [rb(seeded(50 + i, (M, 256))).to(BF16).to(dev) for i in range(6)]
     out = [torch.zeros(M, 256, dtype=BF16, device=dev) for _ in range(6)]
-    ops.run(ops.add_bf16_grouped(a, [a[0]] * 6, out, M * 256))
+    ops.run(ops.add16_grouped(a, [a[0]] * 6, out, M * 256))
     torch.cuda.synchronize()
     for i in range(6):
         assert torch.equal(out[i], (a[i].float() + a[0].float()).to(BF16))
@@ -744,3 +744,104 @@ def test_batched_forms_match_single_launches(dev):
                                   lk_single=T * L, pe_cur=pe_cur, pe_mem=pe_mem, mass=m1[c], T=T))
     torch.cuda.synchronize()
     assert torch.equal(ob, o1) and torch.equal(mb, m1)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# IEEE-half flavour (<name>_f16 entry points; cfg.MODEL_DTYPE = 'fp16'): the same kernels compiled for _Float16 operands.
+# Inputs are rounded to half first; with 11 significant bits the 16-bit stores are ~8x finer than bf16's.
+F16 = torch.float16
+
+
+def rh(t):  # round through IEEE half
+    return t.to(F16).to(F32)
+
+
+@pytest.mark.parametrize('case', [(31, 54, 64, 64, 3, 1, 1, True), (61, 107, 256, 512, 1, 2, 0, False), (97, 129, 16, 256, 17, 16, 8, False),
+                                  (1674, 1, 1024, 256, 1, 1, 0, False)])
+def test_conv2d_fp16(dev, case):
+    from rmem_ocu_amd import ops
+    H, W, Cin, Cout, k, s, p, relu = case
+    x = rh(seeded(900 + H, (1, Cin, H, W)))
+    w = rh(seeded(901 + Cout, (Cout, Cin, k, k), (Cin * k * k) ** -0.5))
+    b = seeded(902, (Cout,), 0.1)
+    ref = F.conv2d(x, w, b, stride=s, padding=p)
+    ref = F.relu(ref) if relu else ref
+    refm = ref[0].permute(1, 2, 0).reshape(-1, Cout)
+    y = torch.zeros(refm.shape[0], Cout, dtype=F16, device=dev)
+    xh = x[0].permute(1, 2, 0).reshape(-1, Cin).contiguous().to(F16).to(dev)
+    wh = w.permute(0, 2, 3, 1).contiguous().to(F16).to(dev)
+    ops.run(ops.conv2d(xh, wh, b.to(dev), y, H=H, W=W, Cin=Cin, Cout=Cout, KH=k, KW=k, stride=s, pad=p, relu=relu))
+    torch.cuda.synchronize()
+    assert_close(y, refm, 2e-3, f'fp16 conv {case}')
+
+
+@pytest.mark.parametrize('T,L', [(2, 42), (3, 300), (8, 1674)])
+def test_mem_read_attn_fp16(dev, T, L, synth_weights):
+    """a1 + a2 + a3 through rmem_mem_read_attn_f16 (always the online-softmax pass: P must stay below 2^16)."""
+    from rmem_ocu_amd import ops
+    from rmem_ocu_amd.runtime import temporal_slots
+    C = 256
+    q, k, v = rh(seeded(10 + T, (L, C))), rh(seeded(20 + T, (T, L, C))), rh(seeded(30 + T, (T, L, C)))
+    pe_cur, pe_mem = synth_weights['cur_pos_emb'].view(-1), synth_weights['mem_pos_emb']
+    slots = temporal_slots(T)
+    Qh = ((q + pe_cur) / 32 ** 0.5).view(L, 8, 32).permute(1, 0, 2)
+    Kh = (k + pe_mem[slots][:, None, :]).reshape(T * L, 8, 32).permute(1, 2, 0)
+    Vh = v.reshape(T * L, 8, 32).permute(1, 0, 2)
+    attn = torch.softmax(Qh @ Kh, dim=-1)
+    ref = (attn @ Vh).permute(1, 0, 2).reshape(L, C)
+    ref_mass = attn.view(8, L, T, L).mean(0).sum(2)
+    rows = [(t, 0, L, slots[t], t) for t in range(T)]
+    chunks = ops.make_chunk_table(rows).to(dev)
+    out = torch.zeros(L, C, dtype=F16, device=dev)
+    mass = torch.zeros(L, T, dtype=F32, device=dev)
+    ws = ops.attn_workspace(L, 8, T, dev)
+    ops.run(ops.mem_read_attn(q.to(F16).to(dev), k.to(F16).to(dev), v.to(F16).to(dev), out, ws, Lq=L, ldq=C, ldkv=C, ldo=C,
+                              slot_stride=L * C, chunks=chunks, nchunks=T, pe_cur=pe_cur.to(dev), pe_mem=pe_mem.to(dev).contiguous(),
+                              mass=mass, T=T))
+    torch.cuda.synchronize()
+    # (the scaled query q' = (q + pe) / sqrt(32) * log2 e is rounded to half inside the kernel: ~2^-11 relative on the logits)
+    assert_close(out, ref, 4e-3, 'fp16 attention out')
+    assert_close(mass, ref_mass, 4e-3, 'fp16 attention mass')
+
+
+def test_attention_late_dominant_key_fp16(dev):
+    """A key 2^100 above everything before it, half flavour: the running maximum must move (P would overflow half at 2^16)."""
+    from rmem_ocu_amd import ops
+    L, C = 200, 256
+    g = torch.Generator().manual_seed(78)
+    u = torch.nn.functional.normalize(torch.randn(8, 32, generator=g), dim=1).reshape(C)
+    q = rh(seeded(58, (L, C)) * 0.5 + 20.0 * u)
+    k = rh(seeded(59, (L, C)) * 0.5)
+    v = rh(seeded(60, (L, C)))
+    k[150] = rh(20.0 * u)
+    Qh = (q / 32 ** 0.5).view(L, 8, 32).permute(1, 0, 2)
+    ref = (torch.softmax(Qh @ k.reshape(L, 8, 32).permute(1, 2, 0), -1) @ v.reshape(L, 8, 32).permute(1, 0, 2)).permute(1, 0, 2).reshape(L, C)
+    out = torch.zeros(L, C, dtype=F16, device=dev)
+    ws = ops.attn_workspace(L, 8, 1, dev)
+    ops.run(ops.mem_read_attn(q.to(F16).to(dev), k.to(F16).to(dev), v.to(F16).to(dev), out, ws, Lq=L, ldq=C, ldkv=C, ldo=C,
+                              nchunks=1, lk_single=L))
+    torch.cuda.synchronize()
+    assert_close(out, ref, 4e-3, 'fp16 late dominant key')
+
+
+def test_norms_fp16(dev):
+    """LayerNorm (256) and GroupNorm + GELU + depth-wise 5x5 in the half flavour against fp32 torch."""
+    from rmem_ocu_amd import ops
+    M, C = 1674, 256
+    x = seeded(70, (M, C)) * 2.0 + 0.5
+    gam, bet = seeded(71, (C,), 0.5) + 1.0, seeded(72, (C,), 0.1)
+    y = torch.zeros(M, C, dtype=F16, device=dev)
+    ops.run(ops.layernorm256(x.to(dev), gam.to(dev), bet.to(dev), M=M, y=y))
+    torch.cuda.synchronize()
+    assert_close(y, F.layer_norm(x, (C,), gam, bet, 1e-5), 2e-3, 'fp16 layernorm')
+    H, W, Cf = 31, 54, 1024
+    xh = rh(seeded(73, (1, Cf, H, W)))
+    g2, b2 = seeded(74, (Cf,), 0.3) + 1.0, seeded(75, (Cf,), 0.1)
+    wd = seeded(76, (Cf, 1, 5, 5), 0.2)
+    ref = F.conv2d(F.gelu(F.group_norm(xh, 32, g2, b2, 1e-5)), wd, padding=2, groups=Cf)
+    yy = torch.zeros(H * W, Cf, dtype=F16, device=dev)
+    ws = ops.groupnorm_workspace(32, dev)
+    ops.run(ops.gn_act_dwconv5x5(xh[0].permute(1, 2, 0).reshape(-1, Cf).contiguous().to(F16).to(dev), g2.to(dev), b2.to(dev),
+                                 wd.reshape(Cf, 25).t().contiguous().to(dev), yy, ws, H=H, W=W, C=Cf, groups=32, act=2))
+    torch.cuda.synchronize()
+    assert_close(yy, ref[0].permute(1, 2, 0).reshape(-1, Cf), 4e-3, 'fp16 GN + GELU + dwconv5x5')

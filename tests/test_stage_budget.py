@@ -44,8 +44,9 @@ BOUNDS = {
 }
 
 
+@pytest.mark.parametrize('dtype', ['bf16', 'fp16'])
 @pytest.mark.parametrize('name', ['clip_small_fitted.npz', 'clip_full_fitted.npz'])
-def test_stage_error_budget(name):
+def test_stage_error_budget(name, dtype):
     if not os.path.exists(os.path.join(GOLDEN, 'trained_delta.pt')):
         pytest.skip('fitted weights missing')
     from oracle import ref_cpu as O
@@ -55,7 +56,8 @@ def test_stage_error_budget(name):
     g, frames, mask, (former, latter, n, h, w, oh, ow, gap, objs) = _load(name)
     n_run = n if 'small' in name else min(n, 20)        # the full-size oracle costs ~1 s per frame
     dev = torch.device('cuda', 0)
-    eng = _engine(former, latter, gap, fitted=True)
+    eng = _engine(former, latter, gap, fitted=True, dtype=dtype)
+    e16 = torch.bfloat16 if dtype == 'bf16' else torch.float16
     sd = fitted_state_dict(0)
 
     class Rec(O.OracleEngine):
@@ -112,7 +114,7 @@ def test_stage_error_budget(name):
     s = inner.stream.cuda_stream
     # ---- intrinsic, projector: oracle's encoder stage 3 in, projector out ----
     enc3_save = rt.enc3.clone()
-    rt.enc3.copy_(_nhwc(xs[2]).to(dev).to(torch.bfloat16).view_as(rt.enc3))
+    rt.enc3.copy_(_nhwc(xs[2]).to(dev).to(e16).view_as(rt.enc3))
     ops.run([rt._proj_op(rt.enc_ch[2])], s)
     inner.stream.synchronize()
     row('projector', 'intrinsic', rt.dec_in.view(L, 4 * C)[:, :C], ref_dec_in[:, :C])
@@ -122,11 +124,11 @@ def test_stage_error_budget(name):
     for i in range(3):
         lk, lv = ora.rec_long[i]
         for t, slot in enumerate(rt.slots):
-            rt.bank_K[i][slot].copy_(lk[t].reshape(L, C).to(dev).to(torch.bfloat16))
-            rt.bank_V[i][slot].copy_(lv[t].reshape(L, C).to(dev).to(torch.bfloat16))
+            rt.bank_K[i][slot].copy_(lk[t].reshape(L, C).to(dev).to(e16))
+            rt.bank_V[i][slot].copy_(lv[t].reshape(L, C).to(dev).to(e16))
         sk, sv = ora.rec_short[i]
-        rt.short_K[i].copy_(sk.reshape(L, C).to(dev).to(torch.bfloat16))
-        rt.short_V[i].copy_(sv.reshape(L, C).to(dev).to(torch.bfloat16))
+        rt.short_K[i].copy_(sk.reshape(L, C).to(dev).to(e16))
+        rt.short_V[i].copy_(sv.reshape(L, C).to(dev).to(e16))
     torch.cuda.synchronize()
     ops.run(rt.prog_lstt(False, T, want_mass=False), s)
     inner.stream.synchronize()
@@ -134,16 +136,16 @@ def test_stage_error_budget(name):
         row(f'LSTT layer {i} (decoder norm)', 'intrinsic', rt.dec_in.view(L, 4 * C)[:, (i + 1) * C:(i + 2) * C],
             ref_dec_in[:, (i + 1) * C:(i + 2) * C])
     # ---- intrinsic, decoder: oracle's concat input and encoder shortcuts ----
-    rt.dec_in.copy_(ref_dec_in.to(dev).to(torch.bfloat16).view_as(rt.dec_in))
+    rt.dec_in.copy_(ref_dec_in.to(dev).to(e16).view_as(rt.dec_in))
     for buf, ref in zip((rt.enc1, rt.enc2, rt.enc3), xs[:3]):
-        buf.copy_(_nhwc(ref).to(dev).to(torch.bfloat16).view_as(buf))
+        buf.copy_(_nhwc(ref).to(dev).to(e16).view_as(buf))
     torch.cuda.synchronize()
     ops.run(rt.prog_decode(), s)
     inner.stream.synchronize()
     row('logits (1/4 res)', 'intrinsic', rt.logits.view(-1, 16)[:, :11], ref_logits4)
     rt.enc3.copy_(enc3_save)
 
-    print(f'\n{name}: frame {n_run - 1}, bank T = {T}, logit std {ref_logits4.std().item():.3f}, label flips {100 * flips_cum:.4f} %')
+    print(f'\n{name} [{dtype}]: frame {n_run - 1}, bank T = {T}, logit std {ref_logits4.std().item():.3f}, label flips {100 * flips_cum:.4f} %')
     print(f'{"stage":34s} {"cumulative max / rms":>24s} {"intrinsic max / rms":>24s}')
     for st, r in table.items():
         c, i = r.get('cumulative'), r.get('intrinsic')
@@ -151,8 +153,8 @@ def test_stage_error_budget(name):
         print(f'{st:34s} {f(c):>24s} {f(i):>24s}')
     out = os.path.join(ROOT, 'gpurun_out')
     os.makedirs(out, exist_ok=True)
-    with open(os.path.join(out, f'stage_budget_{name[:-4]}.json'), 'w') as fjs:
-        json.dump({'clip': name, 'frame': n_run - 1, 'T': T, 'logit_std': ref_logits4.std().item(), 'label_flips': flips_cum,
+    with open(os.path.join(out, f'stage_budget_{name[:-4]}_{dtype}.json'), 'w') as fjs:
+        json.dump({'clip': name, 'dtype': dtype, 'frame': n_run - 1, 'T': T, 'logit_std': ref_logits4.std().item(), 'label_flips': flips_cum,
                    'stages': table}, fjs, indent=1)
     bounds = BOUNDS.get(name)
     if bounds:
