@@ -97,7 +97,7 @@ int rmem_conv1x1_dual_nhwc(const rmem_conv_desc* desc, const void* x, const void
 typedef struct rmem_attn_chunk {
   int slot;       /* bank slot: keys at k_bank + slot * slot_stride */
   int key_begin;  /* first key (row) of the chunk inside the slot */
-  int key_count;  /* >= 1 */
+  int key_count;  /* >= 0; 0 = padding row (no keys, no mass): lets clips with shorter banks share a launch, rmem_mem_read_attn_clips */
   int pe_slot;    /* row of pe_mem added to these keys, or -1 */
   int t;          /* memory-frame index the chunk's probability mass is credited to */
   int reserved[3];

@@ -232,14 +232,19 @@ class GroupSlot:
         self.cursor = 0
         self.done = True
 
-    def start(self, frames: Sequence[torch.Tensor], first_masks: Sequence[torch.Tensor], num_objs: int):
+    def start(self, frames: Sequence[torch.Tensor], first_masks: Sequence[torch.Tensor], num_objs: int, new_objects=None):
         """frames: B tensors [n, 3, H, W] fp32 device (equal n), or B uint8 [n, Hs, Ws, 3] tensors in PINNED HOST memory (every
         frame then crosses PCIe as uint8 and is resized + normalised on the device); first_masks: B tensors [1, 1, H, W] at the
-        network size."""
+        network size.  new_objects: {clip index: (frame index, uint8 [Ho, Wo] device map: the new object's label on its pixels, 0
+        elsewhere)} -- the evaluator's protocol for an object that appears mid-clip (managers/evaluator.py:484-508): the frame is
+        propagated, the new label is laid over the prediction and the frame is re-added as a reference frame for that clip."""
         assert len(frames) == self.B and len({int(f.shape[0]) for f in frames}) == 1
         n = int(frames[0].shape[0])
         self.frames = list(frames)
         self.host_u8 = frames[0].dtype == torch.uint8
+        self.new_objects = dict(new_objects or {})
+        if self.new_objects and self.host_u8:
+            raise ValueError('new_objects: frames must be fp32 device tensors at the network size')
         if self.labels is None or self.labels.shape[1] < n:
             self.labels = torch.zeros(self.B, n, self.out_hw[0], self.out_hw[1], dtype=torch.uint8, device=self.device)
         eng = self.engine
@@ -302,7 +307,15 @@ class GroupSlot:
                 with torch.cuda.stream(eng.stream):
                     imgs = torch.cat([f[i:i + 1] for f in self.frames], 0)
             eng.propagate_to_labels(self.cur_label, imgs=imgs)
-        eng.update_from_labels(self.cur_label)
+        inject = [c for c, (fi, _) in self.new_objects.items() if fi == i]
+        if inject:
+            with torch.cuda.stream(eng.stream):
+                for c in inject:                      # the new object's label over the prediction (evaluator.py:484-497)
+                    new = self.new_objects[c][1]
+                    self.cur_label[c].copy_(torch.where(new > 0, new, self.cur_label[c]))
+        eng.update_from_labels(self.cur_label, skip=inject)
+        for c in inject:
+            eng.add_reference_frame_for(c, self.frames[c][i], self.cur_label[c])
         nb = self.cur_label[0].numel()                # frame i of every clip's label stack: one pitched copy
         ops.copy2d_async(self.labels.view(-1)[i * nb:], self.labels.shape[1] * nb, self.cur_label, nb, nb, B)(s)
         self.cursor += 1

@@ -242,9 +242,9 @@ __global__ __launch_bounds__(256, 3) void k_attn_partial(AttnParams pin) {
     const Row r = row_info(c);
     const long off = (long)r.slot * p.slot_stride + (long)r.kb * p.ldkv + head * D;
     row_k = p.k + off; row_v = p.v + off;
-    row_bytes = ((r.kn - 1) * p.ldkv + D) * 2;  // up to the end of the last key's slice
-    row_kn = r.kn;
-    dc = c; dt = 0; dnt = (r.kn + KT - 1) / KT;
+    row_bytes = r.kn > 0 ? ((r.kn - 1) * p.ldkv + D) * 2 : 0;  // up to the end of the last key's slice; an EMPTY row (key_count 0:
+    row_kn = r.kn;                                              // padding of a clip whose bank is shorter than its group's) is one
+    dc = c; dt = 0; dnt = max(1, (r.kn + KT - 1) / KT);         // tile of out-of-range reads = zeros, with zeros in the row-sum operand
   };
   // Next tile of the group -> LDS buffer BUF (asynchronous: counted s_waitcnt vmcnt before use); false once the group is
   // exhausted.  The descriptor is rebuilt per tile (scalar work) so that it starts at the tile and ends with the row: the
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(256, 3) void k_attn_partial(AttnParams pin) {
     m_ref = 0.f; ltot = 0.f;
     int c = c0;
     Row cur = row_info(c);
-    int ntiles = (cur.kn + KT - 1) / KT, t = 0;
+    int ntiles = max(1, (cur.kn + KT - 1) / KT), t = 0;
     {
       // (bias - m_ref) replicated over the 16 accumulator registers: the C operand of the first S^T MFMA of every
       // block, rewritten only at a row boundary or a rescale, so no per-tile register fill is needed (D != C)
@@ -435,7 +435,7 @@ __global__ __launch_bounds__(256, 3) void k_attn_partial(AttnParams pin) {
         }
         if (last) return true;
         ++c; cur = row_info(c); t = 0;
-        ntiles = (cur.kn + KT - 1) / KT;
+        ntiles = max(1, (cur.kn + KT - 1) / KT);
         if (wave_active) {
           const float bias = row_bias(cur.pe_slot) - m_ref;
 #pragma unroll
@@ -514,13 +514,17 @@ __global__ __launch_bounds__(256) void k_attn_combine(CombineParams pin) {
   const int head = hg >> 3, G = hg & 7;
   if (head < p.heads) {
     const f32x4* op = reinterpret_cast<const f32x4*>(p.opart);
-    float m = NEG_BIG;
-    for (int c = 0; c < p.ngroups; ++c) m = fmaxf(m, p.mlg[(((long)c * p.heads + head) * p.Lq + qc) * 2]);
+    float m = NEG_BIG;      // (groups / rows that saw no real key have l = 0: their reference is meaningless and must not set the scale)
+    for (int c = 0; c < p.ngroups; ++c) {
+      const f32x2 mlv = *reinterpret_cast<const f32x2*>(p.mlg + (((long)c * p.heads + head) * p.Lq + qc) * 2);
+      if (mlv[1] > 0.f) m = fmaxf(m, mlv[0]);
+    }
     f32x4 num = {0.f, 0.f, 0.f, 0.f};
     float den = 0.f;
     for (int c = 0; c < p.ngroups; ++c) {
       const long ch = (long)c * p.heads + head;
       const f32x2 mlv = *reinterpret_cast<const f32x2*>(p.mlg + (ch * p.Lq + qc) * 2);
+      if (!(mlv[1] > 0.f)) continue;
       const float w = __builtin_amdgcn_exp2f(mlv[0] - m);
       den += w * mlv[1];
       num += op[(ch * 8 + G) * p.Lq + qc] * w;
@@ -547,15 +551,18 @@ __global__ __launch_bounds__(256) void k_attn_mass(CombineParams pin) {
   __syncthreads();
   for (int h = hq; h < p.heads; h += 4) {
     float m = NEG_BIG, den = 0.f;
-    for (int c = 0; c < p.nchunks; ++c) m = fmaxf(m, p.ml[(((long)c * p.heads + h) * p.Lq + qc) * 2]);
     for (int c = 0; c < p.nchunks; ++c) {
       const f32x2 mlv = *reinterpret_cast<const f32x2*>(p.ml + (((long)c * p.heads + h) * p.Lq + qc) * 2);
-      den += __builtin_amdgcn_exp2f(mlv[0] - m) * mlv[1];
+      if (mlv[1] > 0.f) m = fmaxf(m, mlv[0]);
+    }
+    for (int c = 0; c < p.nchunks; ++c) {
+      const f32x2 mlv = *reinterpret_cast<const f32x2*>(p.ml + (((long)c * p.heads + h) * p.Lq + qc) * 2);
+      if (mlv[1] > 0.f) den += __builtin_amdgcn_exp2f(mlv[0] - m) * mlv[1];
     }
     const float inv = 1.f / (den * (float)p.heads);
     for (int c = 0; c < p.nchunks; ++c) {
       const f32x2 mlv = *reinterpret_cast<const f32x2*>(p.ml + (((long)c * p.heads + h) * p.Lq + qc) * 2);
-      macc[hq][ql][ct[c]] += __builtin_amdgcn_exp2f(mlv[0] - m) * mlv[1] * inv;
+      if (mlv[1] > 0.f) macc[hq][ql][ct[c]] += __builtin_amdgcn_exp2f(mlv[0] - m) * mlv[1] * inv;
     }
   }
   __syncthreads();

@@ -107,7 +107,9 @@ class GroupRuntime:
 
     @property
     def T(self) -> int:
-        return len(self.slots[0])
+        """Bank size the group's launches are built for: the LONGEST bank among the clips (after a mid-clip reference frame a
+        clip's bank restarts at one entry, aot_engine.py:322; shorter banks are padded with empty table rows)."""
+        return max(len(s) for s in self.slots)
 
     def chunk_plan(self, T: int) -> Tuple[int, int]:
         if T > MAX_CHUNKS:
@@ -116,17 +118,22 @@ class GroupRuntime:
         return splits, T * splits
 
     def _chunk_rows(self, slots: List[List[int]]):
-        """Chunk-table rows (global slot, key begin, key count, temporal-PE slot, t) for per-clip slot orders of equal length."""
-        T = len(slots[0])
-        assert all(len(s) == T for s in slots)
+        """Chunk-table rows (global slot, key begin, key count, temporal-PE slot, t), one block of n rows per clip, for per-clip slot
+        orders.  Banks may differ in length: the block is laid out for the longest one (same key split for every clip), a shorter
+        bank uses its own temporal-PE slots (layers/transformer.py:598-621 depends on that clip's T) and its block is padded with
+        empty rows (key_count 0), which the kernel reads as zero keys with zero mass."""
+        T = max(len(s) for s in slots)
         splits, n = self.chunk_plan(T)
-        pes = temporal_slots(T)
         per = (self.L + splits - 1) // splits
         rows = []
         for c in range(self.B):
+            pes = temporal_slots(len(slots[c]))
+            mine = []
             for t, s in enumerate(slots[c]):
                 for kb in range(0, self.L, per):
-                    rows.append((c * self.S + s, kb, min(per, self.L - kb), pes[t], t))
+                    mine.append((c * self.S + s, kb, min(per, self.L - kb), pes[t], t))
+            mine += [(c * self.S, 0, 0, -1, 0)] * (n - len(mine))
+            rows += mine
         return rows, n
 
     def upload_chunks(self, stream: int):

@@ -117,6 +117,13 @@ def pack_state_dict(sd: Dict[str, torch.Tensor], device, num_lstt: int = 3, dtyp
     if dtype not in (torch.bfloat16, torch.float16):
         raise ValueError(f'pack_state_dict: dtype must be torch.bfloat16 or torch.float16, got {dtype}')
     _DT = dtype
+    try:
+        return _pack_state_dict(sd, device, num_lstt)
+    finally:
+        _DT = torch.bfloat16          # the helpers of this module pack bfloat16 unless told otherwise
+
+
+def _pack_state_dict(sd: Dict[str, torch.Tensor], device, num_lstt: int) -> Dict[str, torch.Tensor]:
     P: Dict[str, torch.Tensor] = {}
 
     def put(name, t):

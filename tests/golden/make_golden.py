@@ -353,6 +353,12 @@ if __name__ == '__main__':
         # cfg-2 geometry with the shipped bank size 1 + 8 (configs/models/r50_deaotl.py:8-9, eval_vost.sh:28)
         np.savez_compressed(os.path.join(HERE, 'deaot_clip_full.npz'),
                             **gen_clip('deaot_full', 1, 8, 30, 481, 849, (480, 854), 2, 3, 21, model_name='r50_deaotl'))
+    if what in ('n2', 'all'):
+        # cfg-1 stand-in (BASELINE.json configs[0]: one DAVIS-16 clip, 82 frames, 480p, bank N = 2 = 1 + 1): 82 frames at network size
+        # 481x849, one object, gap = max(round(82 / 30), 5) = 5 as the evaluator sets it (evaluator.py:330-335), fitted weights:
+        # the bank overflows at every append from frame 10 on, 15 evictions of the only evictable entry
+        np.savez_compressed(os.path.join(HERE, 'clip_n2_fitted.npz'),
+                            **gen_clip('n2', 1, 1, 82, 481, 849, (480, 854), 5, 1, 71, fitted=True))
     if what in ('full', 'all'):
         # cfg-2 geometry: 480x854 video at network size 481x849, bank N = 8, gap 2 so the bank fills
         # by frame 14 and evicts from frame 16

@@ -70,3 +70,13 @@ def test_deaot_first_frames_vs_oracle():
         ora.update_memory(m)
         eng.update_memory(m.to(dev))
     assert list(eng.long_memories_indexes) == list(ora.long_memories_indexes)
+
+
+def test_deaot_small_clip_teacher_forced_fp16():
+    """The IEEE-half flavour of the DeAOT path (rmem_gated_attn_f16, rmem_local_gated_attn_f16 and the _f16 GEMMs / norms)."""
+    g, labels, samples, trace = _run('deaot_clip_small.npz', True, dtype='fp16')
+    ref = g['logit_samples']
+    err = np.abs(samples - ref).max()
+    print('deaot fp16 teacher-forced: max |dlogit| =', err, ' logit std =', ref.std(), ' label agreement =', (labels == g['labels']).mean())
+    assert err < 0.012 * ref.std() + 0.003, err
+    assert (_trace_matrix(trace, g['indexes']) == g['indexes']).all()

@@ -845,3 +845,75 @@ def test_norms_fp16(dev):
                                  wd.reshape(Cf, 25).t().contiguous().to(dev), yy, ws, H=H, W=W, C=Cf, groups=32, act=2))
     torch.cuda.synchronize()
     assert_close(yy, ref[0].permute(1, 2, 0).reshape(-1, Cf), 4e-3, 'fp16 GN + GELU + dwconv5x5')
+
+
+@pytest.mark.parametrize('L,T,dtype', [(2442, 30, 'bf16'), (3600, 12, 'bf16'), (3600, 12, 'fp16')])
+def test_mem_read_full_geometry_properties(dev, synth_weights, L, T, dtype):
+    """The memory read at the full geometries of BASELINE cfg 3 / 4 (577x1041 -> HW = 37 x 66 = 2442 tokens, unbounded bank grown
+    to T = 30) and cfg 5 (720x1280 -> HW = 45 x 80 = 3600, N = 12; also in the half flavour the config names), through
+    size-independent properties -- no oracle at these sizes: per-query mass over the bank frames sums to 1 and is >= 0; a second
+    launch is bit-identical; moving every frame to another physical slot changes nothing (bit-identical); the result does not
+    depend on how many table rows one workgroup walks; the read is linear in V; a bank of T identical frames reads the same as
+    one frame with mass 1/T each."""
+    import os
+    from rmem_ocu_amd import ops
+    from rmem_ocu_amd.runtime import temporal_slots
+    E = BF16 if dtype == 'bf16' else F16
+    C, S = 256, T + 2
+    slots = temporal_slots(T)
+    q = seeded(401, (L, C)).to(E).to(dev)
+    kb = seeded(402, (S, L, C)).to(E).to(dev)
+    vb = seeded(403, (S, L, C)).to(E).to(dev)
+    pe_cur = synth_weights['cur_pos_emb'].view(-1).to(dev)
+    pe_mem = synth_weights['mem_pos_emb'].to(dev).contiguous()
+    ws = ops.attn_workspace(L, 8, T, dev)
+
+    def read(kbank, vbank, order, pe=True):
+        out = torch.zeros(L, C, dtype=E, device=dev)
+        mass = torch.zeros(L, T, dtype=F32, device=dev)
+        tab = ops.make_chunk_table([(int(order[t]), 0, L, slots[t] if pe else -1, t) for t in range(T)]).to(dev)
+        ops.run(ops.mem_read_attn(q, kbank, vbank, out, ws, Lq=L, ldq=C, ldkv=C, ldo=C, slot_stride=L * C, chunks=tab, nchunks=T,
+                                  pe_cur=pe_cur if pe else None, pe_mem=pe_mem if pe else None, mass=mass, T=T))
+        torch.cuda.synchronize()
+        return out, mass
+
+    order = list(np.random.RandomState(7).permutation(S)[:T])
+    out, mass = read(kb, vb, order)
+    assert torch.isfinite(out.float()).all() and out.float().abs().mean().item() > 1e-3
+    assert (mass.sum(1) - 1.0).abs().max().item() < 1e-4 and mass.min().item() >= 0.0
+    out2, mass2 = read(kb, vb, order)
+    assert torch.equal(out, out2) and torch.equal(mass, mass2), 'two launches differ'
+    order2 = list(np.random.RandomState(8).permutation(S)[:T])
+    kb2, vb2 = torch.zeros_like(kb), torch.zeros_like(vb)
+    for t in range(T):
+        kb2[int(order2[t])] = kb[int(order[t])]
+        vb2[int(order2[t])] = vb[int(order[t])]
+    outp, massp = read(kb2, vb2, order2)
+    assert torch.equal(out, outp) and torch.equal(mass, massp), 'result depends on the physical bank slots'
+    res = {}
+    for tgt in ('1', '1000000'):                       # all T frames in one workgroup (no partials) / one frame per workgroup
+        os.environ['RMEM_ATTN_WGS'] = tgt
+        try:
+            res[tgt] = read(kb, vb, order)
+        finally:
+            del os.environ['RMEM_ATTN_WGS']
+    tol = 1e-2 if dtype == 'bf16' else 2e-3
+    assert_close(res['1'][0], res['1000000'][0].float().cpu(), tol, 'rows per workgroup')
+    assert_close(res['1'][0], out.float().cpu(), tol, 'one group vs default grouping')
+    assert (res['1'][1] - res['1000000'][1]).abs().max().item() < 1e-4
+    # linearity in V
+    v2 = seeded(404, (S, L, C)).to(E).to(dev)
+    o2, _ = read(kb, v2, order)
+    o12, _ = read(kb, (vb.float() + v2.float()).to(E), order)
+    assert_close(o12, (out.float() + o2.float()).cpu(), 2e-2 if dtype == 'bf16' else 4e-3, 'linearity in V')
+    # T identical frames (no temporal PE): the read equals the one-frame read, every frame gets mass 1 / T
+    kb3, vb3 = kb.clone(), vb.clone()
+    for t in range(1, T):
+        kb3[int(order[t])] = kb[int(order[0])]
+        vb3[int(order[t])] = vb[int(order[0])]
+    oT, mT = read(kb3, vb3, order, pe=False)
+    o1 = torch.zeros(L, C, dtype=E, device=dev)
+    ops.run(ops.mem_read_attn(q, kb[int(order[0])], vb[int(order[0])], o1, ws, Lq=L, ldq=C, ldkv=C, ldo=C, nchunks=1, lk_single=L))
+    torch.cuda.synchronize()
+    assert_close(oT, o1.float().cpu(), tol, 'T identical frames vs one frame')
+    assert (mT - 1.0 / T).abs().max().item() < 2e-3 / T

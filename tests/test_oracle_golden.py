@@ -94,7 +94,7 @@ def test_encoder_idbank_decoder(golden_ops, synth_weights):
     close(O.assign_identity(oh, None, w).permute(1, 2, 0).reshape(256, 7, 9), golden_ops['id_emb'])
 
 
-def _run_clip(name):
+def _run_clip(name, max_frames=None):
     g = np.load(os.path.join(GOLDEN, name))
     former, latter, n, h, wd, oh, ow, gap, objs, seed = g['meta'].tolist()
     frames, mask = make_clip(seed, n, h, wd, objs)
@@ -116,7 +116,7 @@ def _run_clip(name):
     eng.add_reference_frame(frames[0:1], mask, 0)
     ys, xs = g['sample_y'], g['sample_x']
     inject_at = int(g['inject_at']) if 'inject_at' in g.files else -1
-    for i in range(1, n):
+    for i in range(1, n if max_frames is None else min(n, max_frames)):
         logit = eng.match_propogate_one_frame(frames[i:i + 1], (oh, ow))
         label = torch.argmax(torch.softmax(logit, 1), 1, keepdim=True).float()
         if i == inject_at:        # evaluator.py:484-508
@@ -201,3 +201,17 @@ def test_swin_clip_matches_reference():
 def test_fitted_small_clip_matches_reference():
     """The oracle with the fitted ("trained-like") weights against the reference's free-running clip."""
     _check_clip('clip_small_fitted.npz')
+
+
+def test_n2_bank_clip_matches_reference():
+    """cfg-1 stand-in (BASELINE.json configs[0]: one 82-frame 480p clip, bank N = 2 = 1 + 1, gap 5, one object, fitted weights):
+    the oracle against the reference's free-running clip over the first 24 frames (three evictions of the only evictable entry;
+    the whole clip is compared on the GPU tier, tests/test_hip_engine.py::test_n2_bank_clip)."""
+    g, labels, trace, samples = _run_clip('clip_n2_fitted.npz', max_frames=24)
+    k = len(trace)
+    got = -np.ones_like(g['indexes'][:k])
+    for i, t in enumerate(trace):
+        got[i, :len(t)] = t
+    assert (got == g['indexes'][:k]).all()
+    assert np.abs(samples - g['logit_samples'][:k]).max() < 2e-3
+    assert (labels == g['labels'][:k]).mean() > 0.9999
