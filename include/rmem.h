@@ -293,6 +293,16 @@ int rmem_evict_scores(const float* logits_nhwc, int ldl, int num_classes, int ke
  * Capturable into a hipGraph (memcpy node). */
 int rmem_copy_async(void* dst, const void* src, size_t bytes, void* stream);
 
+/* Clips with more than 10 objects run one engine per 10 objects (engines/aot_engine.py:604-673).
+ * rmem_split_label: engine e's label map = ids start_id..end_id renumbered from 1, everything else 0 (separate_mask, 610-628).
+ * rmem_soft_logit_aggregate: soft_logit_aggregation (650-673) -- per engine softmax over its num_classes channels, background =
+ * product of the engines' background probabilities, then the engines' objs_per_engine foreground channels concatenated;
+ * clamp to [1e-5, 1 - 1e-5] and logit.  logits_nchw: HOST array of n_engines device pointers to [num_classes][H][W] fp32;
+ * out: [1 + n_engines * objs_per_engine][H][W] fp32. */
+int rmem_split_label(const float* label, int start_id, int end_id, float* out, long long n, void* stream);
+int rmem_soft_logit_aggregate(const float* const* logits_nchw, int n_engines, int num_classes, int objs_per_engine, int H, int W,
+                              float* out_nchw, void* stream);
+
 /* Test-time-augmentation merge: softmax of each augmentation's NCHW logits (read horizontally flipped where flips[a] != 0),
  * mean over the <= 8 augmentations (scales x flips), argmax; writes any of uint8 labels, fp32 labels, NCHW mean probabilities.
  * logits_nchw / flips are HOST arrays of n_aug entries.  Replaces managers/evaluator.py:427-441 (flip / multi-scale TTA). */

@@ -72,6 +72,8 @@ SIGNATURES = {
     'rmem_evict_scores': (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp]),
     'rmem_tta_merge': (_i, [C.POINTER(_vp), C.POINTER(_i), _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     'rmem_mask_iou_counts': (_i, [_vp, _vp, _ll, _i, _i, _vp, _vp]),
+    'rmem_split_label': (_i, [_vp, _i, _i, _vp, _ll, _vp]),
+    'rmem_soft_logit_aggregate': (_i, [C.POINTER(_vp), _i, _i, _i, _i, _i, _vp, _vp]),
     'rmem_copy_async': (_i, [_vp, _vp, C.c_size_t, _vp]),
     'rmem_scatter_blocks': (_i, [_vp, _vp, _vp, _i, _ll, _ll, _vp]),
     'rmem_copy2d_async': (_i, [_vp, _ll, _vp, _ll, _ll, _i, _vp]),

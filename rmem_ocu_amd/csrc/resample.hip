@@ -253,6 +253,40 @@ __global__ __launch_bounds__(256) void k_tta_merge(TtaParams p) {
   if (p.label_f32) p.label_f32[i] = (float)arg;
 }
 
+// > 10 objects: one AOTEngine per 10 objects (engines/aot_engine.py:604-673).
+// split: the label map of engine e keeps ids start..end renumbered from 1, everything else 0 (separate_mask, 610-628).
+__global__ __launch_bounds__(256) void k_split_label(const float* label, int start_id, int end_id, float* out, long n) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float v = label[i];
+  out[i] = (v >= (float)start_id && v <= (float)end_id) ? v - (float)start_id + 1.f : 0.f;
+}
+// aggregate (soft_logit_aggregation, 650-673): per engine softmax over its nc channels; background = product of the engines'
+// background probabilities, foreground channels concatenated; clamp to [1e-5, 1 - 1e-5]; logit.
+struct AggParams { const float* lg[8]; int n, nc, nobj; long total; float* out; };
+__global__ __launch_bounds__(256) void k_soft_aggregate(AggParams p) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= p.total) return;
+  float bg = 1.f;
+  for (int e = 0; e < p.n; ++e) {
+    float v[16], mx = -3.0e38f, den = 0.f;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) { v[c] = c < p.nc ? p.lg[e][(long)c * p.total + i] : -3.0e38f; mx = fmaxf(mx, v[c]); }
+#pragma unroll
+    for (int c = 0; c < 16; ++c) { v[c] = c < p.nc ? expf(v[c] - mx) : 0.f; den += v[c]; }
+    const float inv = 1.f / den;
+    bg *= v[0] * inv;
+#pragma unroll
+    for (int c = 1; c < 16; ++c)
+      if (c <= p.nobj) {
+        const float pr = fminf(fmaxf(v[c] * inv, 1e-5f), 1.f - 1e-5f);
+        p.out[(long)(1 + e * p.nobj + (c - 1)) * p.total + i] = logf(pr / (1.f - pr));
+      }
+  }
+  bg = fminf(fmaxf(bg, 1e-5f), 1.f - 1e-5f);
+  p.out[i] = logf(bg / (1.f - bg));
+}
+
 // Jaccard counts per object id (evaluation/source/metrics.py:6-37 applied per id): counts[id] = {|pred == id & gt == id|,
 // |pred == id | gt == id|}, pixels whose ground truth is the void label are skipped.  Integer atomics: deterministic.
 __global__ __launch_bounds__(256) void k_mask_iou(const uint8_t* pred, const uint8_t* gt, long n, int num_ids, int void_label,
@@ -451,6 +485,23 @@ extern "C" int rmem_tta_merge(const float* const* logits_nchw, const int* flips,
 #endif
 
 #ifndef RMEM_F16
+extern "C" int rmem_split_label(const float* label, int start_id, int end_id, float* out, long long n, void* stream) {
+  RMEM_REQUIRE(label && out && n > 0 && start_id >= 1 && end_id >= start_id, "rmem_split_label: bad argument");
+  hipLaunchKernelGGL(k_split_label, dim3(nblk((long)n)), dim3(256), 0, (hipStream_t)stream, label, start_id, end_id, out, (long)n);
+  return rmem_check_launch("rmem_split_label");
+}
+
+extern "C" int rmem_soft_logit_aggregate(const float* const* logits_nchw, int n_engines, int num_classes, int objs_per_engine, int H, int W,
+                                         float* out_nchw, void* stream) {
+  RMEM_REQUIRE(logits_nchw && out_nchw && n_engines >= 1 && n_engines <= 8 && num_classes >= 2 && num_classes <= 16 &&
+               objs_per_engine >= 1 && objs_per_engine < num_classes && H > 0 && W > 0, "rmem_soft_logit_aggregate: bad argument");
+  AggParams p;
+  for (int e = 0; e < 8; ++e) p.lg[e] = e < n_engines ? logits_nchw[e] : nullptr;
+  p.n = n_engines; p.nc = num_classes; p.nobj = objs_per_engine; p.total = (long)H * W; p.out = out_nchw;
+  hipLaunchKernelGGL(k_soft_aggregate, dim3(nblk(p.total)), dim3(256), 0, (hipStream_t)stream, p);
+  return rmem_check_launch("rmem_soft_logit_aggregate");
+}
+
 extern "C" int rmem_mask_iou_counts(const unsigned char* pred, const unsigned char* gt, long long n, int num_ids, int void_label,
                                     unsigned long long* counts, void* stream) {
   RMEM_REQUIRE(pred && gt && counts && n > 0 && num_ids >= 2 && num_ids <= 32, "rmem_mask_iou_counts: bad argument");

@@ -19,7 +19,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-from . import _lib
+from . import _lib, ops
 from .networks.engines import build_engine
 
 
@@ -136,7 +136,16 @@ class SequenceEvaluator:
                     self.engines[a].add_reference_frame(frame(a, t), lab, obj_nums=nobj, frame_step=t)
             else:
                 for a, (si, fl) in enumerate(augs):
-                    lab = F.interpolate(label_f.flip(3) if fl else label_f, size=self.engines[a].input_size_2d, mode='nearest')
-                    self.engines[a].update_memory(lab)
+                    e = self.engines[a]
+                    if not fl and len(e.aot_engines) == 1:
+                        # the nearest resize to the network size (evaluator.py:518-522) happens inside the one-hot kernel;
+                        # a fixed buffer, so the engine's prepared launch list for it is built once
+                        if getattr(self, '_lab_u8', None) is None or self._lab_u8.shape != label_u8.shape:
+                            self._lab_u8 = torch.empty_like(label_u8)
+                        ops.copy_async(self._lab_u8, label_u8, label_u8.numel())(torch.cuda.current_stream(label_u8.device).cuda_stream)
+                        e.update_memory_from_label_u8(self._lab_u8)
+                    else:
+                        lab = F.interpolate(label_f.flip(3) if fl else label_f, size=e.input_size_2d, mode='nearest')
+                        e.update_memory(lab)
             outs.append(label_u8)
         return outs

@@ -165,7 +165,15 @@ class AOTEngine:
         m = mask.reshape(mask.shape[-2], mask.shape[-1])
         if tuple(m.shape) != (self.rt.H, self.rt.W):
             raise ValueError(f'mask must be at the network size {(self.rt.H, self.rt.W)}, got {tuple(m.shape)}')
-        self.label_in.copy_(m, non_blocking=True)
+        self._copy_in(self.label_in, m)
+
+    def _copy_in(self, dst, src):
+        """Frame / label into the engine's fixed input buffer on the engine's stream: a plain memcpy node through the C ABI when
+        the caller's tensor already has the buffer's type and layout (the evaluator's do), torch's converting copy otherwise."""
+        if src.is_cuda and src.dtype == dst.dtype and src.is_contiguous():
+            ops.copy_async(dst, src, dst.numel() * dst.element_size())(self._stream())
+        else:
+            dst.copy_(src, non_blocking=True)
 
     # ------------------------------------------------------------------ reference frame
     def add_reference_frame(self, img=None, mask=None, frame_step=-1, obj_nums=None, img_embs=None):
@@ -189,7 +197,7 @@ class AOTEngine:
         # (the reference keeps that list across the reset, aot_engine.py:323) and on the policy state must still happen
         self._resolve_pending()
         with self._scope():
-            self.img_in.copy_(img.reshape(3, rt.H, rt.W), non_blocking=True)
+            self._copy_in(self.img_in, img.reshape(3, rt.H, rt.W))
             self._set_label(mask)
             # (re)initialise the bank to this frame only (aot_engine.py:322; quirk: long_memories_indexes keeps growing, 323)
             rt.prepare_pos(self._stream())
@@ -212,7 +220,7 @@ class AOTEngine:
         rt = self.rt
         self._resolve_pending()
         with self._scope() as cur:
-            self.img_in.copy_(img.reshape(3, rt.H, rt.W), non_blocking=True)
+            self._copy_in(self.img_in, img.reshape(3, rt.H, rt.W))
             T = len(rt.slots)
             self._T_at_propagate = T
             wm = self._mass_needed(T)
@@ -404,33 +412,40 @@ class AOTInferEngine:
         self.obj_nums = None
 
     def separate_mask(self, mask):
-        """aot_engine.py:604-628 (label-map branch)."""
+        """aot_engine.py:604-628 (label-map branch): engine e keeps ids e*10+1 .. (e+1)*10, renumbered from 1 (rmem_split_label)."""
         if mask is None:
             return [None] * len(self.aot_engines)
         if len(self.aot_engines) == 1:
             return [mask]
         if mask.dim() == 3 or mask.shape[0] == 1:
+            import ctypes as C
+            from ... import _lib
+            m = mask.to(F32).contiguous()
+            s = torch.cuda.current_stream(m.device).cuda_stream
             out = []
             for idx in range(len(self.aot_engines)):
-                start_id = idx * self.max_aot_obj_num + 1
-                end_id = (idx + 1) * self.max_aot_obj_num
-                fg = ((mask >= start_id) & (mask <= end_id)).float()
-                out.append((fg * mask - start_id + 1) * fg)
+                o = torch.empty_like(m)
+                _lib.check(_lib.lib().rmem_split_label(m.data_ptr(), idx * self.max_aot_obj_num + 1, (idx + 1) * self.max_aot_obj_num,
+                                                       o.data_ptr(), m.numel(), C.c_void_p(s)), 'rmem_split_label')
+                out.append(o)
             return out
         raise NotImplementedError('probability masks for >10 objects')
 
     def soft_logit_aggregation(self, all_logits):
-        """aot_engine.py:650-673."""
+        """aot_engine.py:650-673 as one HIP launch (rmem_soft_logit_aggregate)."""
         if len(all_logits) == 1:
             return all_logits[0]
-        fg_probs, bg_probs = [], []
-        for logit in all_logits:
-            prob = torch.softmax(logit, dim=1)
-            bg_probs.append(prob[:, 0:1])
-            fg_probs.append(prob[:, 1:1 + self.max_aot_obj_num])
-        bg_prob = torch.prod(torch.cat(bg_probs, dim=1), dim=1, keepdim=True)
-        merged = torch.cat([bg_prob] + fg_probs, dim=1).clamp(1e-5, 1 - 1e-5)
-        return torch.logit(merged)
+        import ctypes as C
+        from ... import _lib
+        n = len(all_logits)
+        lg = [t.contiguous() for t in all_logits]
+        _, nc, H, W = lg[0].shape
+        out = torch.empty(1, 1 + n * self.max_aot_obj_num, H, W, dtype=F32, device=lg[0].device)
+        ptrs = (C.c_void_p * n)(*[t.data_ptr() for t in lg])
+        _lib.check(_lib.lib().rmem_soft_logit_aggregate(ptrs, n, nc, self.max_aot_obj_num, H, W, out.data_ptr(),
+                                                        C.c_void_p(torch.cuda.current_stream(out.device).cuda_stream)),
+                   'rmem_soft_logit_aggregate')
+        return out
 
     def add_reference_frame(self, img, mask, obj_nums, frame_step=-1):
         if isinstance(obj_nums, list):
