@@ -657,9 +657,11 @@ def ingest_rgb8(rgb: np.ndarray, hd: int, wd: int) -> np.ndarray:
     return img.transpose(2, 0, 1).astype(np.float32)
 
 
-def db_eval_iou(annotation: np.ndarray, segmentation: np.ndarray) -> float:
-    """evaluation/source/metrics.py:6-37 (single frame, no void)."""
+def db_eval_iou(annotation: np.ndarray, segmentation: np.ndarray, void_pixels: Optional[np.ndarray] = None) -> float:
+    """evaluation/source/metrics.py:6-37 (single frame): Jaccard index of two binary maps, void pixels excluded from both
+    counts, 1 when the union is empty."""
     a = annotation.astype(bool)
     s = segmentation.astype(bool)
-    union = np.sum(a | s)
-    return 1.0 if union == 0 else float(np.sum(a & s)) / float(union)
+    keep = np.ones_like(a) if void_pixels is None else np.logical_not(void_pixels.astype(bool))
+    union = np.sum((a | s) & keep)
+    return 1.0 if union == 0 else float(np.sum((a & s) & keep)) / float(union)

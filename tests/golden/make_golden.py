@@ -307,9 +307,37 @@ def gen_clip(tag, former, latter, n_frames, h, w, out_hw, gap, objs, seed, injec
     }
 
 
+def gen_iou():
+    """J (region similarity) of the reference's own metric, evaluation/source/metrics.py:6-37, on seeded mask pairs.  The module
+    imports cv2 at the top (absent here; only db_eval_boundary, the F metric, uses it): an empty in-memory module entry lets the
+    import succeed, db_eval_iou itself is plain numpy."""
+    import types
+    sys.modules.setdefault('cv2', types.ModuleType('cv2'))
+    sys.path.insert(0, os.path.join(os.path.dirname(REF), 'evaluation', 'source') if os.path.basename(REF) == 'aot_plus' else REF)
+    import importlib
+    metrics = importlib.import_module('metrics')
+    rng = np.random.Generator(np.random.PCG64([77, 0xC0FFEE]))
+    out = {'n': np.array(24)}
+    for i in range(24):
+        h, w = int(rng.integers(8, 97)), int(rng.integers(8, 129))
+        ids = int(rng.integers(1, 6))
+        gt = (rng.integers(0, ids + 1, size=(h // 4 + 1, w // 4 + 1)).repeat(4, 0).repeat(4, 1)[:h, :w]).astype(np.uint8)
+        flip = rng.random((h, w)) < 0.15
+        pred = np.where(flip, rng.integers(0, ids + 1, size=(h, w)), gt).astype(np.uint8)
+        if i % 6 == 0:
+            pred[pred == 1] = 0; gt[gt == 1] = 0                    # an id absent from both: union 0 -> J = 1
+        void = (rng.random((h, w)) < 0.05) if i % 3 == 0 else None
+        js = [float(metrics.db_eval_iou(gt == k, pred == k, void)) for k in range(1, ids + 1)]
+        out[f'gt{i}'], out[f'pred{i}'], out[f'j{i}'] = gt, pred, np.array(js, dtype=np.float64)
+        out[f'void{i}'] = np.zeros((0,), dtype=bool) if void is None else void
+    return out
+
+
 if __name__ == '__main__':
     what = sys.argv[1] if len(sys.argv) > 1 else 'all'
     torch.set_num_threads(8)
+    if what in ('iou', 'all'):
+        np.savez_compressed(os.path.join(HERE, 'iou.npz'), **gen_iou())
     if what in ('ops', 'all'):
         _, model, _ = load_reference()
         np.savez_compressed(os.path.join(HERE, 'ops.npz'), **gen_ops(model))

@@ -917,3 +917,23 @@ def test_mem_read_full_geometry_properties(dev, synth_weights, L, T, dtype):
     torch.cuda.synchronize()
     assert_close(oT, o1.float().cpu(), tol, 'T identical frames vs one frame')
     assert (mT - 1.0 / T).abs().max().item() < 2e-3 / T
+
+
+def test_mask_iou_counts_vs_reference_fixture(dev):
+    """f4: the device J counts (rmem_mask_iou_counts via evaluator.region_similarity) against J values produced by the reference's
+    own evaluation/source/metrics.py::db_eval_iou (tests/golden/iou.npz): several ids, void pixels (label 255), absent ids."""
+    import os
+    from conftest import GOLDEN
+    from rmem_ocu_amd.evaluator import region_similarity
+    g = np.load(os.path.join(GOLDEN, 'iou.npz'))
+    for i in range(int(g['n'])):
+        gt, pred, js, void = g[f'gt{i}'].copy(), g[f'pred{i}'], g[f'j{i}'], g[f'void{i}']
+        if void.size:
+            gt[void] = 255                        # the DAVIS convention the kernel implements: void pixels carry label 255 in the annotation
+        got = region_similarity(torch.from_numpy(pred).to(dev), torch.from_numpy(gt).to(dev))
+        for k, j in enumerate(js, start=1):
+            present = bool(((gt == k) | ((pred == k) & (gt != 255))).any())
+            if present:
+                assert abs(got[k] - j) < 1e-9, (i, k, got.get(k), j)
+            else:
+                assert k not in got and j == 1.0   # absent from both maps: the reference defines J = 1, the device skips the id

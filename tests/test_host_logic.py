@@ -120,3 +120,17 @@ def test_davis_palette_and_png_writer(tmp_path):
     save_mask(m, str(tmp_path / 'a.png'), squeeze_idx=[0, 4, 9])
     back = np.array(Image.open(str(tmp_path / 'a.png')))
     assert back.max() == 9 and (back == 9).sum() == 6
+
+
+def test_oracle_iou_metric_matches_reference_fixture():
+    """f4 pinned: oracle.db_eval_iou against J values the reference's own evaluation/source/metrics.py produced
+    (tests/golden/make_golden.py iou) -- several ids per pair, void pixels, an id absent from both maps (J = 1)."""
+    import os
+    from conftest import GOLDEN
+    from oracle import ref_cpu as O
+    g = np.load(os.path.join(GOLDEN, 'iou.npz'))
+    for i in range(int(g['n'])):
+        gt, pred, js, void = g[f'gt{i}'], g[f'pred{i}'], g[f'j{i}'], g[f'void{i}']
+        v = void if void.size else None
+        for k, j in enumerate(js, start=1):
+            assert abs(O.db_eval_iou(gt == k, pred == k, v) - j) < 1e-12, (i, k)
