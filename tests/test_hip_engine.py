@@ -556,6 +556,45 @@ def test_group_engine_unbounded_bank():
         assert ge.long_memories_indexes(c) == refs[c][1][-1] and len(refs[c][1][-1]) == 20
 
 
+def test_group_engine_table_uploads_never_race_the_gpu():
+    """The key table and the append-slot table are re-sent through small pinned staging rings while earlier frames are still
+    queued (graph replay enqueues ~10x faster than the GPU runs).  Unbounded bank + gap 1: both tables change EVERY frame and
+    nothing makes the host wait (no eviction read-back), so a staging row would be rewritten under a queued copy if the ring did
+    not wait on its upload events.  A run that never synchronises must equal a run that synchronises after every step."""
+    from rmem_ocu_amd import build_vos_model, get_config
+    from rmem_ocu_amd.clip_runner import GroupSlot
+    from rmem_ocu_amd.networks.engines.group_engine import GroupEngine
+    from rmem_ocu_amd.synth import make_clip
+    from rmem_ocu_amd.weights import synth_state_dict
+    dev = torch.device('cuda', 0)
+    B, n, oh, ow = 2, 30, 160, 192
+    clips = [make_clip(120 + c, n, 161, 193, 2) for c in range(B)]
+    cfg = get_config('pre_vost', 'test', 'r50_aotl')
+    cfg.FORMER_MEM_LEN, cfg.LATTER_MEM_LEN = 1, 9999
+    model = build_vos_model(cfg.MODEL_VOS, cfg).cuda(0)
+    model.load_state_dict(synth_state_dict(0))
+    runs = []
+    for sync_every_step in (True, False):
+        ge = GroupEngine(model, B, 0, 1, lookahead=2)
+        gs = GroupSlot(ge, (oh, ow), dev)
+        gs.start([f.to(dev) for f, _ in clips], [m.to(dev) for _, m in clips], 2)
+        ge.long_term_mem_gap = 1
+        if not sync_every_step:              # first build every graph (bank sizes 1..30) so that the racing run only replays
+            while not gs.done:
+                gs.step()
+            ge.synchronize()
+            gs.start([f.to(dev) for f, _ in clips], [m.to(dev) for _, m in clips], 2)
+            ge.long_term_mem_gap = 1
+        while not gs.done:
+            gs.step()
+            if sync_every_step:
+                ge.synchronize()
+        ge.synchronize()
+        runs.append((gs.labels[:, :n].cpu().numpy().copy(), [list(ge.long_memories_indexes(c)) for c in range(B)]))
+    assert runs[0][1] == runs[1][1] and len(runs[0][1][0]) == n
+    assert np.array_equal(runs[0][0], runs[1][0]), 'asynchronous table uploads changed the masks'
+
+
 def test_group_slot_from_pinned_uint8_frames():
     """Clip group fed from decoded uint8 frames in pinned host memory (H2D + ingest kernel into the look-ahead encoder's input)
     gives the masks of the same group fed with the ingested fp32 frames from device memory."""
