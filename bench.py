@@ -24,7 +24,10 @@ inside the timed region are executed but not counted as steps.  Inside a clip th
 the LSTT (frames do not depend on each other before the memory read): one launch per encoder layer covers 2 frames x 4
 clips, every frame is still encoded exactly once (config.encoder_lookahead).  A group step propagates 4 frames, so the timed
 region executes ceil(K / 4) * 4 frames while `value` = K / elapsed (never over-reports;
-config.frames_executed_in_timed_region).  Inputs are resident in HBM when the timed region starts.
+config.frames_executed_in_timed_region).  Because of the look-ahead a SHORT window can contain more or less encoder work than the
+frames it counts (the encoder of a counted frame may have run just before the window, that of a frame after it inside):
+config.frames_encoded_in_timed_region says how many frames the encoder processed inside the window (rank 0) -- with the default
+configuration it is >= the counted steps (24 for --steps 20), over a long window the two converge.  Inputs are resident in HBM when the timed region starts.
 
 The single JSON line also carries
   roofline     -- the dominant kernel (the long-term memory read, rmem_mem_read_attn_clips): AFTER the timed region (so
@@ -279,6 +282,7 @@ def main():
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
+    enc0 = sum(s.frames_encoded for s in slots)
     t0 = time.perf_counter()
     run_steps(args.steps)
     host_enqueue = time.perf_counter() - t0
@@ -286,6 +290,7 @@ def main():
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    enc_in_window = sum(s.frames_encoded for s in slots) - enc0
 
     checksum = float(sum(int(s.labels.sum().item()) for s in slots))
     from rmem_ocu_amd.clip_runner import gather_stats
@@ -342,6 +347,7 @@ def main():
                        'tokens': L16, 'objects': NUM_OBJS,
                        'memory_bank': f"{wl['former']}+{wl['latter']}", 'gap': [max(int(round(n / 30)), 5) for n in wl['lengths']][0],
                        'clips_in_flight_per_gpu': C * G, 'clips_per_group': G, 'frames_executed_in_timed_region': -(-args.steps // G) * G,
+                       'frames_encoded_in_timed_region': enc_in_window,
                        'parallelism': f'clip-parallel x{world}', 'weights': 'synthetic (no checkpoint offline)',
                        'hipgraphs': not args.no_graphs, 'frames_from': 'pinned host uint8 (PCIe-inclusive)' if args.host_frames else 'HBM',
                        'encoder_lookahead': lookahead, 'host_enqueue_ms_per_step': round(1e3 * host_enqueue / args.steps, 4)},

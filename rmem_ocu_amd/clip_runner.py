@@ -144,6 +144,7 @@ class ClipSlot:
         self.frames = None
         self.cursor = 0
         self.done = True
+        self.frames_encoded = 0             # frames that went through the encoder (reference frames + look-ahead batches)
 
     def start(self, frames: torch.Tensor, first_mask: torch.Tensor, num_objs: int):
         """frames [n,3,H,W] fp32 device at network size, or decoded uint8 RGB [n,Hs,Ws,3] in PINNED HOST memory (then every
@@ -177,6 +178,7 @@ class ClipSlot:
             eng.add_reference_frame(self._first, first_mask, obj_nums=[num_objs], frame_step=0)
         else:
             eng.add_reference_frame(frames[0:1], first_mask, obj_nums=[num_objs], frame_step=0)
+        self.frames_encoded += 1
         self.cursor = 1
         self.done = n <= 1
 
@@ -199,6 +201,7 @@ class ClipSlot:
         if self.lookahead > 1:
             e = (i - 1) % self.lookahead
             if e == 0:
+                self.frames_encoded += min(self.lookahead, self.frames.shape[0] - i)
                 if self.host_u8:
                     self._ingest_group(i)
                     self.engine.encode_ahead(None, self.lookahead)
@@ -206,9 +209,11 @@ class ClipSlot:
                     self.engine.encode_ahead(self.frames[i:i + self.lookahead], self.lookahead)
             self.engine.propagate_to_label(None, self.cur_label, enc_slot=e)
         elif self.host_u8:
+            self.frames_encoded += 1
             self._ingest_group(i)
             self.engine.propagate_to_label(self._first, self.cur_label)
         else:
+            self.frames_encoded += 1
             self.engine.propagate_to_label(self.frames[i:i + 1], self.cur_label)
         self.engine.update_memory_from_label_u8(self.cur_label)
         # the clip's delivered masks stay on the device
@@ -231,6 +236,7 @@ class GroupSlot:
         self.frames = None
         self.cursor = 0
         self.done = True
+        self.frames_encoded = 0             # frames that went through the encoder (reference frames + look-ahead batches)
 
     def start(self, frames: Sequence[torch.Tensor], first_masks: Sequence[torch.Tensor], num_objs: int, new_objects=None):
         """frames: B tensors [n, 3, H, W] fp32 device (equal n), or B uint8 [n, Hs, Ws, 3] tensors in PINNED HOST memory (every
@@ -269,6 +275,7 @@ class GroupSlot:
                 imgs = torch.cat([f[0:1] for f in frames], 0)
             masks = torch.cat([m.reshape(1, 1, m.shape[-2], m.shape[-1]).float() for m in first_masks], 0)
         eng.add_reference_frames(imgs, masks, num_objs)
+        self.frames_encoded += self.B
         self.cursor = 1
         self.done = n <= 1
 
@@ -296,10 +303,13 @@ class GroupSlot:
         if la > 1:
             e = (i - 1) % la
             if e == 0:
-                self._fill_encoder_inputs(eng.encode_inputs(), i, min(la, self.frames[0].shape[0] - i))
+                m = min(la, self.frames[0].shape[0] - i)
+                self.frames_encoded += B * m
+                self._fill_encoder_inputs(eng.encode_inputs(), i, m)
                 eng.encode_ahead()
             eng.propagate_to_labels(self.cur_label, enc_slot=e)
         else:
+            self.frames_encoded += B
             if self.host_u8:
                 self._fill_encoder_inputs(self._first, i, 1)
                 imgs = self._first
