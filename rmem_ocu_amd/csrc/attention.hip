@@ -128,26 +128,26 @@ template <int N>
 __device__ __forceinline__ void lds_wait4(e16x8& a, e16x8& b, e16x8& c, e16x8& d) {
   asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "n"(N));
 }
-struct PvFrag { s16x4 lo[2], hi[2]; e16x8 ones[2]; };      // one 32-key block: V^T fragments and row-sum operands of its 2 slabs
+struct PvFrag { s16x4 lo[2], hi[2]; };      // one 32-key block: the V^T fragments of its 2 slabs
 template <int N>
 __device__ __forceinline__ void lds_wait_pv(PvFrag& f) {
-  asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(f.lo[0]), "+v"(f.hi[0]), "+v"(f.lo[1]), "+v"(f.hi[1]), "+v"(f.ones[0]), "+v"(f.ones[1]) : "n"(N));
+  asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(f.lo[0]), "+v"(f.hi[0]), "+v"(f.lo[1]), "+v"(f.hi[1]) : "n"(N));
 }
 
 // MEM = true: memory-read flavour (row table, temporal PE); false: one plain key frame cut into nchunks ranges.  Two
 // symbols so a kernel trace separates the long-term memory read from the short-term / self attention launches.
 // TIMED changes nothing but the symbol: launches bracketed by rmem_profile_* HIP events use the <true, true> instance, so
 // a kernel trace of the same run lists exactly the launches bench.py timed under their own name.
+#ifndef RMEM_ATTN_WGS_PER_CU
+#define RMEM_ATTN_WGS_PER_CU 3          // workgroups (= waves per SIMD) the register budget is set for
+#endif
 template <bool MEM, bool TIMED = false>
-__global__ __launch_bounds__(256, 3) void k_attn_partial(AttnParams pin) {
+__global__ __launch_bounds__(256, RMEM_ATTN_WGS_PER_CU) void k_attn_partial(AttnParams pin) {
   AttnParams p = pin;
   __shared__ __attribute__((aligned(16))) e16 Ks[NB][KT * D];  // ring of NB tiles: [key][32], 16-byte chunks XOR-swizzled
   __shared__ __attribute__((aligned(16))) e16 Vs[NB][KT * D];  // [key][32] row-major, read transposed (ds_read_b64_tr_b16)
-  // 1.0 / 0.0 per key of the tile: the A operand of the row-sum MFMA.  A row's ragged last tile (HW = 1674 = 26 * 64 + 10) is
-  // padded with K = V = 0 keys (the DMA's range check); they add nothing to O, and reading the "ones" from here keeps them
-  // out of l without a single per-score select (masking S instead costs 90 VALU instructions per tile once the compiler
-  // if-converts it)
-  __shared__ __attribute__((aligned(16))) e16 Ones[NB][KT];
+  // A row's ragged last tile (HW = 1674 = 26 * 64 + 10) is padded with K = V = 0 keys (the DMA's range check); they add
+  // nothing to O, and what they add to the row sum is known exactly (see the row end in step()).
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // provably wave-uniform: LDS-DMA destinations stay in SGPRs
@@ -225,22 +225,19 @@ __global__ __launch_bounds__(256, 3) void k_attn_partial(AttnParams pin) {
   const int skey = 16 * wave + (lane >> 2), spos = lane & 3;
   const int voff_k = (skey * p.ldkv + ((spos ^ ((skey >> 2) & 3)) << 3)) * 2;
   const int voff_v = (skey * p.ldkv + (spos << 3)) * 2;
-  // Ones[] is kept in the k-order of the P^T fragment (see the header: k = 8h + j of a 16-key slab is key 8(j>>2) + 4h + (j&3)),
-  // so that one 16-byte read per (block, slab, lane half) is the row-sum MFMA's A operand
-  const int sones = (skey & ~15) | (((skey >> 2) & 1) << 3) | (((skey >> 3) & 1) << 2) | (skey & 3);
   const int tile_elems = KT * p.ldkv;
   // The DMA cursor runs NB - 1 tiles ahead of the arithmetic, across row boundaries: (row dc, tile dt) with the row's base
   // pointers at this head's columns (wave-uniform: SGPRs).
   const e16* row_k = nullptr;
   const e16* row_v = nullptr;
-  int row_bytes = 0, row_kn = 0, dc = 0, dt = 0, dnt = 0;
+  int row_bytes = 0, dc = 0, dt = 0, dnt = 0;
   auto open_row = [&](int c) {
     const Row r = row_info(c);
     const long off = (long)r.slot * p.slot_stride + (long)r.kb * p.ldkv + head * D;
     row_k = p.k + off; row_v = p.v + off;
     row_bytes = r.kn > 0 ? ((r.kn - 1) * p.ldkv + D) * 2 : 0;  // up to the end of the last key's slice; an EMPTY row (key_count 0:
-    row_kn = r.kn;                                              // padding of a clip whose bank is shorter than its group's) is one
-    dc = c; dt = 0; dnt = max(1, (r.kn + KT - 1) / KT);         // tile of out-of-range reads = zeros, with zeros in the row-sum operand
+                                                                // padding of a clip whose bank is shorter than its group's) is one
+    dc = c; dt = 0; dnt = max(1, (r.kn + KT - 1) / KT);         // tile of out-of-range reads = zeros, its row sum is forced to 0
   };
   // Next tile of the group -> LDS buffer BUF (asynchronous: counted s_waitcnt vmcnt before use); false once the group is
   // exhausted.  The descriptor is rebuilt per tile (scalar work) so that it starts at the tile and ends with the row: the
@@ -250,8 +247,6 @@ __global__ __launch_bounds__(256, 3) void k_attn_partial(AttnParams pin) {
     constexpr int BUF = decltype(buf_tag)::value;
     if (dc >= c1) return false;
     const int left = row_bytes - dt * tile_elems * 2;
-    // (the plain LDS store goes first: behind a DMA the compiler would wait for the DMA before it)
-    if (spos == 0) Ones[BUF][sones] = (e16)(dt * KT + skey < row_kn ? 1.0f : 0.0f);
     buf_load_lds16(make_rsrc(row_k + (long)dt * tile_elems, left), (lptr_t)&Ks[BUF][wave * 16 * D], voff_k, 0);
     buf_load_lds16(make_rsrc(row_v + (long)dt * tile_elems, left), (lptr_t)&Vs[BUF][wave * 16 * D], voff_v, 0);
     if (++dt >= dnt) {
@@ -267,7 +262,6 @@ __global__ __launch_bounds__(256, 3) void k_attn_partial(AttnParams pin) {
   // LDS byte addresses of this lane's fragments in buffer 0 (buffer and block are instruction offsets)
   const unsigned k_addr[2] = {(unsigned)(size_t)(lptr_t)&Ks[0][kswz(lq, lh)], (unsigned)(size_t)(lptr_t)&Ks[0][kswz(lq, 2 + lh)]};
   const unsigned v_addr = (unsigned)(size_t)(lptr_t)&Vs[0][tr_off];
-  const unsigned o_addr = (unsigned)(size_t)(lptr_t)&Ones[0][8 * lh];
 
   // HW = 1674 = 13 * 128 + 10: in the last query tile only wave 0 owns real rows.  The other waves still stage K/V and meet
   // the barriers, but skip the softmax / MFMA work (3 of 56 wave-tiles per (head, group) saved).
@@ -280,9 +274,12 @@ __global__ __launch_bounds__(256, 3) void k_attn_partial(AttnParams pin) {
   // One pass over the group's rows.  SAFE = false: m_ref is the first tile's maximum and stays; true: online softmax.
   auto walk = [&](auto safe_tag) {
     constexpr bool SAFE = decltype(safe_tag)::value;
-    f32x16 lacc, cinit;
+    f32x16 cinit;
+    // row sum of the probabilities this LANE holds (the other 32 keys of every tile sit in lane ^ 32), two chains
+    float lrow[2] = {0.f, 0.f};
+    const e16x2 one2 = {(e16)1.0f, (e16)1.0f};
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { oacc[r] = 0.f; lacc[r] = 0.f; }
+    for (int r = 0; r < 16; ++r) oacc[r] = 0.f;
     m_ref = 0.f; ltot = 0.f;
     int c = c0;
     Row cur = row_info(c);
@@ -308,13 +305,13 @@ __global__ __launch_bounds__(256, 3) void k_attn_partial(AttnParams pin) {
     // first tile (m_ref := tile maximum, nothing accumulated yet); 2: SAFE pass (move m_ref and rescale when a tile exceeds
     // it by 2^8).  The FAST steady state must not carry any of the extras: predicated off they are if-converted into ~60
     // subtractions / maxima per tile, which is exactly the VALU work this kernel cannot afford -- hence one copy per
-    // MAXMODE.  Padded keys of a ragged tile score S' = bias - m_ref (K = 0): a finite P that meets V = 0 and a 0 in the
-    // row-sum operand.
+    // MAXMODE.  Padded keys of a ragged tile score exactly S' = bias - m_ref (K = 0): a finite P that meets V = 0; the row sum
+    // counts them and the row end takes them out again.
     auto tile = [&](auto mode_tag, auto buf_tag) {
       constexpr int MAXMODE = decltype(mode_tag)::value;
       constexpr int BUF = decltype(buf_tag)::value;
       // S'^T = K . Q^T + (bias - m_ref) for the two 32-key blocks of this tile
-      constexpr int KB = BUF * KT * D * 2, VB = BUF * KT * D * 2, OB = BUF * KT * 2;      // byte offsets of the ring slot
+      constexpr int KB = BUF * KT * D * 2, VB = BUF * KT * D * 2;      // byte offsets of the ring slot
       e16x8 ka[2][2];
       ka[0][0] = lds_b128<KB>(k_addr[0]);
       ka[0][1] = lds_b128<KB>(k_addr[1]);
@@ -335,17 +332,15 @@ __global__ __launch_bounds__(256, 3) void k_attn_partial(AttnParams pin) {
         sacc[b] = RMEM_MFMA_32x32x16(ka[b][1], qf[1], sacc[b], 0, 0, 0);
       }
       if (MAXMODE == 0) asm volatile("" : "+v"(sacc[1]) : "v"(cinit), "v"(ka[0][0]), "v"(ka[1][0]), "v"(qf[0]));
-      // the 6 reads of one 32-key block's V^T fragments and row-sum operands; issued one block ahead of their use, so that
-      // their latency sits under the exponentials (and at most one block's fragments are live)
+      // the 4 reads of one 32-key block's V^T fragments; issued one block ahead of their use, so that their latency sits
+      // under the exponentials (and at most one block's fragments are live)
       PvFrag pv;
       auto read_pv = [&](auto blk_tag) {
         constexpr int B = decltype(blk_tag)::value;
         pv.lo[0] = lds_tr16<VB + (B * 32) * D * 2>(v_addr);
         pv.hi[0] = lds_tr16<VB + (B * 32 + 8) * D * 2>(v_addr);
-        pv.ones[0] = lds_b128<OB + (B * 32) * 2>(o_addr);
         pv.lo[1] = lds_tr16<VB + (B * 32 + 16) * D * 2>(v_addr);
         pv.hi[1] = lds_tr16<VB + (B * 32 + 24) * D * 2>(v_addr);
-        pv.ones[1] = lds_b128<OB + (B * 32 + 16) * 2>(o_addr);
       };
       read_pv(std::integral_constant<int, 0>{});
       if (MAXMODE != 0) {
@@ -369,8 +364,9 @@ __global__ __launch_bounds__(256, 3) void k_attn_partial(AttnParams pin) {
             m_ref += delta;
             const float sc = __builtin_amdgcn_exp2f(-delta);
             ltot *= sc;
+            lrow[0] *= sc; lrow[1] *= sc;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { oacc[r] *= sc; lacc[r] *= sc; cinit[r] -= delta; }
+            for (int r = 0; r < 16; ++r) { oacc[r] *= sc; cinit[r] -= delta; }
 #pragma unroll
             for (int b = 0; b < 2; ++b)
 #pragma unroll
@@ -378,7 +374,9 @@ __global__ __launch_bounds__(256, 3) void k_attn_partial(AttnParams pin) {
           }
         }
       }
-      // P = exp2(S'), packed to e16: the B operand of O^T += V^T . P^T and l += 1^T . P^T (same fragments)
+      // P = exp2(S'), packed to e16: the B operand of O^T += V^T . P^T.  The row sum adds the SAME rounded probabilities: one
+      // v_dot2c_f32 (pair . (1, 1) + acc, full-rate VALU) per packed register -- 16 per tile instead of the 4 "ones"-operand
+      // MFMAs (a third of the matrix pipe's time for no FLOPs) and their 16 accumulator registers
 #pragma unroll
       for (int b = 0; b < 2; ++b) {
         e16x8 pb[2];
@@ -396,9 +394,10 @@ __global__ __launch_bounds__(256, 3) void k_attn_partial(AttnParams pin) {
           const e16x8 a = __builtin_bit_cast(e16x8, a16);
           oacc = RMEM_MFMA_32x32x16(a, pb[sl], oacc, 0, 0, 0);
 #ifndef RMEM_ATTN_ABLATE_L      // timing experiments only (results are then wrong by construction)
-          lacc = RMEM_MFMA_32x32x16(pv.ones[sl], pb[sl], lacc, 0, 0, 0);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) lrow[sl] = rmem_dot2(e16x2{pb[sl][2 * j], pb[sl][2 * j + 1]}, one2, lrow[sl]);
 #else
-          lacc[0] += (float)pb[sl][0];
+          lrow[sl] += (float)pb[sl][0];
 #endif
         }
         if (b == 0) read_pv(std::integral_constant<int, 1>{});
@@ -422,12 +421,23 @@ __global__ __launch_bounds__(256, 3) void k_attn_partial(AttnParams pin) {
       if (wave_active) tile(mode_tag, buf_tag);
       if (last_in_row) {
         if (wave_active) {
+          float lr = lrow[0] + lrow[1];
+          const int valid = cur.kn - t * KT;             // keys of the row's last tile that exist (workgroup-uniform)
+          if (valid < KT) {
+            // the padded keys of the ragged tile all scored exactly S' = cinit (K = 0), i.e. each added the same e16-rounded
+            // 2^cinit to the sum: take this lane's share out (its keys are 32b + 8g + 4h + 0..3 of the tile)
+            int npad = 0;
+#pragma unroll
+            for (int g8 = 0; g8 < 8; ++g8) npad += min(4, max(0, 8 * g8 + 4 * lh + 4 - valid));
+            lr -= (float)npad * (float)(e16)__builtin_amdgcn_exp2f(cinit[0]);
+          }
+          lr += __shfl_xor(lr, 32, 64);                  // + the other half of the keys
+          if (cur.kn <= 0) lr = 0.f;                     // an empty row has no mass, exactly
           // the row's own (reference, sum): all the mass output needs; the running total keeps the group's normaliser
           if (p.ml != nullptr && lh == 0 && qg < p.Lq)
-            *reinterpret_cast<f32x2*>(p.ml + (((long)c * p.heads + head) * p.Lq + qg) * 2) = f32x2{m_ref, lacc[0]};
-          ltot += lacc[0];
-#pragma unroll
-          for (int r = 0; r < 16; ++r) lacc[r] = 0.f;
+            *reinterpret_cast<f32x2*>(p.ml + (((long)c * p.heads + head) * p.Lq + qg) * 2) = f32x2{m_ref, lr};
+          ltot += lr;
+          lrow[0] = 0.f; lrow[1] = 0.f;
         }
         if (last) return true;
         ++c; cur = row_info(c); t = 0;

@@ -24,6 +24,16 @@ typedef __attribute__((ext_vector_type(2))) e16 e16x2;
 typedef __attribute__((ext_vector_type(4))) e16 e16x4;
 typedef __attribute__((ext_vector_type(8))) e16 e16x8;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
+// a.x * b.x + a.y * b.y + c in fp32 (v_dot2c_f32_bf16 / v_dot2c_f32_f16): one full-rate VALU instruction per 16-bit pair
+__device__ __forceinline__ float rmem_dot2(e16x2 a, e16x2 b, float c) {
+#if !defined(__HIP_DEVICE_COMPILE__)
+  return c;
+#elif defined(RMEM_F16)
+  return __builtin_amdgcn_fdot2(a, b, c, false);
+#else
+  return __builtin_amdgcn_fdot2_f32_bf16(a, b, c, false);
+#endif
+}
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 

@@ -31,10 +31,15 @@ from .runtime import BF16, D_MODEL, F32, FFN, HEADS, MAX_CHUNKS, PLAIN_CHUNKS, _
 
 
 class GroupRuntime:
+    deaot = False
+    max_rows = MAX_CHUNKS                 # key-table rows per clip
+    bank_kw = bank_vw = D_MODEL           # widths of a bank entry's key / value rows
+    dec_cin = 4 * D_MODEL                 # columns of the decoder's LSTT input
+
     def __init__(self, P: Dict[str, torch.Tensor], in_hw: Tuple[int, int], bank_slots: int, device, clips: int,
                  num_lstt: int = 3, align_corners: bool = True, num_classes: int = 11, lookahead: int = 4):
-        if 'pe.w' in P or 'g0.qvu.w' in P:
-            raise ops.RmemError('GroupRuntime covers the R50-AOTL path')
+        if 'pe.w' in P or ('g0.qvu.w' in P) != self.deaot:
+            raise ops.RmemError('GroupRuntime covers the R50-AOTL path, group_runtime_deaot.GroupRuntimeDeAOT the R50-DeAOTL path')
         self.P, self.dev, self.NL, self.B = P, device, num_lstt, clips
         self.dt = P['proj.w'].dtype
         self.align, self.nc = align_corners, num_classes
@@ -55,8 +60,37 @@ class GroupRuntime:
         self.enc_ahead = BatchEncoder(P, in_hw, B * lookahead, device) if lookahead > 1 else None
         # ---- LSTT buffers, [B * L, .] clip-major ----
         R = B * L
+        self.dec_in = e(R, self.dec_cin)
+        self.id_emb = e(R, D_MODEL)
+        self.onehot = e(B * H * W, 16)
+        self._alloc_lstt(R, num_lstt)
+        self.gn_ws = ops.groupnorm_workspace(32, device, images=B)
+        self.conv_ws = torch.empty(16 * R * D_MODEL, dtype=F32, device=device)
+        self.mass = torch.zeros(B * L * MAX_CHUNKS, dtype=F32, device=device)          # [B][L][T] compact for the current T
+        self.scores = torch.zeros(B, 32 + 64 * 32, dtype=F32, device=device)
+        self.scores_host = torch.zeros(B, MAX_CHUNKS, dtype=F32).pin_memory()
+        # ---- decoder buffers ----
+        self.d16a, self.d16b = e(R, 256), e(R, 256)
+        self.d8a, self.d8b = e(B * M8, 256), e(B * M8, 256)
+        self.d4a, self.d4b = e(B * M4, 128), e(B * M4, 128)
+        self.logits = torch.zeros(B * M4, 16, dtype=F32, device=device)
+        # ---- memory bank: [B * S, L, width] per layer, clip c owns slots c * S .. ----
+        self.S = bank_slots
+        self.bank_K = [e(B * bank_slots, L, self.bank_kw) for _ in range(num_lstt)]
+        self.bank_V = [e(B * bank_slots, L, self.bank_vw) for _ in range(num_lstt)]
+        self.slots: List[List[int]] = [[] for _ in range(B)]            # per clip: logical order t -> local slot
+        self.free: List[List[int]] = [list(range(bank_slots)) for _ in range(B)]
+        self.chunks = torch.zeros(B * self.max_rows, 8, dtype=torch.int32, device=device)
+        self.chunks_ring = ops.PinnedRing(4, (B * self.max_rows, 8), torch.int32, device)
+        self.append_slots = torch.full((B,), -1, dtype=torch.int32, device=device)   # global destination slot per clip
+        self.append_ring = ops.PinnedRing(4, (B,), torch.int32, device)
+        self._prog: Dict[str, list] = {}
+
+    def _alloc_lstt(self, R: int, num_lstt: int):
+        """LSTT activations, [B * L, .] clip-major."""
+        device, L, B = self.dev, self.L, self.B
+        e = lambda *shape, dt=None: torch.empty(*shape, dtype=dt or self.dt, device=device)  # noqa: E731
         self.x = e(R, D_MODEL, dt=F32)
-        self.dec_in = e(R, 4 * D_MODEL)
         self.t1b = e(R, D_MODEL)
         self.qkv = e(R, 3 * D_MODEL)
         self.att = e(R, D_MODEL)
@@ -71,34 +105,11 @@ class GroupRuntime:
         self.short_V = [e(R, D_MODEL) for _ in range(num_lstt)]
         self.tmpA = [e(R, D_MODEL) for _ in range(num_lstt)]
         self.tmpB = [e(R, D_MODEL) for _ in range(num_lstt)]
-        self.id_emb = e(R, D_MODEL)
-        self.onehot = e(B * H * W, 16)
         pos = sine_pos_emb(self.H16, self.W16).to(device)
         self.posb = pos.to(self.dt).repeat(B, 1).contiguous()
         self.pos_qk = [torch.zeros(R, 3 * D_MODEL, dtype=F32, device=device) for _ in range(num_lstt)]
         self._pos_ready = False
         self.attn_ws = ops.attn_workspace(L, HEADS, MAX_CHUNKS, device, nclips=B)
-        self.gn_ws = ops.groupnorm_workspace(32, device, images=B)
-        self.conv_ws = torch.empty(16 * R * D_MODEL, dtype=F32, device=device)
-        self.mass = torch.zeros(B * L * MAX_CHUNKS, dtype=F32, device=device)          # [B][L][T] compact for the current T
-        self.scores = torch.zeros(B, 32 + 64 * 32, dtype=F32, device=device)
-        self.scores_host = torch.zeros(B, MAX_CHUNKS, dtype=F32).pin_memory()
-        # ---- decoder buffers ----
-        self.d16a, self.d16b = e(R, 256), e(R, 256)
-        self.d8a, self.d8b = e(B * M8, 256), e(B * M8, 256)
-        self.d4a, self.d4b = e(B * M4, 128), e(B * M4, 128)
-        self.logits = torch.zeros(B * M4, 16, dtype=F32, device=device)
-        # ---- memory bank: [B * S, L, 256] per layer, clip c owns slots c * S .. ----
-        self.S = bank_slots
-        self.bank_K = [e(B * bank_slots, L, D_MODEL) for _ in range(num_lstt)]
-        self.bank_V = [e(B * bank_slots, L, D_MODEL) for _ in range(num_lstt)]
-        self.slots: List[List[int]] = [[] for _ in range(B)]            # per clip: logical order t -> local slot
-        self.free: List[List[int]] = [list(range(bank_slots)) for _ in range(B)]
-        self.chunks = torch.zeros(B * MAX_CHUNKS, 8, dtype=torch.int32, device=device)
-        self.chunks_ring = ops.PinnedRing(4, (B * MAX_CHUNKS, 8), torch.int32, device)
-        self.append_slots = torch.full((B,), -1, dtype=torch.int32, device=device)   # global destination slot per clip
-        self.append_ring = ops.PinnedRing(4, (B,), torch.int32, device)
-        self._prog: Dict[str, list] = {}
 
     # ------------------------------------------------------------------ bank bookkeeping (host) + device tables
     def reset_bank(self):
@@ -117,6 +128,9 @@ class GroupRuntime:
         splits = max(1, min(8 // T, MAX_CHUNKS // T))
         return splits, T * splits
 
+    def _keys_per_chunk(self, splits: int) -> int:
+        return (self.L + splits - 1) // splits
+
     def _chunk_rows(self, slots: List[List[int]]):
         """Chunk-table rows (global slot, key begin, key count, temporal-PE slot, t), one block of n rows per clip, for per-clip slot
         orders.  Banks may differ in length: the block is laid out for the longest one (same key split for every clip), a shorter
@@ -124,7 +138,7 @@ class GroupRuntime:
         empty rows (key_count 0), which the kernel reads as zero keys with zero mass."""
         T = max(len(s) for s in slots)
         splits, n = self.chunk_plan(T)
-        per = (self.L + splits - 1) // splits
+        per = self._keys_per_chunk(splits)
         rows = []
         for c in range(self.B):
             pes = temporal_slots(len(slots[c]))
@@ -268,7 +282,7 @@ class GroupRuntime:
                                                     images=B)
         lin = lambda x, name, y, M, K, N, **kw: ops.conv2d(x, P[name + '.w'], P[name + '.b'], y, H=B * M, W=1, Cin=K, Cout=N,  # noqa: E731
                                                            ws=self.conv_ws, **kw)
-        o.append(lin(self.dec_in, 'dec.conv_in', self.d16a, L, 1024, 256))
+        o.append(lin(self.dec_in, 'dec.conv_in', self.d16a, L, self.dec_cin, 256))
         o.append(gn(self.d16a, 'dec.conv_in', self.d16b, L, 256))
         o.append(lin(enc3, 'dec.adapter_16x', self.d16a, L, 1024, 256, residual=self.d16b))
         o.append(self._conv(self.d16a, P['dec.conv_16x.w'], P['dec.conv_16x.b'], self.d16b, H=self.H16, W=self.W16, Cin=256, Cout=256,

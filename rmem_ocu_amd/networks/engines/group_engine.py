@@ -15,7 +15,9 @@ Covered protocols (the reference's evaluator, managers/evaluator.py:385-523):
     so from then on the clips of a group hold banks of DIFFERENT lengths and append at different frames.  The launches are laid
     out for the longest bank; shorter ones are padded with empty key-table rows (include/rmem.h: key_count 0), and bank appends
     go through the per-clip destination table (negative = no append for this clip).
-DeAOT, Swin and > 10 objects run on the per-clip engines, which are the drop-in API.
+R50-DeAOTL models run through group_runtime_deaot.GroupRuntimeDeAOT (same protocol; the eviction policy's scores and visit
+counts then move on EVERY long-term update, deaot_engine.py / transformer.py:880-892; no mid-clip reference frames there).
+Swin and > 10 objects run on the per-clip engines, which are the drop-in API.
 """
 from __future__ import annotations
 
@@ -25,6 +27,7 @@ import torch
 
 from ... import ops
 from ...group_runtime import GroupRuntime
+from ...group_runtime_deaot import GroupRuntimeDeAOT
 from ...runtime import MAX_CHUNKS, ClipRuntime
 from .aot_engine import MemoryPolicy
 
@@ -36,6 +39,8 @@ class GroupEngine:
         self.cfg = aot_model.cfg
         self.AOT = aot_model
         self.B = clips
+        self.deaot = self.cfg.MODEL_VOS == 'deaot'
+        self.policy_every_update = self.deaot      # DeAOTEngine.policy_every_update
         self.gpu_id = gpu_id
         self.device = torch.device('cuda', gpu_id)
         self.align_corners = self.cfg.MODEL_ALIGN_CORNERS
@@ -80,8 +85,9 @@ class GroupEngine:
         # +1: a restricted bank holds N + 1 entries between append and eviction; unbounded: as many as the key table has rows
         slots = n + 1 if n < MAX_CHUNKS else MAX_CHUNKS
         if self.rt is None or (self.rt.H, self.rt.W) != (H, W) or self.rt.S != slots:
-            self.rt = GroupRuntime(self.AOT.packed(), (H, W), slots, self.device, self.B, self.cfg.MODEL_LSTT_NUM, self.align_corners,
-                                   self.max_obj_num + 1, self.lookahead)
+            cls = GroupRuntimeDeAOT if self.deaot else GroupRuntime
+            self.rt = cls(self.AOT.packed(), (H, W), slots, self.device, self.B, self.cfg.MODEL_LSTT_NUM, self.align_corners,
+                          self.max_obj_num + 1, self.lookahead)
             self.label_in = torch.empty(self.B, H, W, dtype=F32, device=self.device)
             self._graphs = {}
             self._side = None
@@ -135,6 +141,8 @@ class GroupEngine:
         memory, the clip's long-term schedule restarts here, ``long_memories_indexes`` keeps growing (the reference's quirk, 323),
         the eviction policy's state is reset (init_memory, transformer.py:438-443)."""
         rt, c = self.rt, clip
+        if self.deaot:
+            raise NotImplementedError('mid-clip reference frames of DeAOT clips run on the per-clip engine (DeAOTInferEngine)')
         self._resolve_pending()
         if self._side is None:
             self._side = ClipRuntime(self.AOT.packed(), (rt.H, rt.W), 1, self.device, self.cfg.MODEL_LSTT_NUM, self.align_corners,
@@ -181,8 +189,9 @@ class GroupEngine:
 
     def _mass_needed(self) -> bool:
         """The attention mass of layer 0 is only read by the eviction policy: needed iff the update after this propagation appends
-        to some clip's bank and overflows it."""
-        need = any(self._will_append(c) and len(self.rt.slots[c]) + 1 > self.n_keep for c in range(self.B))
+        to some clip's bank and overflows it (DeAOT: appends at all)."""
+        need = any(self._will_append(c) and (self.policy_every_update or len(self.rt.slots[c]) + 1 > self.n_keep)
+                   for c in range(self.B))
         self._mass_valid = need
         return need
 
@@ -232,38 +241,42 @@ class GroupEngine:
             self._run(f'upd{int(any(appends))}_{labels_u8.data_ptr()}', rt.prog_id_emb(labels_u8, hs, ws) + rt.prog_update(any(appends)))
             if not any(appends):
                 return
-            over = []
+            scored, over = [], set()            # clips whose policy state moves / whose bank overflows
             for c in range(B):
                 if appends[c]:
                     self.last_mem_step[c] = self.frame_step
                     rt.slots[c].append(new_slots[c])
                     self._indexes[c].append(self.frame_step)
                     if len(rt.slots[c]) > self.n_keep:
-                        over.append(c)
-            if over:
+                        over.add(c)
+                    if c in over or self.policy_every_update:
+                        scored.append(c)
+            if scored:
                 if not self._mass_valid:
                     raise RuntimeError('long_term_mem_gap changed between propagate and update: attention mass not recorded')
                 Tp, L = self._T_at_propagate, rt.L
                 ops.run([ops.evict_scores(rt.logits[c * rt.M4:(c + 1) * rt.M4], rt.mass[c * L * Tp:(c + 1) * L * Tp], rt.scores[c],
                                           ldl=16, nc=rt.nc, keep=self.obj_nums[0], Hi=rt.H4, Wi=rt.W4, He=rt.H16, We=rt.W16, T=Tp)
-                         for c in over], s)
-                for c in over:
+                         for c in scored], s)
+                for c in scored:
                     ops.copy_async(rt.scores_host[c], rt.scores[c], 4 * Tp)(s)
                 ev = torch.cuda.Event()
                 ev.record(self.stream)
-                self._pending = (ev, over, list(self._Tc_at_propagate))
+                self._pending = (ev, scored, over, list(self._Tc_at_propagate))
             else:
                 rt.upload_chunks(s)
 
     def _resolve_pending(self):
         if self._pending is None:
             return
-        ev, over, tc = self._pending
+        ev, scored, over, tc = self._pending
         self._pending = None
         ev.synchronize()
         rt = self.rt
-        for c in over:
+        for c in scored:
             drop = self.policies[c].choose(rt.scores_host[c, :tc[c]].clone(), self._indexes[c])
+            if c not in over:                 # DeAOT: the scores moved, nothing is dropped yet
+                continue
             self.drop_trace[c].append(drop)
             rt.free[c].append(rt.slots[c].pop(drop))
             del self._indexes[c][drop]

@@ -12,8 +12,11 @@ from typing import Dict
 
 import torch
 
+import threading
+
 BN_EPS = 1e-5
-_DT = torch.bfloat16          # element type of the pack in progress (set by pack_state_dict)
+_DT = torch.bfloat16          # element type of the pack in progress (set by pack_state_dict, under _PACK_LOCK)
+_PACK_LOCK = threading.Lock()
 R50_BLOCKS = (3, 4, 6)
 R50_STRIDES = (1, 2, 2)
 
@@ -116,11 +119,12 @@ def pack_state_dict(sd: Dict[str, torch.Tensor], device, num_lstt: int = 3, dtyp
     global _DT
     if dtype not in (torch.bfloat16, torch.float16):
         raise ValueError(f'pack_state_dict: dtype must be torch.bfloat16 or torch.float16, got {dtype}')
-    _DT = dtype
-    try:
-        return _pack_state_dict(sd, device, num_lstt)
-    finally:
-        _DT = torch.bfloat16          # the helpers of this module pack bfloat16 unless told otherwise
+    with _PACK_LOCK:                  # the helpers below read the element type from the module: one pack at a time
+        _DT = dtype
+        try:
+            return _pack_state_dict(sd, device, num_lstt)
+        finally:
+            _DT = torch.bfloat16      # the helpers of this module pack bfloat16 unless told otherwise
 
 
 def _pack_state_dict(sd: Dict[str, torch.Tensor], device, num_lstt: int) -> Dict[str, torch.Tensor]:

@@ -80,3 +80,47 @@ def test_deaot_small_clip_teacher_forced_fp16():
     print('deaot fp16 teacher-forced: max |dlogit| =', err, ' logit std =', ref.std(), ' label agreement =', (labels == g['labels']).mean())
     assert err < 0.012 * ref.std() + 0.003, err
     assert (_trace_matrix(trace, g['indexes']) == g['indexes']).all()
+
+
+def test_deaot_group_engine_matches_per_clip_engines():
+    """Throughput mode of the DeAOT path: three clips in lockstep on one GroupEngine (group_runtime_deaot: batched GEMMs / norms /
+    decoder, per-clip gated attentions, scattered bank appends, eviction-policy state moving on every long-term update) deliver the
+    masks and eviction traces of three per-clip DeAOT engines."""
+    from rmem_ocu_amd import build_vos_model, get_config
+    from rmem_ocu_amd.clip_runner import ClipSlot, GroupSlot
+    from rmem_ocu_amd.networks.engines.group_engine import GroupEngine
+    from rmem_ocu_amd.synth import make_clip
+    from rmem_ocu_amd.weights import synth_state_dict
+    from test_hip_engine import _engine
+    dev = torch.device('cuda', 0)
+    B, n = 3, 26
+    clips = [make_clip(60 + c, n, 161, 193, 3) for c in range(B)]
+    ref_labels, ref_traces = [], []
+    for f, m in clips:
+        eng = _engine(1, 2, 5, model_name='r50_deaotl')
+        eng.set_async(use_graphs=True)
+        slot = ClipSlot(eng, (160, 192), dev, lookahead=4)
+        slot.start(f.to(dev), m.to(dev), 3)
+        while not slot.done:
+            slot.step()
+        eng.synchronize()
+        ref_labels.append(slot.labels[:n].cpu().numpy().copy())
+        ref_traces.append((list(eng.long_memories_indexes), list(eng.aot_engines[0].drop_trace)))
+    cfg = get_config('pre_vost', 'test', 'r50_deaotl')
+    cfg.FORMER_MEM_LEN, cfg.LATTER_MEM_LEN = 1, 2
+    model = build_vos_model(cfg.MODEL_VOS, cfg).cuda(0)
+    model.load_state_dict(synth_state_dict(0, model='deaot'))
+    ge = GroupEngine(model, B, 0, 5, lookahead=4)
+    gs = GroupSlot(ge, (160, 192), dev)
+    gs.start([f.to(dev) for f, _ in clips], [m.to(dev) for _, m in clips], 3)
+    while not gs.done:
+        gs.step()
+    ge.synchronize()
+    got = gs.labels[:, :n].cpu().numpy()
+    for c in range(B):
+        agree = (got[c][1:] == ref_labels[c][1:]).mean()
+        print(f'deaot clip {c}: label agreement {agree:.5f}, indexes {ge.long_memories_indexes(c)}, drops {ge.drop_trace[c]}')
+        assert agree > 0.995
+        assert (ge.long_memories_indexes(c), ge.drop_trace[c]) == ref_traces[c]
+    with pytest.raises(NotImplementedError):
+        ge.add_reference_frame_for(0, clips[0][0][3].to(dev), gs.cur_label[0])
