@@ -134,6 +134,15 @@ __device__ __forceinline__ void lds_wait_pv(PvFrag& f) {
   asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(f.lo[0]), "+v"(f.hi[0]), "+v"(f.lo[1]), "+v"(f.hi[1]) : "n"(N));
 }
 
+#ifdef RMEM_ATTN_TIMELINE
+// Measurement build only (scripts/build_attn_variants.sh timeline=-DRMEM_ATTN_TIMELINE): wave 0 of every workgroup reads the
+// shader clock at four points of every tile and sums the phases; rmem_attn_timeline_read() returns the sums.
+//   A: barrier left -> K fragments in registers      B: -> first exponential issued (S^T out of the matrix pipe)
+//   C: -> last row-sum instruction issued            D: -> next barrier left (scalar work, DMA issue, vmcnt wait, barrier wait)
+__device__ unsigned g_attn_timeline[8192 * 8];
+#define RMEM_TL_STAMP(var, tie) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var), "+v"(tie))
+#endif
+
 // MEM = true: memory-read flavour (row table, temporal PE); false: one plain key frame cut into nchunks ranges.  Two
 // symbols so a kernel trace separates the long-term memory read from the short-term / self attention launches.
 // TIMED changes nothing but the symbol: launches bracketed by rmem_profile_* HIP events use the <true, true> instance, so
@@ -208,6 +217,9 @@ __global__ __launch_bounds__(256, RMEM_ATTN_WGS_PER_CU) void k_attn_partial(Attn
   auto row_bias = [&](int pe_slot) -> float {
     float bias = 0.f;
     if (MEM && pe_slot >= 0 && p.pe_mem != nullptr) {     // workgroup-uniform
+      // (the fragments pass through an empty asm so that their 16 fp32 conversions are redone here, once per row, instead of
+      // being hoisted into 16 registers that stay live across the whole tile loop)
+      asm volatile("" : "+v"(qf[0]), "+v"(qf[1]));
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         const float* pm = p.pe_mem + pe_slot * p.C + head * D + 16 * s + 8 * lh;
@@ -247,8 +259,10 @@ __global__ __launch_bounds__(256, RMEM_ATTN_WGS_PER_CU) void k_attn_partial(Attn
     constexpr int BUF = decltype(buf_tag)::value;
     if (dc >= c1) return false;
     const int left = row_bytes - dt * tile_elems * 2;
+#ifndef RMEM_ATTN_ABLATE_DMA        // timing experiments only
     buf_load_lds16(make_rsrc(row_k + (long)dt * tile_elems, left), (lptr_t)&Ks[BUF][wave * 16 * D], voff_k, 0);
     buf_load_lds16(make_rsrc(row_v + (long)dt * tile_elems, left), (lptr_t)&Vs[BUF][wave * 16 * D], voff_v, 0);
+#endif
     if (++dt >= dnt) {
       if (dc + 1 < c1) open_row(dc + 1);
       else dc = c1;
@@ -270,6 +284,10 @@ __global__ __launch_bounds__(256, RMEM_ATTN_WGS_PER_CU) void k_attn_partial(Attn
 
   f32x16 oacc;
   float m_ref, ltot;
+#ifdef RMEM_ATTN_TIMELINE
+  unsigned long long tl_t0 = 0, tl_t1 = 0, tl_t2 = 0, tl_t3 = 0;
+  unsigned tl_a = 0, tl_b = 0, tl_c = 0, tl_d = 0, tl_n = 0;
+#endif
 
   // One pass over the group's rows.  SAFE = false: m_ref is the first tile's maximum and stays; true: online softmax.
   auto walk = [&](auto safe_tag) {
@@ -313,11 +331,19 @@ __global__ __launch_bounds__(256, RMEM_ATTN_WGS_PER_CU) void k_attn_partial(Attn
       // S'^T = K . Q^T + (bias - m_ref) for the two 32-key blocks of this tile
       constexpr int KB = BUF * KT * D * 2, VB = BUF * KT * D * 2;      // byte offsets of the ring slot
       e16x8 ka[2][2];
+#ifndef RMEM_ATTN_ABLATE_KREAD      // timing experiments only
       ka[0][0] = lds_b128<KB>(k_addr[0]);
       ka[0][1] = lds_b128<KB>(k_addr[1]);
       ka[1][0] = lds_b128<KB + 32 * D * 2>(k_addr[0]);
       ka[1][1] = lds_b128<KB + 32 * D * 2>(k_addr[1]);
       lds_wait4<0>(ka[0][0], ka[0][1], ka[1][0], ka[1][1]);
+#ifdef RMEM_ATTN_TIMELINE
+      RMEM_TL_STAMP(tl_t1, ka[1][1]);
+#endif
+#else
+      ka[0][0] = qf[0]; ka[0][1] = qf[1]; ka[1][0] = qf[1]; ka[1][1] = qf[0];
+      asm volatile("" : "+v"(ka[0][0]), "+v"(ka[0][1]), "+v"(ka[1][0]), "+v"(ka[1][1]));
+#endif
       f32x16 sacc[2];
 #pragma unroll
       for (int b = 0; b < 2; ++b) {
@@ -337,6 +363,10 @@ __global__ __launch_bounds__(256, RMEM_ATTN_WGS_PER_CU) void k_attn_partial(Attn
       PvFrag pv;
       auto read_pv = [&](auto blk_tag) {
         constexpr int B = decltype(blk_tag)::value;
+#ifdef RMEM_ATTN_ABLATE_VREAD       // timing experiments only
+        asm volatile("" : "=v"(pv.lo[0]), "=v"(pv.hi[0]), "=v"(pv.lo[1]), "=v"(pv.hi[1]));
+        return;
+#endif
         pv.lo[0] = lds_tr16<VB + (B * 32) * D * 2>(v_addr);
         pv.hi[0] = lds_tr16<VB + (B * 32 + 8) * D * 2>(v_addr);
         pv.lo[1] = lds_tr16<VB + (B * 32 + 16) * D * 2>(v_addr);
@@ -382,17 +412,29 @@ __global__ __launch_bounds__(256, RMEM_ATTN_WGS_PER_CU) void k_attn_partial(Attn
         e16x8 pb[2];
 #pragma unroll
 #ifndef RMEM_ATTN_ABLATE_EXP
-        for (int r = 0; r < 16; ++r) pb[r >> 3][r & 7] = (e16)__builtin_amdgcn_exp2f(sacc[b][r]);
+        for (int r = 0; r < 16; ++r) {
+          float ev = __builtin_amdgcn_exp2f(sacc[b][r]);
+#ifdef RMEM_ATTN_TIMELINE
+          if (b == 0 && r == 0) RMEM_TL_STAMP(tl_t2, ev);
+#endif
+          pb[r >> 3][r & 7] = (e16)ev;
+        }
 #else
         for (int r = 0; r < 16; ++r) pb[r >> 3][r & 7] = (e16)(sacc[b][r]);
 #endif
+#ifndef RMEM_ATTN_ABLATE_VREAD
         lds_wait_pv<0>(pv);
+#endif
 #pragma unroll
         for (int sl = 0; sl < 2; ++sl) {
           const __attribute__((ext_vector_type(8))) short a16 = {pv.lo[sl][0], pv.lo[sl][1], pv.lo[sl][2], pv.lo[sl][3],
                                                                  pv.hi[sl][0], pv.hi[sl][1], pv.hi[sl][2], pv.hi[sl][3]};
           const e16x8 a = __builtin_bit_cast(e16x8, a16);
+#ifndef RMEM_ATTN_ABLATE_PV         // timing experiments only
           oacc = RMEM_MFMA_32x32x16(a, pb[sl], oacc, 0, 0, 0);
+#else
+          oacc[sl] += (float)pb[sl][1] * (float)a[0];
+#endif
 #ifndef RMEM_ATTN_ABLATE_L      // timing experiments only (results are then wrong by construction)
 #pragma unroll
           for (int j = 0; j < 4; ++j) lrow[sl] = rmem_dot2(e16x2{pb[sl][2 * j], pb[sl][2 * j + 1]}, one2, lrow[sl]);
@@ -402,6 +444,10 @@ __global__ __launch_bounds__(256, RMEM_ATTN_WGS_PER_CU) void k_attn_partial(Attn
         }
         if (b == 0) read_pv(std::integral_constant<int, 1>{});
       }
+#ifdef RMEM_ATTN_TIMELINE
+      RMEM_TL_STAMP(tl_t3, lrow[1]);
+      tl_a += (unsigned)(tl_t1 - tl_t0); tl_b += (unsigned)(tl_t2 - tl_t1); tl_c += (unsigned)(tl_t3 - tl_t2); ++tl_n;
+#endif
     };
 
     // One loop step on ring slot BUF.  The slot's tile was issued three steps ago; with the DMA cursor still running exactly
@@ -413,7 +459,18 @@ __global__ __launch_bounds__(256, RMEM_ATTN_WGS_PER_CU) void k_attn_partial(Attn
       if (more) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifndef RMEM_ATTN_ABLATE_BARRIER
-      __syncthreads();
+      // a bare s_barrier: __syncthreads() is fence + barrier, and the fence drains EVERY LDS-DMA in flight (s_waitcnt vmcnt(0)
+      // in front of the barrier) -- the two younger tiles included, which turns the ring into "load, wait, compute".  What the
+      // barrier has to order here is covered by the counted waits: this wave's share of the tile has landed (vmcnt above), and
+      // its LDS reads of the previous tile were waited for (lgkmcnt) before the MFMAs that consumed them.
+      asm volatile("s_barrier" ::: "memory");
+#endif
+#ifdef RMEM_ATTN_TIMELINE
+      {
+        const unsigned long long prev = tl_t3;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tl_t0));
+        if (prev) tl_d += (unsigned)(tl_t0 - prev);
+      }
 #endif
       if (more) more = dma_next(std::integral_constant<int, (BUF + NB - 1) % NB>{});
       const bool last_in_row = t + 1 >= ntiles;
@@ -471,7 +528,15 @@ __global__ __launch_bounds__(256, RMEM_ATTN_WGS_PER_CU) void k_attn_partial(Attn
   walk(std::false_type{});
   // any query of the workgroup whose sums left the safe range sends the whole group through the online-softmax pass
   // (the vote is also the barrier that frees the LDS tiles for it)
+#ifndef RMEM_ATTN_ABLATE_FALLBACK     // timing experiments only (their garbage operands must not send every group through both passes)
   if (__syncthreads_or(wave_active && !(ltot <= L_LIMIT))) walk(std::true_type{});
+#endif
+#endif
+#ifdef RMEM_ATTN_TIMELINE
+  if (tid == 0 && blockIdx.x < 8192) {
+    unsigned* o = g_attn_timeline + blockIdx.x * 8;
+    o[0] = tl_a; o[1] = tl_b; o[2] = tl_c; o[3] = tl_d; o[4] = tl_n;
+  }
 #endif
   if (!wave_active) return;
 
@@ -585,6 +650,21 @@ __global__ __launch_bounds__(256) void k_attn_mass(CombineParams pin) {
 extern "C" size_t rmem_attn_workspace_bytes(int Lq, int heads, int nchunks) {
   // worst case one group per table row: partial O (D floats) + group (m, l) + row (m, l) per (row, head, query)
   return (size_t)nchunks * heads * Lq * (D + 4) * sizeof(float);
+}
+#endif
+
+#if defined(RMEM_ATTN_TIMELINE) && !defined(RMEM_F16)
+// out[0..4] = mean over the first nwg workgroups of (A, B, C, D) cycles per tile and tiles per workgroup (measurement build only)
+extern "C" int rmem_attn_timeline_read(double* out, int nwg) {
+  static unsigned host[8192 * 8];
+  if (nwg > 8192) nwg = 8192;
+  if (hipDeviceSynchronize() != hipSuccess) return 1;
+  if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_attn_timeline), sizeof(unsigned) * 8 * nwg) != hipSuccess) return 2;
+  double s[5] = {0, 0, 0, 0, 0};
+  for (int i = 0; i < nwg; ++i) for (int j = 0; j < 5; ++j) s[j] += host[i * 8 + j];
+  for (int j = 0; j < 4; ++j) out[j] = s[4] > 0 ? s[j] / s[4] : 0;
+  out[4] = s[4] / nwg;
+  return 0;
 }
 #endif
 

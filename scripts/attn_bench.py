@@ -65,6 +65,15 @@ def main():
             med = ts[len(ts) // 2]
             print(f'T={T} clips={B} rows={n} target_wgs={w:>8s}: median {med:8.1f} us  min {ts[0]:8.1f} us  '
                   f'{flops / med / 1e6:7.1f} TFLOP/s (all launches of the call: attention + combine + mass)', flush=True)
+            from rmem_ocu_amd import _lib
+            L = _lib.lib()
+            if hasattr(L, 'rmem_attn_timeline_read'):       # measurement build (scripts/build_attn_variants.sh timeline=...)
+                import ctypes
+                buf = (ctypes.c_double * 5)()
+                L.rmem_attn_timeline_read.restype = ctypes.c_int
+                rc = L.rmem_attn_timeline_read(buf, 1792)
+                print(f'  timeline (cycles per tile, wave 0 of each workgroup; rc {rc}): LDS-K wait {buf[0]:.0f}  QK->first exp {buf[1]:.0f}  '
+                      f'exp/PV/sum {buf[2]:.0f}  scalar+DMA+barrier {buf[3]:.0f}  total {sum(buf[:4]):.0f}   tiles/WG {buf[4]:.1f}', flush=True)
 
 
 if __name__ == '__main__':
