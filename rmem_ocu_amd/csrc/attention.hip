@@ -155,8 +155,8 @@ __global__ __launch_bounds__(256, RMEM_ATTN_WGS_PER_CU) void k_attn_partial(Attn
   AttnParams p = pin;
   __shared__ __attribute__((aligned(16))) e16 Ks[NB][KT * D];  // ring of NB tiles: [key][32], 16-byte chunks XOR-swizzled
   __shared__ __attribute__((aligned(16))) e16 Vs[NB][KT * D];  // [key][32] row-major, read transposed (ds_read_b64_tr_b16)
-  // A row's ragged last tile (HW = 1674 = 26 * 64 + 10) is padded with K = V = 0 keys (the DMA's range check); they add
-  // nothing to O, and what they add to the row sum is known exactly (see the row end in step()).
+  // A row's ragged last tile (HW = 1674 = 26 * 64 + 10) is padded with K = V = 0 keys (the DMA's range check); their scores
+  // are overwritten with -1e30 in that tile only (P = 0 exactly: no part in the maximum, the row sum or O).
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // provably wave-uniform: LDS-DMA destinations stay in SGPRs
@@ -323,9 +323,8 @@ __global__ __launch_bounds__(256, RMEM_ATTN_WGS_PER_CU) void k_attn_partial(Attn
     // first tile (m_ref := tile maximum, nothing accumulated yet); 2: SAFE pass (move m_ref and rescale when a tile exceeds
     // it by 2^8).  The FAST steady state must not carry any of the extras: predicated off they are if-converted into ~60
     // subtractions / maxima per tile, which is exactly the VALU work this kernel cannot afford -- hence one copy per
-    // MAXMODE.  Padded keys of a ragged tile score exactly S' = bias - m_ref (K = 0): a finite P that meets V = 0; the row sum
-    // counts them and the row end takes them out again.
-    auto tile = [&](auto mode_tag, auto buf_tag) {
+    // MAXMODE.  ``valid`` = keys of this tile that exist (workgroup-uniform); only a row's last tile has fewer than KT.
+    auto tile = [&](auto mode_tag, auto buf_tag, int valid) {
       constexpr int MAXMODE = decltype(mode_tag)::value;
       constexpr int BUF = decltype(buf_tag)::value;
       // S'^T = K . Q^T + (bias - m_ref) for the two 32-key blocks of this tile
@@ -358,6 +357,20 @@ __global__ __launch_bounds__(256, RMEM_ATTN_WGS_PER_CU) void k_attn_partial(Attn
         sacc[b] = RMEM_MFMA_32x32x16(ka[b][1], qf[1], sacc[b], 0, 0, 0);
       }
       if (MAXMODE == 0) asm volatile("" : "+v"(sacc[1]) : "v"(cinit), "v"(ka[0][0]), "v"(ka[1][0]), "v"(qf[0]));
+      if (valid < KT) {
+        // ragged tile (one in 27 at HW = 1674), a real branch: the padded keys scored q . 0 + (bias - m_ref), which may lie far
+        // ABOVE every real score (logits of a trained model can all be very negative), so neither "count them and subtract
+        // them again" nor "let them meet V = 0" is safe -- their scores become -1e30 here.  Register r of block b and lane half
+        // h is key 32 b + 8 (r >> 2) + 4 h + (r & 3).  The empty asm keeps the compiler from if-converting the block into 64
+        // selects that every tile would execute.
+        asm volatile("" : "+v"(sacc[0]), "+v"(sacc[1]));
+        const int lim = valid - 4 * lh;
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (32 * b + 8 * (r >> 2) + (r & 3) >= lim) sacc[b][r] = NEG_BIG;
+      }
       // the 4 reads of one 32-key block's V^T fragments; issued one block ahead of their use, so that their latency sits
       // under the exponentials (and at most one block's fragments are live)
       PvFrag pv;
@@ -380,6 +393,7 @@ __global__ __launch_bounds__(256, RMEM_ATTN_WGS_PER_CU) void k_attn_partial(Attn
         for (int r = 1; r < 16; ++r) tmax = fmaxf(fmaxf(tmax, sacc[0][r]), sacc[1][r]);   // v_max3_f32
         tmax = pair_max(tmax);
         if (MAXMODE == 1) {
+          if (tmax < 0.5f * NEG_BIG) tmax = 0.f;          // the group starts with an empty row: any reference will do
           m_ref = tmax;
 #pragma unroll
           for (int r = 0; r < 16; ++r) cinit[r] -= tmax;
@@ -475,21 +489,11 @@ __global__ __launch_bounds__(256, RMEM_ATTN_WGS_PER_CU) void k_attn_partial(Attn
       if (more) more = dma_next(std::integral_constant<int, (BUF + NB - 1) % NB>{});
       const bool last_in_row = t + 1 >= ntiles;
       const bool last = last_in_row && c + 1 >= c1;
-      if (wave_active) tile(mode_tag, buf_tag);
+      if (wave_active) tile(mode_tag, buf_tag, cur.kn - t * KT);
       if (last_in_row) {
         if (wave_active) {
           float lr = lrow[0] + lrow[1];
-          const int valid = cur.kn - t * KT;             // keys of the row's last tile that exist (workgroup-uniform)
-          if (valid < KT) {
-            // the padded keys of the ragged tile all scored exactly S' = cinit (K = 0), i.e. each added the same e16-rounded
-            // 2^cinit to the sum: take this lane's share out (its keys are 32b + 8g + 4h + 0..3 of the tile)
-            int npad = 0;
-#pragma unroll
-            for (int g8 = 0; g8 < 8; ++g8) npad += min(4, max(0, 8 * g8 + 4 * lh + 4 - valid));
-            lr -= (float)npad * (float)(e16)__builtin_amdgcn_exp2f(cinit[0]);
-          }
           lr += __shfl_xor(lr, 32, 64);                  // + the other half of the keys
-          if (cur.kn <= 0) lr = 0.f;                     // an empty row has no mass, exactly
           // the row's own (reference, sum): all the mass output needs; the running total keeps the group's normaliser
           if (p.ml != nullptr && lh == 0 && qg < p.Lq)
             *reinterpret_cast<f32x2*>(p.ml + (((long)c * p.heads + head) * p.Lq + qg) * 2) = f32x2{m_ref, lr};

@@ -301,6 +301,46 @@ def test_attention_late_dominant_key_takes_safe_pass(dev, synth_weights, wgs):
     assert_close(mass, ref_mass, 2e-2, 'late dominant key: mass')
 
 
+@pytest.mark.parametrize('dtype', ['bf16', 'fp16'])
+@pytest.mark.parametrize('wgs', ['1', '1000000'])
+def test_attention_all_logits_far_below_zero_with_ragged_rows(dev, wgs, dtype):
+    """Every real key scores far BELOW zero (q . k ~ -150 in log2 units: queries and keys point in opposite directions, as the
+    logits of a trained model may), and every row ends in a ragged tile (200 keys = 3 x 64 + 8) plus one EMPTY row: the zero
+    keys the DMA pads a tile with score q . 0 = 0, i.e. 2^150 above everything real.  They must have no part in the maximum,
+    the row sums, the mass or O (the clip of tests/test_hip_engine.py::test_n2_bank_clip is such a case)."""
+    import os
+    from rmem_ocu_amd import ops
+    e16, rnd = (BF16, rb) if dtype == 'bf16' else (F16, rh)
+    T, L, C = 3, 200, 256
+    g = torch.Generator().manual_seed(79)
+    u = torch.nn.functional.normalize(torch.randn(8, 32, generator=g), dim=1).reshape(C)
+    q = rnd(seeded(61, (L, C)) * 0.5 + 24.0 * u)
+    k = rnd(seeded(62, (T, L, C)) * 0.5 - 24.0 * u)
+    v = rnd(seeded(63, (T, L, C)))
+    Qh = (q / 32 ** 0.5).view(L, 8, 32).permute(1, 0, 2)
+    logits = Qh @ k.reshape(T * L, 8, 32).permute(1, 2, 0)
+    assert logits.max().item() < -60.0                    # natural-log units: < -86 in log2
+    attn = torch.softmax(logits, dim=-1)
+    ref = (attn @ v.reshape(T * L, 8, 32).permute(1, 0, 2)).permute(1, 0, 2).reshape(L, C)
+    ref_mass = torch.cat((attn.view(8, L, T, L).mean(0).sum(2), torch.zeros(L, 1)), 1)
+    rows = [(t, 0, L, -1, t) for t in range(T)] + [(0, 0, 0, -1, T)]      # + an empty row (frame T has no keys)
+    chunks = ops.make_chunk_table(rows).to(dev)
+    out = torch.zeros(L, C, dtype=e16, device=dev)
+    mass = torch.zeros(L, T + 1, dtype=F32, device=dev)
+    ws = ops.attn_workspace(L, 8, T + 1, dev)
+    os.environ['RMEM_ATTN_WGS'] = wgs
+    try:
+        ops.run(ops.mem_read_attn(q.to(e16).to(dev), k.to(e16).to(dev), v.to(e16).to(dev), out, ws, Lq=L, ldq=C, ldkv=C, ldo=C,
+                                  slot_stride=L * C, chunks=chunks, nchunks=T + 1, mass=mass, T=T + 1))
+        torch.cuda.synchronize()
+    finally:
+        del os.environ['RMEM_ATTN_WGS']
+    assert torch.isfinite(out.float()).all() and torch.isfinite(mass).all()
+    assert_close(out, ref, 2e-2, 'negative logits, ragged rows')
+    assert_close(mass, ref_mass, 2e-2, 'negative logits, ragged rows: mass')
+    assert mass[:, T].abs().max().item() == 0.0
+
+
 def test_attention_slow_ramp_no_rescale(dev):
     """Lazy-max path: logits that climb a little every tile (below the rescale threshold per step, far above it
     in total), so P is exponentiated against a stale reference for many tiles."""
