@@ -61,7 +61,8 @@ struct AttnParams {
   const float* pe_cur; const float* pe_mem;
   int Lq, heads, C, nq;
   int ngroups, rpg;               // key groups per (query tile, head); table rows per group
-  float* opart; float* mlg;       // per group: unnormalised partial O, (m_ref, l)      (ngroups > 1)
+  float* opart; float* mlg;       // per group: partial O normalised by its own l, stored as e16 (the workspace is sized and
+                                  // strided in floats; half of each block is used), and (m_ref, l) in fp32     (ngroups > 1)
   float* ml;                      // per table row: (m_ref at the row's end, l_row)     (mass output wanted), or null
   float qscale;
   e16* out; int ldo;             // normalised e16 output (written here when ngroups == 1)
@@ -556,12 +557,17 @@ __global__ __launch_bounds__(256, RMEM_ATTN_WGS_PER_CU) void k_attn_partial(Attn
     return;
   }
   if (qg < p.Lq) {
-    // partial O layout [group][head][G = d / 4][q] x float4: a half-wave stores 512 contiguous bytes per instruction
+    // partial O layout [group][head][G = d / 4][q] x e16x4: a half-wave stores 256 contiguous bytes per instruction.  The
+    // partial is normalised by the group's own sum and rounded to e16 -- the merge is a convex combination of the groups, so
+    // this costs one more e16 rounding of the output's own size and halves the bytes the partials write and the merge reads
+    // (they were a quarter of the launch's HBM traffic); the weights (m_ref, l) stay fp32.
     const long ch = (long)g * p.heads + head;
-    f32x4* o = reinterpret_cast<f32x4*>(p.opart) + ch * 8 * p.Lq + qg;
+    const float inv = ltot > 0.f ? 1.f / ltot : 0.f;
+    e16x4* o = reinterpret_cast<e16x4*>(p.opart) + ch * 8 * p.Lq + qg;
 #pragma unroll
     for (int gg = 0; gg < 4; ++gg)  // C/D rows (r&3) + 8(r>>2) + 4h  ->  d = 8g + 4h + (0..3)  ->  G = 2g + h
-      o[(long)(2 * gg + lh) * p.Lq] = f32x4{oacc[4 * gg], oacc[4 * gg + 1], oacc[4 * gg + 2], oacc[4 * gg + 3]};
+      o[(long)(2 * gg + lh) * p.Lq] = e16x4{(e16)(oacc[4 * gg] * inv), (e16)(oacc[4 * gg + 1] * inv), (e16)(oacc[4 * gg + 2] * inv),
+                                            (e16)(oacc[4 * gg + 3] * inv)};
     if (lh == 0) *reinterpret_cast<f32x2*>(p.mlg + (ch * p.Lq + qg) * 2) = f32x2{m_ref, ltot};
   }
 }
@@ -588,7 +594,7 @@ __global__ __launch_bounds__(256) void k_attn_combine(CombineParams pin) {
   const int hg = blockIdx.y * 4 + (tid >> 6);  // 0..63
   const int head = hg >> 3, G = hg & 7;
   if (head < p.heads) {
-    const f32x4* op = reinterpret_cast<const f32x4*>(p.opart);
+    const e16x4* op = reinterpret_cast<const e16x4*>(p.opart);
     float m = NEG_BIG;      // (groups / rows that saw no real key have l = 0: their reference is meaningless and must not set the scale)
     for (int c = 0; c < p.ngroups; ++c) {
       const f32x2 mlv = *reinterpret_cast<const f32x2*>(p.mlg + (((long)c * p.heads + head) * p.Lq + qc) * 2);
@@ -600,9 +606,10 @@ __global__ __launch_bounds__(256) void k_attn_combine(CombineParams pin) {
       const long ch = (long)c * p.heads + head;
       const f32x2 mlv = *reinterpret_cast<const f32x2*>(p.mlg + (ch * p.Lq + qc) * 2);
       if (!(mlv[1] > 0.f)) continue;
-      const float w = __builtin_amdgcn_exp2f(mlv[0] - m);
-      den += w * mlv[1];
-      num += op[(ch * 8 + G) * p.Lq + qc] * w;
+      const float w = __builtin_amdgcn_exp2f(mlv[0] - m) * mlv[1];      // the partial is normalised: its weight is w l
+      den += w;
+      const e16x4 o4 = op[(ch * 8 + G) * p.Lq + qc];
+      num += f32x4{(float)o4[0], (float)o4[1], (float)o4[2], (float)o4[3]} * w;
     }
     if (live) {
       const f32x4 o = num * (1.f / den);
