@@ -229,7 +229,7 @@ def main():
         return f[:lengths[cid]], m
 
     # frames the encoder runs ahead (0 = default: 2 with clip groups -- 8 images per launch --, 4 for single clips)
-    lookahead = (args.encoder_lookahead or (2 if G > 1 else 4)) if cfg.MODEL_ENCODER == 'resnet50' else 1
+    lookahead = args.encoder_lookahead or (2 if G > 1 else 4)      # ResNet-50: encoder_batch.BatchEncoder, Swin-B: SwinBatchEncoder
     slots = []
     if G > 1:
         from rmem_ocu_amd.clip_runner import GroupSlot

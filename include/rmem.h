@@ -151,7 +151,8 @@ int rmem_layernorm256_pair(const void* a0, const void* b0, void* y0, const void*
                            const float* gamma, const float* beta, float eps, int M, void* stream);
 
 /* LayerNorm over C in {128, 256, 512, 1024} channels; bf16 and/or fp32 output.  Replaces the nn.LayerNorm call sites of the
- * Swin-B encoder (encoders/swin/swin_transformer.py:266, 318, 354, 538, 704). */
+ * Swin-B encoder (encoders/swin/swin_transformer.py:266, 318, 354, 538, 704).  Rows move as 8 / 16-byte vectors: lda, ldy, ldyf
+ * multiples of 4, a / y_f32 / gamma / beta 16-byte and y_bf16 8-byte aligned. */
 int rmem_layernorm(const void* a, int a_is_f32, int lda, const float* gamma, const float* beta, float eps, int M, int C,
                    void* y_bf16, int ldy, float* y_f32, int ldyf, void* stream);
 

@@ -1,4 +1,4 @@
-"""ResNet-50 encoder over the frames of several clips at once.
+"""The frozen image encoders over several frames at once (ResNet-50: BatchEncoder, Swin-B: SwinBatchEncoder).
 
 Clips are independent but share the frozen encoder (encoders/resnet.py:10-196; models/aot.py:116-134), and one 481x849
 frame gives GEMMs of only 1.7 k - 26 k rows.  ``BatchEncoder`` runs every encoder layer once for B frames (the conv
@@ -79,5 +79,82 @@ class BatchEncoder:
                     o.append(self._conv(bb, P[p + '.conv3.w'], P[p + '.conv3.b'], y, H=ho, W=wo, Cin=planes, Cout=planes * 4,
                                         residual=x, relu=True))
                 x, (h, w), cin = y, (ho, wo), planes * 4
+        self._prog = o
+        return o
+
+
+class SwinBatchEncoder:
+    """Swin-B (cfg 5; encoders/swin/swin_transformer.py:500-716) over B frames: the look-ahead counterpart of
+    ClipRuntime._prog_encode_swin.  One 720x1280 frame leaves only 3600 tokens for the 18 blocks of stage 3, so its linears are
+    GEMMs of 3600 rows and its LayerNorms launches of 3.7 MB; with B frames stacked as rows [frame][token] every linear and
+    LayerNorm is ONE launch over B times the rows (weights are shared, rows independent).  Window attention and patch merging
+    depend on the image geometry and have no image dimension: they run once per frame on that frame's rows.  Same kernels, same
+    operands per row as the per-frame encoder; interface of BatchEncoder (img_in, prog(), enc_out)."""
+
+    def __init__(self, P: Dict[str, torch.Tensor], in_hw: Tuple[int, int], batch: int, device):
+        if 'pe.w' not in P:
+            raise ops.RmemError('SwinBatchEncoder covers the Swin-B encoder')
+        self.P, self.B, self.dev = P, batch, device
+        H, W = in_hw
+        if H % 4 or W % 4:
+            raise ops.RmemError('Swin-B path: network size must be a multiple of 4')
+        self.H, self.W = H, W
+        B = batch
+        self.H4, self.W4 = H // 4, W // 4
+        self.H8, self.W8 = (self.H4 + 1) // 2, (self.W4 + 1) // 2
+        self.H16, self.W16 = (self.H8 + 1) // 2, (self.W8 + 1) // 2
+        M4, M8, L = self.H4 * self.W4, self.H8 * self.W8, self.H16 * self.W16
+        dt16 = P['proj.w'].dtype
+        e = lambda *shape, dt=None: torch.empty(*shape, dtype=dt or dt16, device=device)  # noqa: E731
+        self.img_in = e(B, 3, H, W, dt=F32)
+        self.img8 = e(B, H * W, 8)
+        self.sx = e(B * M4, 128, dt=F32)            # fp32 residual stream of the current stage
+        self.sln = e(B * M4, 128)
+        self.sqkv = e(B * M4, 384)
+        self.satt = e(B * M4, 128)
+        self.smlp = e(B * M4, 512)
+        self.smerge = e(B * M8, 512)
+        self.enc_out = (e(B, M4, 128), e(B, M8, 256), e(B, L, 512))
+        self.conv_ws = torch.empty(16 * B * L * 256, dtype=F32, device=device)
+        self._prog = None
+
+    def _lin(self, x, name, y, M, K, N, **kw):
+        return ops.linear(x, self.P[name + '.w'], self.P[name + '.b'], y, M=M, K=K, N=N, ws=self.conv_ws, **kw)
+
+    def prog(self) -> list:
+        if self._prog is not None:
+            return self._prog
+        from .pack import SWIN_DEPTHS, SWIN_HEADS
+        P, B, o = self.P, self.B, []
+        o.append(ops.image_to_nhwc8(self.img_in, self.img8, H=self.H, W=self.W, images=B))
+        h, w, C = self.H4, self.W4, 128
+        x = self.sx.view(-1)
+        o.append(ops.conv2d(self.img8, P['pe.w'], P['pe.b'], x[: B * h * w * C], H=self.H, W=self.W, Cin=8, Cout=C, KH=4, KW=4, stride=4,
+                            batch=B))
+        o.append(ops.layernorm(x, P['pe.ln.g'], P['pe.ln.b'], M=B * h * w, C=C, yf=x))
+        for li, (depth, heads) in enumerate(zip(SWIN_DEPTHS, SWIN_HEADS)):
+            M = h * w
+            ln, qkv, att, mlp = self.sln.view(-1), self.sqkv.view(-1), self.satt.view(-1), self.smlp.view(-1)
+            for b in range(depth):
+                d = f'sw{li}.{b}'
+                o.append(ops.layernorm(x, P[d + '.norm1.g'], P[d + '.norm1.b'], M=B * M, C=C, y=ln))
+                o.append(self._lin(ln, d + '.qkv', qkv, B * M, C, 3 * C))
+                for f in range(B):      # windows are cut per image
+                    o.append(ops.window_attn(qkv[f * M * 3 * C:], P[d + '.qkv.b'], P[d + '.table'], att[f * M * C:], H=h, W=w, C=C,
+                                             heads=heads, shift=0 if b % 2 == 0 else 3))
+                o.append(self._lin(att, d + '.proj', x, B * M, C, C, residual=x))
+                o.append(ops.layernorm(x, P[d + '.norm2.g'], P[d + '.norm2.b'], M=B * M, C=C, y=ln))
+                o.append(self._lin(ln, d + '.fc1', mlp, B * M, C, 4 * C, relu=2))
+                o.append(self._lin(mlp, d + '.fc2', x, B * M, 4 * C, C, residual=x))
+            o.append(ops.layernorm(x, P[f'sw.norm{li}.g'], P[f'sw.norm{li}.b'], M=B * M, C=C, y=self.enc_out[li]))
+            if li < len(SWIN_DEPTHS) - 1:
+                mg = self.smerge.view(-1)
+                h2, w2 = (h + 1) // 2, (w + 1) // 2
+                for f in range(B):
+                    o.append(ops.patch_merge_ln(x[f * M * C:], P[f'sw{li}.merge.g'], P[f'sw{li}.merge.b'], mg[f * h2 * w2 * 4 * C:],
+                                                H=h, W=w, C=C))
+                h, w = h2, w2
+                o.append(ops.linear(mg, P[f'sw{li}.merge.w'], None, x, M=B * h * w, K=4 * C, N=2 * C, ws=self.conv_ws))
+                C *= 2
         self._prog = o
         return o

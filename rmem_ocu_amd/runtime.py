@@ -334,14 +334,12 @@ class ClipRuntime:
 
     # ------------------------------------------------------------------ encoder look-ahead
     def batch_encoder(self, frames: int):
-        """The frames of a clip do not depend on each other before the LSTT, so the ResNet-50 encoder may run ``frames``
-        frames ahead as ONE launch per layer (rmem_ocu_amd.encoder_batch); slot e of its outputs then feeds
+        """The frames of a clip do not depend on each other before the LSTT, so the encoder (ResNet-50 or Swin-B) may run
+        ``frames`` frames ahead as ONE launch per layer (rmem_ocu_amd.encoder_batch); slot e of its outputs then feeds
         prog_project(e) / prog_decode(e) of the frame that is propagated."""
-        if self.swin:
-            raise ops.RmemError('encoder look-ahead is built for the ResNet-50 encoder')
         if getattr(self, '_benc', None) is None or self._benc.B != frames:
-            from .encoder_batch import BatchEncoder
-            self._benc = BatchEncoder(self.P, (self.H, self.W), frames, self.dev)
+            from .encoder_batch import BatchEncoder, SwinBatchEncoder
+            self._benc = (SwinBatchEncoder if self.swin else BatchEncoder)(self.P, (self.H, self.W), frames, self.dev)
             self._prog = {k: v for k, v in self._prog.items() if not k.startswith(('project_', 'decode_'))}
         return self._benc
 

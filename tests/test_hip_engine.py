@@ -454,6 +454,39 @@ def test_encoder_lookahead_matches_per_frame_path():
     assert agree > 0.995
 
 
+def test_swin_encoder_lookahead_matches_per_frame_path():
+    """The Swin-B encoder running 3 frames ahead (encoder_batch.SwinBatchEncoder: every linear / LayerNorm one launch over the
+    rows of 3 frames, window attention and patch merging per frame) against the frame-by-frame path: same masks, same bank trace.
+    The network size is NOT a multiple of the 7-token window (the padded / shifted windows of every frame must stay its own)."""
+    from rmem_ocu_amd import build_engine, build_vos_model, get_config
+    from rmem_ocu_amd.clip_runner import ClipSlot
+    from rmem_ocu_amd.synth import make_clip
+    from rmem_ocu_amd.weights import synth_state_dict
+    dev = torch.device('cuda', 0)
+    frames, mask = make_clip(9, 11, 160, 192, 3)
+    cfg = get_config('pre_vost', 'test', 'swinb_aotl')
+    cfg.FORMER_MEM_LEN, cfg.LATTER_MEM_LEN = 1, 2
+    cfg.MODEL_DTYPE = 'fp16'
+    model = build_vos_model(cfg.MODEL_VOS, cfg).cuda(0)
+    model.load_state_dict(synth_state_dict(0, encoder='swin_base'))
+    out = []
+    for la in (1, 3):
+        eng = build_engine(cfg.MODEL_ENGINE, phase='eval', aot_model=model, gpu_id=0, long_term_mem_gap=2)
+        eng.eval()
+        eng.set_async(use_graphs=True)
+        slot = ClipSlot(eng, (160, 192), dev, lookahead=la)
+        slot.start(frames.to(dev), mask.to(dev), 3)
+        while not slot.done:
+            slot.step()
+        eng.synchronize()
+        out.append((slot.labels[:11].cpu().numpy().copy(), list(eng.long_memories_indexes)))
+    (l1, t1), (l3, t3) = out
+    agree = (l1[1:] == l3[1:]).mean()
+    print('swin look-ahead 3 vs 1: label agreement', agree)
+    assert t1 == t3
+    assert agree > 0.999
+
+
 def test_sequence_evaluator_multiscale_tta():
     """f3: multi-scale + flip testing (TEST_MULTISCALE = [1.0, 1.3], TEST_FLIP): four engines at two network sizes, logits
     resized to the original size and averaged (managers/evaluator.py:342-355, 427-438) -- against the oracle."""
