@@ -146,7 +146,7 @@ def parse_args(argv=None):
     ap.add_argument('--workload', default='davis17_480p_r50_N8', choices=sorted(WORKLOADS))
     ap.add_argument('--no-graphs', action='store_true')
     ap.add_argument('--clips-per-group', type=int, default=int(os.environ.get('RMEM_CLIPS_PER_GROUP', 4)),
-                    help='> 1: that many clips advance in lockstep on one GroupEngine (one launch per layer for the group); R50-AOTL and R50-DeAOTL')
+                    help='> 1: that many clips advance in lockstep on one GroupEngine (one launch per layer for the group)')
     ap.add_argument('--host-frames', action='store_true',
                     help='PCIe-inclusive variant (not the contract line): frames start as decoded uint8 RGB in pinned host memory')
     ap.add_argument('--encoder-lookahead', type=int, default=int(os.environ.get('RMEM_ENC_LOOKAHEAD', 0)),
@@ -202,7 +202,7 @@ def main():
     net_hw = wl['net'] or network_size(*VIDEO_HW)
 
     C = max(1, args.clips_in_flight)
-    G = args.clips_per_group if wl['model'] in ('r50_aotl', 'r50_deaotl') else 1
+    G = args.clips_per_group           # GroupEngine covers R50-AOTL, SwinB-AOTL and R50-DeAOTL
     # ---- the job: clips_per_gpu * world clips, lengths cycling through wl['lengths'] (whole groups per length) ----
     per_len = max(G, (wl['clips_per_gpu'] * world // len(wl['lengths'])) // G * G)
     lengths = [n for n in wl['lengths'] for _ in range(per_len)]

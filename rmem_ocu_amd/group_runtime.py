@@ -1,4 +1,4 @@
-"""Device state and launch lists for a GROUP of clips that advance in lockstep (R50-AOTL path).
+"""Device state and launch lists for a GROUP of clips that advance in lockstep (R50-AOTL and SwinB-AOTL paths).
 
 At HW = 1674 tokens a launch costs about as much as its arithmetic and only four kernels are in flight on the GPU
 (DESIGN.md §7b), so the throughput path does not run one clip per launch list: B clips of equal length share one
@@ -25,7 +25,7 @@ from typing import Dict, List, Optional, Tuple
 import torch
 
 from . import ops
-from .encoder_batch import BatchEncoder
+from .encoder_batch import BatchEncoder, SwinBatchEncoder
 from .pack import R50_BLOCKS, R50_STRIDES
 from .runtime import BF16, D_MODEL, F32, FFN, HEADS, MAX_CHUNKS, PLAIN_CHUNKS, _out, sine_pos_emb, temporal_slots
 
@@ -38,26 +38,37 @@ class GroupRuntime:
 
     def __init__(self, P: Dict[str, torch.Tensor], in_hw: Tuple[int, int], bank_slots: int, device, clips: int,
                  num_lstt: int = 3, align_corners: bool = True, num_classes: int = 11, lookahead: int = 4):
-        if 'pe.w' in P or ('g0.qvu.w' in P) != self.deaot:
-            raise ops.RmemError('GroupRuntime covers the R50-AOTL path, group_runtime_deaot.GroupRuntimeDeAOT the R50-DeAOTL path')
+        if ('g0.qvu.w' in P) != self.deaot:
+            raise ops.RmemError('GroupRuntime covers the AOTL paths (ResNet-50 / Swin-B), group_runtime_deaot.GroupRuntimeDeAOT the R50-DeAOTL path')
+        self.swin = 'pe.w' in P
         self.P, self.dev, self.NL, self.B = P, device, num_lstt, clips
         self.dt = P['proj.w'].dtype
         self.align, self.nc = align_corners, num_classes
         H, W = in_hw
         self.H, self.W = H, W
         B = clips
-        self.H2, self.W2 = _out(H, 7, 2, 3), _out(W, 7, 2, 3)
-        self.H4, self.W4 = _out(self.H2, 3, 2, 1), _out(self.W2, 3, 2, 1)
-        self.H8, self.W8 = _out(self.H4, 3, 2, 1), _out(self.W4, 3, 2, 1)
-        self.H16, self.W16 = _out(self.H8, 3, 2, 1), _out(self.W8, 3, 2, 1)
+        if self.swin:     # Swin-B (cfg 5): patch 4 and two patch mergings (runtime.ClipRuntime has the citations)
+            if H % 4 or W % 4:
+                raise ops.RmemError('Swin-B path: network size must be a multiple of 4 (the evaluator makes it a multiple of 16)')
+            self.H4, self.W4 = H // 4, W // 4
+            self.H8, self.W8 = (self.H4 + 1) // 2, (self.W4 + 1) // 2
+            self.H16, self.W16 = (self.H8 + 1) // 2, (self.W8 + 1) // 2
+            self.enc_ch = (128, 256, 512)
+        else:
+            self.H2, self.W2 = _out(H, 7, 2, 3), _out(W, 7, 2, 3)
+            self.H4, self.W4 = _out(self.H2, 3, 2, 1), _out(self.W2, 3, 2, 1)
+            self.H8, self.W8 = _out(self.H4, 3, 2, 1), _out(self.W4, 3, 2, 1)
+            self.H16, self.W16 = _out(self.H8, 3, 2, 1), _out(self.W8, 3, 2, 1)
+            self.enc_ch = (256, 512, 1024)
         self.L = self.H16 * self.W16
         L, M4, M8 = self.L, self.H4 * self.W4, self.H8 * self.W8
         self.M4, self.M8 = M4, M8
         e = lambda *shape, dt=None: torch.empty(*shape, dtype=dt or self.dt, device=device)  # noqa: E731
         # ---- encoders: one for the frame in flight (reference frames), one running `lookahead` frames ahead; image = e * B + c
-        self.enc_now = BatchEncoder(P, in_hw, B, device)
+        Enc = SwinBatchEncoder if self.swin else BatchEncoder
+        self.enc_now = Enc(P, in_hw, B, device)
         self.lookahead = lookahead
-        self.enc_ahead = BatchEncoder(P, in_hw, B * lookahead, device) if lookahead > 1 else None
+        self.enc_ahead = Enc(P, in_hw, B * lookahead, device) if lookahead > 1 else None
         # ---- LSTT buffers, [B * L, .] clip-major ----
         R = B * L
         self.dec_in = e(R, self.dec_cin)
@@ -218,8 +229,8 @@ class GroupRuntime:
     def prog_project(self, e: Optional[int]) -> list:
         key = f'project_{e}'
         if key not in self._prog:
-            self._prog[key] = [ops.conv2d(self._enc(e)[2], self.P['proj.w'], self.P['proj.b'], self.x, H=self.B * self.L, W=1, Cin=1024,
-                                          Cout=D_MODEL, y2=self.dec_in, ld2=4 * D_MODEL, ws=self.conv_ws)]
+            self._prog[key] = [ops.conv2d(self._enc(e)[2], self.P['proj.w'], self.P['proj.b'], self.x, H=self.B * self.L, W=1,
+                                          Cin=self.enc_ch[2], Cout=D_MODEL, y2=self.dec_in, ld2=4 * D_MODEL, ws=self.conv_ws)]
         return self._prog[key]
 
     def prog_lstt(self, ref_mode: bool, T: int, want_mass: bool = True) -> list:
@@ -284,7 +295,8 @@ class GroupRuntime:
                                                            ws=self.conv_ws, **kw)
         o.append(lin(self.dec_in, 'dec.conv_in', self.d16a, L, self.dec_cin, 256))
         o.append(gn(self.d16a, 'dec.conv_in', self.d16b, L, 256))
-        o.append(lin(enc3, 'dec.adapter_16x', self.d16a, L, 1024, 256, residual=self.d16b))
+        c4, c8, c16 = self.enc_ch
+        o.append(lin(enc3, 'dec.adapter_16x', self.d16a, L, c16, 256, residual=self.d16b))
         o.append(self._conv(self.d16a, P['dec.conv_16x.w'], P['dec.conv_16x.b'], self.d16b, H=self.H16, W=self.W16, Cin=256, Cout=256,
                             KH=3, KW=3, pad=1))
         o.append(gn(self.d16b, 'dec.conv_16x', self.d16a, L, 256))
@@ -292,23 +304,23 @@ class GroupRuntime:
         fuse_up = not os.environ.get('RMEM_NO_UPFUSE')      # timing experiments only
         # F.interpolate(x, size) + adapter(shortcut) (decoders/fpn.py:49-52): the resize happens in the GEMM's residual read
         if fuse_up:
-            o.append(ops.conv2d(enc2, P['dec.adapter_8x.w'], P['dec.adapter_8x.b'], self.d8b, H=self.H8, W=self.W8, Cin=512, Cout=256,
+            o.append(ops.conv2d(enc2, P['dec.adapter_8x.w'], P['dec.adapter_8x.b'], self.d8b, H=self.H8, W=self.W8, Cin=c8, Cout=256,
                                 batch=B, residual=self.d16a, res_up=(self.H16, self.W16, self.align)))
         else:
             o.append(ops.bilinear(self.d16a, self.d8a, Hi=self.H16, Wi=self.W16, Ho=self.H8, Wo=self.W8, C=256, align_corners=self.align,
                                   images=B))
-            o.append(lin(enc2, 'dec.adapter_8x', self.d8b, M8, 512, 256, residual=self.d8a))
+            o.append(lin(enc2, 'dec.adapter_8x', self.d8b, M8, c8, 256, residual=self.d8a))
         d8c = self.d8a.view(-1)[: B * M8 * 128]
         o.append(self._conv(self.d8b, P['dec.conv_8x.w'], P['dec.conv_8x.b'], d8c, H=self.H8, W=self.W8, Cin=256, Cout=128, KH=3, KW=3,
                             pad=1))
         d8d = self.d8b.view(-1)[: B * M8 * 128]
         o.append(gn(d8c, 'dec.conv_8x', d8d, M8, 128))
         if fuse_up:
-            o.append(ops.conv2d(enc1, P['dec.adapter_4x.w'], P['dec.adapter_4x.b'], self.d4b, H=self.H4, W=self.W4, Cin=256, Cout=128,
+            o.append(ops.conv2d(enc1, P['dec.adapter_4x.w'], P['dec.adapter_4x.b'], self.d4b, H=self.H4, W=self.W4, Cin=c4, Cout=128,
                                 batch=B, residual=d8d, res_up=(self.H8, self.W8, self.align)))
         else:
             o.append(ops.bilinear(d8d, self.d4a, Hi=self.H8, Wi=self.W8, Ho=self.H4, Wo=self.W4, C=128, align_corners=self.align, images=B))
-            o.append(lin(enc1, 'dec.adapter_4x', self.d4b, M4, 256, 128, residual=self.d4a))
+            o.append(lin(enc1, 'dec.adapter_4x', self.d4b, M4, c4, 128, residual=self.d4a))
         o.append(self._conv(self.d4b, P['dec.conv_4x.w'], P['dec.conv_4x.b'], self.d4a, H=self.H4, W=self.W4, Cin=128, Cout=128, KH=3,
                             KW=3, pad=1))
         if os.environ.get('RMEM_NO_HEADFUSE'):               # timing experiments only

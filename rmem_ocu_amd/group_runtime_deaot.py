@@ -112,8 +112,8 @@ class GroupRuntimeDeAOT(GroupRuntime):
     def prog_project(self, e: Optional[int]) -> list:
         key = f'project_{e}'
         if key not in self._prog:
-            self._prog[key] = [ops.conv2d(self._enc(e)[2], self.P['proj.w'], self.P['proj.b'], self.xc0, H=self.B * self.L, W=1, Cin=1024,
-                                          Cout=D_MODEL, ldo=2 * D_MODEL, ws=self.conv_ws)]
+            self._prog[key] = [ops.conv2d(self._enc(e)[2], self.P['proj.w'], self.P['proj.b'], self.xc0, H=self.B * self.L, W=1,
+                                          Cin=self.enc_ch[2], Cout=D_MODEL, ldo=2 * D_MODEL, ws=self.conv_ws)]
         return self._prog[key]
 
     def prog_lstt(self, ref_mode: bool, T: int, want_mass: bool = True) -> list:

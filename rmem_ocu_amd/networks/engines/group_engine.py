@@ -17,7 +17,8 @@ Covered protocols (the reference's evaluator, managers/evaluator.py:385-523):
     go through the per-clip destination table (negative = no append for this clip).
 R50-DeAOTL models run through group_runtime_deaot.GroupRuntimeDeAOT (same protocol; the eviction policy's scores and visit
 counts then move on EVERY long-term update, deaot_engine.py / transformer.py:880-892; no mid-clip reference frames there).
-Swin and > 10 objects run on the per-clip engines, which are the drop-in API.
+SwinB-AOTL models (cfg 5) run through the same GroupRuntime with encoder_batch.SwinBatchEncoder as the look-ahead encoder.
+Clips with > 10 objects and multi-scale / flip testing run on the per-clip engines, which are the drop-in API.
 """
 from __future__ import annotations
 

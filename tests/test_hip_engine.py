@@ -487,6 +487,48 @@ def test_swin_encoder_lookahead_matches_per_frame_path():
     assert agree > 0.999
 
 
+def test_swin_group_engine_matches_per_clip_engines():
+    """Throughput mode of the cfg-5 model: three clips in lockstep on one GroupEngine over SwinB-AOTL (Swin-B look-ahead encoder
+    over 3 x 2 frames, align_corners False, 16x16 stride-16 identity bank, fp16) against three per-clip engines."""
+    from rmem_ocu_amd import build_engine, build_vos_model, get_config
+    from rmem_ocu_amd.clip_runner import ClipSlot, GroupSlot
+    from rmem_ocu_amd.networks.engines.group_engine import GroupEngine
+    from rmem_ocu_amd.synth import make_clip
+    from rmem_ocu_amd.weights import synth_state_dict
+    dev = torch.device('cuda', 0)
+    B, n = 3, 16
+    clips = [make_clip(80 + c, n, 160, 192, 3) for c in range(B)]
+    cfg = get_config('pre_vost', 'test', 'swinb_aotl')
+    cfg.FORMER_MEM_LEN, cfg.LATTER_MEM_LEN = 1, 2
+    cfg.MODEL_DTYPE = 'fp16'
+    model = build_vos_model(cfg.MODEL_VOS, cfg).cuda(0)
+    model.load_state_dict(synth_state_dict(0, encoder='swin_base'))
+    ref_labels, ref_traces = [], []
+    for f, m in clips:
+        eng = build_engine(cfg.MODEL_ENGINE, phase='eval', aot_model=model, gpu_id=0, long_term_mem_gap=5)
+        eng.eval()
+        eng.set_async(use_graphs=True)
+        slot = ClipSlot(eng, (160, 192), dev, lookahead=1)
+        slot.start(f.to(dev), m.to(dev), 3)
+        while not slot.done:
+            slot.step()
+        eng.synchronize()
+        ref_labels.append(slot.labels[:n].cpu().numpy().copy())
+        ref_traces.append((list(eng.long_memories_indexes), list(eng.aot_engines[0].drop_trace)))
+    ge = GroupEngine(model, B, 0, 5, lookahead=2)
+    gs = GroupSlot(ge, (160, 192), dev)
+    gs.start([f.to(dev) for f, _ in clips], [m.to(dev) for _, m in clips], 3)
+    while not gs.done:
+        gs.step()
+    ge.synchronize()
+    got = gs.labels[:, :n].cpu().numpy()
+    for c in range(B):
+        agree = (got[c][1:] == ref_labels[c][1:]).mean()
+        print(f'swin clip {c}: label agreement {agree:.5f}, indexes {ge.long_memories_indexes(c)}, drops {ge.drop_trace[c]}')
+        assert agree > 0.998
+        assert (ge.long_memories_indexes(c), ge.drop_trace[c]) == ref_traces[c]
+
+
 def test_sequence_evaluator_multiscale_tta():
     """f3: multi-scale + flip testing (TEST_MULTISCALE = [1.0, 1.3], TEST_FLIP): four engines at two network sizes, logits
     resized to the original size and averaged (managers/evaluator.py:342-355, 427-438) -- against the oracle."""
