@@ -363,10 +363,12 @@ __global__ __launch_bounds__(256) void k_gn_apply_rows(const TI* x, int M, int C
 }
 
 // GroupNorm apply + activation + a narrow 1x1 convolution (N <= 16 outputs) in one pass: the segmentation head's last
-// `conv_out(relu(gn(x)))` (decoders/fpn.py:62-66) without writing the normalised 128-channel map.  A workgroup takes 64 pixels:
-// phase 1 normalises them into LDS (e16, the rounding the two-kernel route stores), phase 2 gives thread (pixel, 4 outputs)
-// a 128-long dot product against fp32 weights in LDS.  C = 128 only (the path's head); y is fp32 [M][ldy].
-constexpr int HC = 128, HPIX = 64, HROW = HC + 8;
+// `conv_out(relu(gn(x)))` (decoders/fpn.py:62-66) without writing the normalised 128-channel map.  A workgroup takes HPASS x 64
+// pixels: phase 1 normalises 64 of them into LDS (e16, the rounding the two-kernel route stores); phase 2 is a [16 pixels] x [16
+// outputs] x [K = 128] product per wave on the matrix pipe (four v_mfma_f32_16x16x32; the weights are this wave's B fragments,
+// read from global once) -- as 128-long VALU dot products it was 6 x off the kernel's byte count.  C = 128 only (the path's head);
+// y is fp32 [M][ldy].
+constexpr int HC = 128, HPIX = 64, HROW = HC + 8, HPASS = 2;
 __global__ __launch_bounds__(256) void k_gn_apply_head(const e16* x, int M, int cpg, int groups, const float* ws, const float* gamma,
                                                        const float* beta, float eps, int act, const e16* w, const float* bias, int N,
                                                        float* y, int ldy) {
@@ -375,20 +377,31 @@ __global__ __launch_bounds__(256) void k_gn_apply_head(const e16* x, int M, int 
   ws += (long)blockIdx.y * groups * GN_SPLITS * 2;
   __shared__ float s_mean[64], s_rstd[64];
   __shared__ __attribute__((aligned(16))) e16 tile[HPIX * HROW];
-  __shared__ __attribute__((aligned(16))) float wl[16 * HC];
   gn_finalize(ws, groups, (float)M * (float)cpg, eps, s_mean, s_rstd);
-  const int tid = threadIdx.x;
-  for (int i = tid; i < 16 * HC; i += 256) wl[i] = (i / HC) < N ? (float)w[i] : 0.f;     // w is [N][128] e16
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // B fragments: lane -> output n = lane & 15 (zero rows for n >= N), k = 32 ks + 8 (lane >> 4) .. + 7; w is [N][128] e16
+  const int n = lane & 15, kq = lane >> 4;
+  e16x8 bf[HC / 32];
+#pragma unroll
+  for (int ks = 0; ks < HC / 32; ++ks) {
+    bf[ks] = e16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    if (n < N) bf[ks] = *reinterpret_cast<const e16x8*>(w + n * HC + 32 * ks + 8 * kq);
+  }
+  const float bn = (bias && n < N) ? bias[n] : 0.f;
   __syncthreads();
-  const int m0 = blockIdx.x * HPIX;
+  const int c = tid & 15, rl = tid >> 4, c0 = c * 8;          // phase 1: 16 chunks of 8 channels per pixel, 16 pixels per pass
+  const float mean = s_mean[c0 / cpg], rstd = s_rstd[c0 / cpg];
+  float gm[8], bt[8];
   {
-    const int c = tid & 15, rl = tid >> 4, c0 = c * 8;          // 16 chunks of 8 channels per pixel, 16 pixels per pass
-    const float mean = s_mean[c0 / cpg], rstd = s_rstd[c0 / cpg];
-    float gm[8], bt[8];
     const f32x4 g0v = *reinterpret_cast<const f32x4*>(gamma + c0), g1v = *reinterpret_cast<const f32x4*>(gamma + c0 + 4);
     const f32x4 b0v = *reinterpret_cast<const f32x4*>(beta + c0), b1v = *reinterpret_cast<const f32x4*>(beta + c0 + 4);
 #pragma unroll
     for (int j = 0; j < 4; ++j) { gm[j] = g0v[j]; gm[4 + j] = g1v[j]; bt[j] = b0v[j]; bt[4 + j] = b1v[j]; }
+  }
+  for (int pass = 0; pass < HPASS; ++pass) {
+    const int m0 = (blockIdx.x * HPASS + pass) * HPIX;
+    if (m0 >= M) break;                                        // (workgroup-uniform)
+    if (pass > 0) __syncthreads();                             // everybody has read the previous tile
     float d[4][8];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -410,27 +423,21 @@ __global__ __launch_bounds__(256) void k_gn_apply_head(const e16* x, int M, int 
       }
       *reinterpret_cast<e16x8*>(&tile[(rl + 16 * u) * HROW + c0]) = o;
     }
-  }
-  __syncthreads();
-  const int px = tid & 63, og = tid >> 6;                       // og is wave-uniform: weight reads are LDS broadcasts
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-  for (int c8 = 0; c8 < HC / 8; ++c8) {
-    const e16x8 a = *reinterpret_cast<const e16x8*>(&tile[px * HROW + c8 * 8]);
+    __syncthreads();
+    // phase 2: wave -> pixels 16 wave .. + 15; A fragment: lane -> pixel row (lane & 15), k = 32 ks + 8 (lane >> 4) .. + 7
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float* wq = &wl[(og * 4 + q) * HC + c8 * 8];
-      const f32x4 w0 = *reinterpret_cast<const f32x4*>(wq), w1 = *reinterpret_cast<const f32x4*>(wq + 4);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) { acc[q] += (float)a[j] * w0[j]; acc[q] += (float)a[4 + j] * w1[j]; }
+    for (int ks = 0; ks < HC / 32; ++ks) {
+      const e16x8 a = *reinterpret_cast<const e16x8*>(&tile[(16 * wave + n) * HROW + 32 * ks + 8 * kq]);
+      acc = RMEM_MFMA_16x16x32(a, bf[ks], acc, 0, 0, 0);
     }
-  }
-  const int m = m0 + px;
-  if (m < M) {
+    // D: lane -> output column n, pixel rows 4 (lane >> 4) + i
+    if (n < N) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int n = og * 4 + q;
-      if (n < N) y[(long)m * ldy + n] = acc[q] + (bias ? bias[n] : 0.f);
+      for (int i = 0; i < 4; ++i) {
+        const int m = m0 + 16 * wave + 4 * kq + i;
+        if (m < M) y[(long)m * ldy + n] = acc[i] + bn;
+      }
     }
   }
 }
@@ -706,10 +713,11 @@ extern "C" int RMEM_API(rmem_groupnorm_head_nhwc_images)(const void* x, int imag
                                                float* workspace, void* stream) {
   if (gn_check(x, y, gamma, beta, workspace, groups, C, act, M, images)) return -1;
   RMEM_REQUIRE(C == 128 && w && N >= 1 && N <= 16 && ldy >= N, "rmem_groupnorm_head_nhwc: C must be 128, 1 <= N <= 16 <= ... ldy >= N");
+  RMEM_REQUIRE((uintptr_t)w % 16 == 0, "rmem_groupnorm_head_nhwc: w must be 16-byte aligned");
   const int cpg = C / groups;
   hipStream_t s = (hipStream_t)stream;
   gn_launch_stats((const e16*)x, images, M, C, cpg, workspace, s);
-  hipLaunchKernelGGL(k_gn_apply_head, dim3((M + HPIX - 1) / HPIX, images), dim3(256), 0, s, (const e16*)x, M, cpg, groups, workspace, gamma,
+  hipLaunchKernelGGL(k_gn_apply_head, dim3((M + HPIX * HPASS - 1) / (HPIX * HPASS), images), dim3(256), 0, s, (const e16*)x, M, cpg, groups, workspace, gamma,
                      beta, eps, act, (const e16*)w, bias, N, y, ldy);
   return rmem_check_launch("rmem_groupnorm_head_nhwc_images");
 }

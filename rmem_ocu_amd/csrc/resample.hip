@@ -84,6 +84,63 @@ __global__ __launch_bounds__(256) void k_bilinear_nhwc(const e16* x, e16* y, int
   reinterpret_cast<e16x8*>(y)[i] = o;
 }
 
+// labels only from 16-float logit rows (the per-frame fast path of k_logits_post): a thread makes 4 consecutive output pixels of
+// one row.  At the path's ~4 x upsampling they share their two source columns most of the time, so the 4 x 16-float taps are
+// reloaded only when the source column moves (a third of the cached loads of one-pixel-per-thread); same arithmetic per pixel.
+__global__ __launch_bounds__(256) void k_logits_labels4(const float* lg, int nc, int keep, int Hi, int Wi, int Ho, int Wo, int align,
+                                                        uint8_t* label, float* label_f32) {
+  const int wq = (Wo + 3) / 4;
+  const long item = (long)blockIdx.x * 256 + threadIdx.x;
+  if (item >= (long)Ho * wq) return;
+  const long total = (long)Ho * Wo;
+  lg += (long)blockIdx.y * Hi * Wi * 16;
+  if (label) label += (long)blockIdx.y * total;
+  if (label_f32) label_f32 += (long)blockIdx.y * total;
+  const int oy = (int)(item / wq), oxb = (int)(item - (long)oy * wq) * 4;
+  int y0, y1; float wy;
+  src_coord(oy, Hi, Ho, align, y0, y1, wy);
+  float va[16], vb[16], vc[16], vd[16];
+  int cx0 = -1, cx1 = -1;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int ox = oxb + k;
+    if (ox >= Wo) break;
+    int x0, x1; float wx;
+    src_coord(ox, Wi, Wo, align, x0, x1, wx);
+    if (x0 != cx0 || x1 != cx1) {
+      const float* a = lg + ((long)y0 * Wi + x0) * 16;
+      const float* b = lg + ((long)y0 * Wi + x1) * 16;
+      const float* c = lg + ((long)y1 * Wi + x0) * 16;
+      const float* d = lg + ((long)y1 * Wi + x1) * 16;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 ta = *reinterpret_cast<const f32x4*>(a + 4 * q), tb = *reinterpret_cast<const f32x4*>(b + 4 * q);
+        const f32x4 tc = *reinterpret_cast<const f32x4*>(c + 4 * q), td = *reinterpret_cast<const f32x4*>(d + 4 * q);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { va[4 * q + j] = ta[j]; vb[4 * q + j] = tb[j]; vc[4 * q + j] = tc[j]; vd[4 * q + j] = td[j]; }
+      }
+      cx0 = x0; cx1 = x1;
+    }
+    float best = -3.0e38f; int arg = 0;
+#pragma unroll
+    for (int ch = 0; ch < 16; ++ch) {
+      if (ch < nc) {
+        float v;
+        if (ch > keep) v = -1.0e10f;
+        else {
+          const float top = va[ch] * (1.f - wx) + vb[ch] * wx;
+          const float bot = vc[ch] * (1.f - wx) + vd[ch] * wx;
+          v = top * (1.f - wy) + bot * wy;
+        }
+        if (v > best) { best = v; arg = ch; }
+      }
+    }
+    const long i = (long)oy * Wo + ox;
+    if (label) label[i] = (uint8_t)arg;
+    if (label_f32) label_f32[i] = (float)arg;
+  }
+}
+
 // logits NHWC fp32 [Hi][Wi][ldl] -> NCHW fp32 [nc][Ho][Wo] (optional) + argmax labels (optional)
 __global__ __launch_bounds__(256) void k_logits_post(const float* lg, int ldl, int nc, int keep, int Hi, int Wi, int Ho, int Wo,
                                                      int align, float* out, uint8_t* label, float* label_f32) {
@@ -430,8 +487,12 @@ extern "C" int rmem_logits_post_images(const float* logits_nhwc, int images, int
   RMEM_REQUIRE(logits_nhwc && images >= 1 && num_classes >= 1 && num_classes <= 16 && ldl >= num_classes, "rmem_logits_post: bad argument");
   RMEM_REQUIRE(out_nchw || label_u8 || label_f32, "rmem_logits_post: no output requested");
   RMEM_REQUIRE(images == 1 || !out_nchw, "rmem_logits_post: a batch of images produces labels only");
-  hipLaunchKernelGGL(k_logits_post, dim3(nblk((long)Ho * Wo), images), dim3(256), 0, (hipStream_t)stream, logits_nhwc, ldl, num_classes,
-                     keep_max_id, Hi, Wi, Ho, Wo, align_corners, out_nchw, label_u8, label_f32);
+  if (ldl == 16 && !out_nchw && ((uintptr_t)logits_nhwc % 16) == 0)
+    hipLaunchKernelGGL(k_logits_labels4, dim3(nblk((long)Ho * ((Wo + 3) / 4)), images), dim3(256), 0, (hipStream_t)stream, logits_nhwc,
+                       num_classes, keep_max_id, Hi, Wi, Ho, Wo, align_corners, label_u8, label_f32);
+  else
+    hipLaunchKernelGGL(k_logits_post, dim3(nblk((long)Ho * Wo), images), dim3(256), 0, (hipStream_t)stream, logits_nhwc, ldl, num_classes,
+                       keep_max_id, Hi, Wi, Ho, Wo, align_corners, out_nchw, label_u8, label_f32);
   return rmem_check_launch("rmem_logits_post");
 }
 #endif
