@@ -278,17 +278,35 @@ class GroupSlot:
         self.frames_encoded += self.B
         self.cursor = 1
         self.done = n <= 1
+        if eng.lookahead > 1 and n > 1:
+            self._kick_encoder(0, 1)                            # frames 1 .. lookahead: batch 0
 
-    def _fill_encoder_inputs(self, dst: torch.Tensor, i: int, m: int):
-        """frames i .. i + m - 1 of every clip into rows k * B + c of dst ([., 3, H, W] fp32) on the engine's stream."""
+    def _kick_encoder(self, buf: int, i: int):
+        """Encode frames i .. i + lookahead - 1 of every clip into look-ahead buffer ``buf`` on the engine's side stream."""
+        eng = self.engine
+        m = min(eng.lookahead, self.frames[0].shape[0] - i)
+        self.frames_encoded += self.B * m
+        stage = None
+        if self.host_u8:
+            if getattr(self, '_stage_la', None) is None or tuple(self._stage_la.shape[1:3]) != tuple(self.frames[0].shape[1:3]):
+                hs, ws = int(self.frames[0].shape[1]), int(self.frames[0].shape[2])
+                self._stage_la = torch.empty(eng.lookahead * self.B, hs, ws, 3, dtype=torch.uint8, device=self.device)
+            stage = self._stage_la
+        self._fill_encoder_inputs(eng.encode_inputs(buf), i, m, stream=eng.enc_stream, stage=stage)
+        eng.encode_ahead(buf)
+
+    def _fill_encoder_inputs(self, dst: torch.Tensor, i: int, m: int, stream=None, stage=None):
+        """frames i .. i + m - 1 of every clip into rows k * B + c of dst ([., 3, H, W] fp32) on ``stream`` (default: the engine's
+        main stream), uint8 host frames through the staging buffer ``stage``."""
         eng, B = self.engine, self.B
-        s = eng.stream.cuda_stream
+        s = (stream or eng.stream).cuda_stream
+        stage = getattr(self, '_stage', None) if stage is None else stage
         if self.host_u8:
             hs, ws = int(self.frames[0].shape[1]), int(self.frames[0].shape[2])
             H, W = int(dst.shape[-2]), int(dst.shape[-1])
             for c in range(B):
-                ops.copy_async(self._stage[c * m:(c + 1) * m], self.frames[c][i:i + m], m * hs * ws * 3)(s)
-            ops.run([ops.ingest_rgb8(self._stage[c * m + k], Hs=hs, Ws=ws, Hd=H, Wd=W, out_chw=dst[k * B + c]) for c in range(B)
+                ops.copy_async(stage[c * m:(c + 1) * m], self.frames[c][i:i + m], m * hs * ws * 3)(s)
+            ops.run([ops.ingest_rgb8(stage[c * m + k], Hs=hs, Ws=ws, Hd=H, Wd=W, out_chw=dst[k * B + c]) for c in range(B)
                      for k in range(m)], s)
         else:
             fb = dst[0].numel() * 4
@@ -301,13 +319,10 @@ class GroupSlot:
         la = eng.lookahead
         s = eng.stream.cuda_stream
         if la > 1:
-            e = (i - 1) % la
-            if e == 0:
-                m = min(la, self.frames[0].shape[0] - i)
-                self.frames_encoded += B * m
-                self._fill_encoder_inputs(eng.encode_inputs(), i, m)
-                eng.encode_ahead()
-            eng.propagate_to_labels(self.cur_label, enc_slot=e)
+            b, e = divmod(i - 1, la)
+            if e == 0 and i + la < self.frames[0].shape[0]:
+                self._kick_encoder((b + 1) % 2, i + la)         # the NEXT batch, on the side stream, beside this batch's frames
+            eng.propagate_to_labels(self.cur_label, enc_slot=(b % 2) * la + e)
         else:
             self.frames_encoded += B
             if self.host_u8:

@@ -68,7 +68,10 @@ class GroupRuntime:
         Enc = SwinBatchEncoder if self.swin else BatchEncoder
         self.enc_now = Enc(P, in_hw, B, device)
         self.lookahead = lookahead
-        self.enc_ahead = Enc(P, in_hw, B * lookahead, device) if lookahead > 1 else None
+        # two look-ahead encoders: while the frames of one batch are being propagated, the next batch is encoded on the engine's
+        # side stream (group_engine.py); look-ahead slot s = buffer * lookahead + frame
+        self.enc_bufs = [Enc(P, in_hw, B * lookahead, device) for _ in range(2)] if lookahead > 1 else []
+        self.enc_ahead = self.enc_bufs[0] if self.enc_bufs else None
         # ---- LSTT buffers, [B * L, .] clip-major ----
         R = B * L
         self.dec_in = e(R, self.dec_cin)
@@ -219,8 +222,9 @@ class GroupRuntime:
         if e is None:
             return self.enc_now.enc_out
         B = self.B
-        o = self.enc_ahead.enc_out
-        return tuple(t[e * B:(e + 1) * B] for t in o)
+        buf, f = divmod(e, self.lookahead)
+        o = self.enc_bufs[buf].enc_out
+        return tuple(t[f * B:(f + 1) * B] for t in o)
 
     # ------------------------------------------------------------------ programs
     def prog_encode(self) -> list:

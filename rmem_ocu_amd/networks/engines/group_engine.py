@@ -49,6 +49,11 @@ class GroupEngine:
         self.long_term_mem_gap = long_term_mem_gap
         self.lookahead = lookahead
         self.stream = torch.cuda.Stream(self.device)
+        # the look-ahead encoder of the NEXT batch of frames runs here, beside the propagation of the current batch (events order
+        # the two: a batch is propagated after its encoder finished, a buffer is re-encoded after its last frame was decoded)
+        self.enc_stream = torch.cuda.Stream(self.device)
+        self._enc_done = [torch.cuda.Event(), torch.cuda.Event()]
+        self._enc_free = [None, None]
         self.use_graphs = True
         self.rt: Optional[GroupRuntime] = None
         self._side: Optional[ClipRuntime] = None
@@ -94,8 +99,8 @@ class GroupEngine:
             self._side = None
         return self.rt
 
-    def _run(self, key: str, prog: list):
-        s = self._s()
+    def _run(self, key: str, prog: list, s: Optional[int] = None):
+        s = self._s() if s is None else s
         if self.use_graphs:
             g = self._graphs.get(key)
             if g is None:
@@ -176,13 +181,20 @@ class GroupEngine:
         self._indexes[c].append(self.frame_step)
 
     # ------------------------------------------------------------------ look-ahead encoder
-    def encode_inputs(self) -> torch.Tensor:
-        """fp32 [lookahead * B, 3, H, W]: frame e of clip c goes to row e * B + c."""
-        return self.rt.enc_ahead.img_in
+    def encode_inputs(self, buf: int = 0) -> torch.Tensor:
+        """fp32 [lookahead * B, 3, H, W] of look-ahead buffer ``buf``: frame e of clip c goes to row e * B + c.  Fill it on
+        ``enc_stream`` (the previous encoder pass over this buffer reads it there)."""
+        return self.rt.enc_bufs[buf].img_in
 
-    def encode_ahead(self):
-        with torch.cuda.stream(self.stream):
-            self._run('encB', self.rt.enc_ahead.prog())
+    def encode_ahead(self, buf: int = 0):
+        """Encode the frames in encode_inputs(buf) on the side stream; propagate_to_labels(enc_slot = buf * lookahead + e)
+        waits for it."""
+        es = self.enc_stream
+        if self._enc_free[buf] is not None:
+            es.wait_event(self._enc_free[buf])          # the buffer's previous frames have been projected / decoded
+        with torch.cuda.stream(es):
+            self._run(f'encB{buf}', self.rt.enc_bufs[buf].prog(), es.cuda_stream)
+            self._enc_done[buf].record(es)
 
     # ------------------------------------------------------------------ propagate (aot_engine.py:398-465 + evaluator.py:430-441)
     def _will_append(self, c: int) -> bool:
@@ -217,8 +229,14 @@ class GroupEngine:
                 ops.copy_async(rt.enc_now.img_in, imgs.contiguous(), B * 3 * rt.H * rt.W * 4)(self._s())
                 prog = rt.prog_encode() + rt.prog_project(None) + rt.prog_lstt(False, T, wm) + rt.prog_decode(None) + rt._prog[pk]
             else:
+                buf = enc_slot // rt.lookahead
+                self.stream.wait_event(self._enc_done[buf])
                 prog = rt.prog_project(enc_slot) + rt.prog_lstt(False, T, wm) + rt.prog_decode(enc_slot) + rt._prog[pk]
             self._run(f'prop{T}{int(wm)}e{enc_slot}_{labels_u8.data_ptr()}', prog)
+            if enc_slot is not None:
+                ev = self._enc_free[buf] or torch.cuda.Event()
+                ev.record(self.stream)
+                self._enc_free[buf] = ev
 
     # ------------------------------------------------------------------ memory update (aot_engine.py:327-369)
     def update_from_labels(self, labels_u8: torch.Tensor, skip: Iterable[int] = ()):
