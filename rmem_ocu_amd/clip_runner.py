@@ -224,7 +224,9 @@ class ClipSlot:
 
 class GroupSlot:
     """B clips of equal length in flight on one GroupEngine (networks/engines/group_engine.py): same protocol as ClipSlot, one
-    launch per layer for the whole group."""
+    launch per layer for the whole group.  With an encoder look-ahead of n frames the frames are encoded in batches of n per
+    clip: batch k + 1 is copied in and encoded on the engine's side stream while the frames of batch k are propagated (two
+    look-ahead buffers, alternating; look-ahead slot = buffer * n + frame)."""
 
     def __init__(self, engine, out_hw, device):
         self.engine = engine
