@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define RMEM_ABI_VERSION 5
+#define RMEM_ABI_VERSION 6
 
 int rmem_abi_version(void);
 const char* rmem_last_error_string(void);
@@ -161,6 +161,9 @@ int rmem_layernorm(const void* a, int a_is_f32, int lda, const float* gamma, con
  * reduction Linear at 356 is a rmem_conv2d_nhwc call).  C in {128, 256}. */
 int rmem_patch_merge_ln(const float* x, int H, int W, int C, const float* gamma, const float* beta, float eps,
                         void* y_bf16, void* stream);
+/* the same over a batch: x fp32 [images][H][W][C] -> y [images][ceil(H/2)*ceil(W/2)][4C] (encoder_batch.SwinBatchEncoder) */
+int rmem_patch_merge_ln_images(const float* x, int images, int H, int W, int C, const float* gamma, const float* beta, float eps,
+                               void* y_bf16, void* stream);
 
 /* Swin (shifted-)window attention over a [H][W] token map, 7x7 windows, head dim 32: padding, cyclic shift, window
  * partition / reverse, relative-position bias and the shifted-window mask are index arithmetic inside the kernel.
@@ -170,6 +173,9 @@ int rmem_patch_merge_ln(const float* x, int H, int W, int C, const float* gamma,
  * Replaces encoders/swin/swin_transformer.py:156-195 and the token plumbing of 263-305. */
 int rmem_window_attn(const void* qkv, const float* qkv_bias, const float* bias_mask_table, void* out, int H, int W,
                      int C, int heads, int shift, void* stream);
+/* the same over a batch of token maps: qkv [images][H*W][3C], out [images][H*W][C]; windows never cross images */
+int rmem_window_attn_images(const void* qkv, const float* qkv_bias, const float* bias_mask_table, void* out, int images, int H, int W,
+                            int C, int heads, int shift, void* stream);
 
 /* y = a + b (bf16).  Replaces the `curr_v + curr_id_emb` adds of layers/transformer.py:279-285. */
 int rmem_add16(const void* a, const void* b, void* y, long long n, void* stream);
@@ -340,6 +346,8 @@ int rmem_layernorm256_f16(const void* a, int a_is_f32, int lda, const void* b, i
 int rmem_layernorm_f16(const void* a, int a_is_f32, int lda, const float* gamma, const float* beta, float eps, int M, int C, void* y_bf16, int ldy, float* y_f32, int ldyf, void* stream);
 int rmem_patch_merge_ln_f16(const float* x, int H, int W, int C, const float* gamma, const float* beta, float eps, void* y_bf16, void* stream);
 int rmem_window_attn_f16(const void* qkv, const float* qkv_bias, const float* bias_mask_table, void* out, int H, int W, int C, int heads, int shift, void* stream);
+int rmem_window_attn_images_f16(const void* qkv, const float* qkv_bias, const float* bias_mask_table, void* out, int images, int H, int W, int C, int heads, int shift, void* stream);
+int rmem_patch_merge_ln_images_f16(const float* x, int images, int H, int W, int C, const float* gamma, const float* beta, float eps, void* y_bf16, void* stream);
 int rmem_add16_f16(const void* a, const void* b, void* y, long long n, void* stream);
 int rmem_add16_grouped_f16(int n, const void* const* a, const void* const* b, void* const* y, long long count, void* stream);
 int rmem_layernorm256_pair_f16(const void* a0, const void* b0, void* y0, const void* a1, const void* b1, void* y1, const float* gamma, const float* beta, float eps, int M, void* stream);

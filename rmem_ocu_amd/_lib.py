@@ -11,7 +11,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('RMEM_LIB_PATH') or os.path.join(_HERE, 'librmem_hip.so')   # override: kernel experiments only
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class RmemError(RuntimeError):
@@ -44,6 +44,8 @@ SIGNATURES = {
     'rmem_layernorm': (_i, [_vp, _i, _i, _vp, _vp, _f, _i, _i, _vp, _i, _vp, _i, _vp]),
     'rmem_patch_merge_ln': (_i, [_vp, _i, _i, _i, _vp, _vp, _f, _vp, _vp]),
     'rmem_window_attn': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    'rmem_window_attn_images': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    'rmem_patch_merge_ln_images': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _f, _vp, _vp]),
     'rmem_add16': (_i, [_vp, _vp, _vp, _ll, _vp]),
     'rmem_add16_grouped': (_i, [_i, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), _ll, _vp]),
     'rmem_layernorm256_pair': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _vp]),
@@ -91,7 +93,7 @@ SIGNATURES = {
 
 # entry points with 16-bit operands exist twice: <name> (bfloat16) and <name>_f16 (IEEE half), same signature (include/rmem.h)
 F16_TWINS = ('rmem_conv2d_nhwc', 'rmem_mem_read_attn', 'rmem_mem_read_attn_clips', 'rmem_layernorm256', 'rmem_layernorm', 'rmem_patch_merge_ln',
-             'rmem_window_attn', 'rmem_add16', 'rmem_add16_grouped', 'rmem_layernorm256_pair', 'rmem_conv1x1_dual_nhwc', 'rmem_linear_grouped',
+             'rmem_window_attn', 'rmem_window_attn_images', 'rmem_patch_merge_ln_images', 'rmem_add16', 'rmem_add16_grouped', 'rmem_layernorm256_pair', 'rmem_conv1x1_dual_nhwc', 'rmem_linear_grouped',
              'rmem_groupnorm_nhwc', 'rmem_groupnorm_f32_nhwc', 'rmem_groupnorm_nhwc_images', 'rmem_groupnorm_head_nhwc_images',
              'rmem_gn_act_dwconv5x5_nhwc_images', 'rmem_gn_act_dwconv5x5_nhwc', 'rmem_dwconv5x5_nhwc', 'rmem_image_to_nhwc8',
              'rmem_image_to_nhwc8_images', 'rmem_ingest_rgb8', 'rmem_maxpool3x3s2_nhwc', 'rmem_maxpool3x3s2_nhwc_images', 'rmem_bilinear_nhwc',

@@ -120,6 +120,8 @@ __global__ __launch_bounds__(256) void k_patch_merge_ln(const float* x, int H, i
   const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
   const int tok = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (tok >= Ho * Wo) return;
+  x += (long)blockIdx.y * H * W * C;                      // blockIdx.y = image of a batch
+  y += (long)blockIdx.y * Ho * Wo * C4;
   const int oy = tok / Wo, ox = tok - oy * Wo;
   const int c0 = lane * NV;                  // NV consecutive channels of the 4C vector: one source pixel (NV divides C)
   const int part = c0 / C, cc = c0 - part * C;
@@ -628,10 +630,17 @@ extern "C" int RMEM_API(rmem_layernorm)(const void* a, int a_is_f32, int lda, co
   return rmem_check_launch("rmem_layernorm");
 }
 
+extern "C" int RMEM_API(rmem_patch_merge_ln_images)(const float* x, int images, int H, int W, int C, const float* gamma, const float* beta, float eps,
+                                          void* y_bf16, void* stream);
 extern "C" int RMEM_API(rmem_patch_merge_ln)(const float* x, int H, int W, int C, const float* gamma, const float* beta, float eps, void* y_bf16, void* stream) {
-  RMEM_REQUIRE(x && gamma && beta && y_bf16 && H > 0 && W > 0, "rmem_patch_merge_ln: bad argument");
+  return RMEM_API(rmem_patch_merge_ln_images)(x, 1, H, W, C, gamma, beta, eps, y_bf16, stream);
+}
+
+extern "C" int RMEM_API(rmem_patch_merge_ln_images)(const float* x, int images, int H, int W, int C, const float* gamma, const float* beta, float eps,
+                                          void* y_bf16, void* stream) {
+  RMEM_REQUIRE(x && gamma && beta && y_bf16 && H > 0 && W > 0 && images >= 1, "rmem_patch_merge_ln: bad argument");
   const int M = ((H + 1) / 2) * ((W + 1) / 2);
-  const dim3 g((M + 3) / 4), b(256);
+  const dim3 g((M + 3) / 4, images), b(256);
   hipStream_t s = (hipStream_t)stream;
   if (C == 128) hipLaunchKernelGGL(k_patch_merge_ln<128>, g, b, 0, s, x, H, W, gamma, beta, eps, (e16*)y_bf16);
   else if (C == 256) hipLaunchKernelGGL(k_patch_merge_ln<256>, g, b, 0, s, x, H, W, gamma, beta, eps, (e16*)y_bf16);

@@ -56,12 +56,15 @@ __device__ __forceinline__ e16x8 load8(const WinParams& p, int tok, int col) {
   return v;
 }
 
-__global__ __launch_bounds__(128) void k_window_attn(WinParams p) {
+__global__ __launch_bounds__(128) void k_window_attn(WinParams pin) {
+  WinParams p = pin;
   __shared__ __attribute__((aligned(16))) e16 Ks[64 * D];
   __shared__ __attribute__((aligned(16))) e16 Vs[64 * D];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lq = lane & 31, lh = lane >> 5;
   const int win = blockIdx.x, head = blockIdx.y;
+  p.qkv += (long)blockIdx.z * p.H * p.W * 3 * p.C;       // blockIdx.z = image of a batch (rows [image][token])
+  p.out += (long)blockIdx.z * p.H * p.W * p.C;
   const int wy = win / p.nwx, wx = win - wy * p.nwx;
   const int type = p.shift > 0 ? ((wy == p.nwy - 1) ? 2 : 0) + ((wx == p.nwx - 1) ? 1 : 0) : 0;
 
@@ -153,9 +156,16 @@ __global__ __launch_bounds__(128) void k_window_attn(WinParams p) {
 
 }  // namespace
 
+extern "C" int RMEM_API(rmem_window_attn_images)(const void* qkv, const float* qkv_bias, const float* bias_mask_table, void* out, int images,
+                                       int H, int W, int C, int heads, int shift, void* stream);
 extern "C" int RMEM_API(rmem_window_attn)(const void* qkv, const float* qkv_bias, const float* bias_mask_table, void* out, int H, int W,
                                 int C, int heads, int shift, void* stream) {
-  RMEM_REQUIRE(qkv && qkv_bias && bias_mask_table && out, "rmem_window_attn: null argument");
+  return RMEM_API(rmem_window_attn_images)(qkv, qkv_bias, bias_mask_table, out, 1, H, W, C, heads, shift, stream);
+}
+
+extern "C" int RMEM_API(rmem_window_attn_images)(const void* qkv, const float* qkv_bias, const float* bias_mask_table, void* out, int images,
+                                       int H, int W, int C, int heads, int shift, void* stream) {
+  RMEM_REQUIRE(qkv && qkv_bias && bias_mask_table && out && images >= 1, "rmem_window_attn: null argument");
   RMEM_REQUIRE(H > 0 && W > 0 && heads >= 1 && C == heads * D, "rmem_window_attn: C must equal heads * 32");
   RMEM_REQUIRE(shift == 0 || shift == WS / 2, "rmem_window_attn: shift must be 0 or 3");
   WinParams p;
@@ -163,6 +173,6 @@ extern "C" int RMEM_API(rmem_window_attn)(const void* qkv, const float* qkv_bias
   p.H = H; p.W = W; p.C = C; p.heads = heads; p.shift = shift;
   p.nwy = (H + WS - 1) / WS; p.nwx = (W + WS - 1) / WS;
   p.qscale = 1.4426950408889634f / sqrtf((float)D);
-  hipLaunchKernelGGL(k_window_attn, dim3(p.nwy * p.nwx, heads), dim3(128), 0, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(k_window_attn, dim3(p.nwy * p.nwx, heads, images), dim3(128), 0, (hipStream_t)stream, p);
   return rmem_check_launch("rmem_window_attn");
 }

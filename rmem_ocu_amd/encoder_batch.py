@@ -87,8 +87,8 @@ class SwinBatchEncoder:
     """Swin-B (cfg 5; encoders/swin/swin_transformer.py:500-716) over B frames: the look-ahead counterpart of
     ClipRuntime._prog_encode_swin.  One 720x1280 frame leaves only 3600 tokens for the 18 blocks of stage 3, so its linears are
     GEMMs of 3600 rows and its LayerNorms launches of 3.7 MB; with B frames stacked as rows [frame][token] every linear and
-    LayerNorm is ONE launch over B times the rows (weights are shared, rows independent).  Window attention and patch merging
-    depend on the image geometry and have no image dimension: they run once per frame on that frame's rows.  Same kernels, same
+    LayerNorm is ONE launch over B times the rows (weights are shared, rows independent); window attention and patch merging
+    depend on the image geometry and take the frame as a grid dimension.  Same kernels, same
     operands per row as the per-frame encoder; interface of BatchEncoder (img_in, prog(), enc_out)."""
 
     def __init__(self, P: Dict[str, torch.Tensor], in_hw: Tuple[int, int], batch: int, device):
@@ -139,9 +139,8 @@ class SwinBatchEncoder:
                 d = f'sw{li}.{b}'
                 o.append(ops.layernorm(x, P[d + '.norm1.g'], P[d + '.norm1.b'], M=B * M, C=C, y=ln))
                 o.append(self._lin(ln, d + '.qkv', qkv, B * M, C, 3 * C))
-                for f in range(B):      # windows are cut per image
-                    o.append(ops.window_attn(qkv[f * M * 3 * C:], P[d + '.qkv.b'], P[d + '.table'], att[f * M * C:], H=h, W=w, C=C,
-                                             heads=heads, shift=0 if b % 2 == 0 else 3))
+                o.append(ops.window_attn(qkv, P[d + '.qkv.b'], P[d + '.table'], att, H=h, W=w, C=C, heads=heads,
+                                         shift=0 if b % 2 == 0 else 3, images=B))      # windows are cut per image
                 o.append(self._lin(att, d + '.proj', x, B * M, C, C, residual=x))
                 o.append(ops.layernorm(x, P[d + '.norm2.g'], P[d + '.norm2.b'], M=B * M, C=C, y=ln))
                 o.append(self._lin(ln, d + '.fc1', mlp, B * M, C, 4 * C, relu=2))
@@ -150,9 +149,7 @@ class SwinBatchEncoder:
             if li < len(SWIN_DEPTHS) - 1:
                 mg = self.smerge.view(-1)
                 h2, w2 = (h + 1) // 2, (w + 1) // 2
-                for f in range(B):
-                    o.append(ops.patch_merge_ln(x[f * M * C:], P[f'sw{li}.merge.g'], P[f'sw{li}.merge.b'], mg[f * h2 * w2 * 4 * C:],
-                                                H=h, W=w, C=C))
+                o.append(ops.patch_merge_ln(x, P[f'sw{li}.merge.g'], P[f'sw{li}.merge.b'], mg, H=h, W=w, C=C, images=B))
                 h, w = h2, w2
                 o.append(ops.linear(mg, P[f'sw{li}.merge.w'], None, x, M=B * h * w, K=4 * C, N=2 * C, ws=self.conv_ws))
                 C *= 2

@@ -211,19 +211,23 @@ def layernorm(a, gamma, beta, *, M, C, lda=None, y=None, ldy=None, yf=None, ldyf
     return Op(_fn('rmem_layernorm', dt), args, 'rmem_layernorm', (a, gamma, beta, y, yf))
 
 
-def patch_merge_ln(x, gamma, beta, y, *, H, W, C, eps=1e-5) -> Op:
+def patch_merge_ln(x, gamma, beta, y, *, H, W, C, eps=1e-5, images=1) -> Op:
+    """images > 1: x fp32 [images][H][W][C] -> y [images][ceil(H/2) * ceil(W/2)][4C]."""
     _dev(x, gamma, beta, y)
     dt = y.dtype
     assert x.dtype == F32 and y.dtype == dt and gamma.numel() == 4 * C
-    return Op(_fn('rmem_patch_merge_ln', dt), (_ptr(x), H, W, C, _ptr(gamma), _ptr(beta), eps, _ptr(y)), 'rmem_patch_merge_ln', (x, gamma, beta, y))
+    return Op(_fn('rmem_patch_merge_ln_images', dt), (_ptr(x), images, H, W, C, _ptr(gamma), _ptr(beta), eps, _ptr(y)), 'rmem_patch_merge_ln',
+              (x, gamma, beta, y))
 
 
-def window_attn(qkv, qkv_bias, table, out, *, H, W, C, heads, shift) -> Op:
+def window_attn(qkv, qkv_bias, table, out, *, H, W, C, heads, shift, images=1) -> Op:
+    """images > 1: qkv [images][H * W][3C], out [images][H * W][C] (windows never cross images)."""
     _dev(qkv, qkv_bias, table, out)
     dt = qkv.dtype
     assert qkv.dtype == dt and out.dtype == dt and qkv_bias.dtype == F32 and table.dtype == F32
     assert qkv_bias.numel() == 3 * C and table.numel() == 4 * heads * 49 * 49 and table.is_contiguous()
-    return Op(_fn('rmem_window_attn', dt), (_ptr(qkv), _ptr(qkv_bias), _ptr(table), _ptr(out), H, W, C, heads, shift),
+    assert qkv.numel() >= images * H * W * 3 * C and out.numel() >= images * H * W * C
+    return Op(_fn('rmem_window_attn_images', dt), (_ptr(qkv), _ptr(qkv_bias), _ptr(table), _ptr(out), images, H, W, C, heads, shift),
               'rmem_window_attn', (qkv, qkv_bias, table, out))
 
 
