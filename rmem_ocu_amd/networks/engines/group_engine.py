@@ -304,3 +304,4 @@ class GroupEngine:
 
     def synchronize(self):
         self.stream.synchronize()
+        self.enc_stream.synchronize()
