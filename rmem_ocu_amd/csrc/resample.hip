@@ -141,6 +141,73 @@ __global__ __launch_bounds__(256) void k_logits_labels4(const float* lg, int nc,
   }
 }
 
+// the same for >= 2 x upsampling (the path's 1/4-resolution logits): a workgroup makes a 16 x 64 tile of output pixels; the <= 10 x
+// 34 source pixels under it go to LDS once (16 floats each) and the four taps of every output pixel are LDS reads -- per output
+// pixel the one-pixel-per-thread form issued 256 bytes of cached global loads.  Same arithmetic per pixel.
+constexpr int LT_H = 16, LT_W = 64, LT_SRC = 12 * 40;
+__global__ __launch_bounds__(256) void k_logits_labels_tile(const float* lg, int nc, int keep, int Hi, int Wi, int Ho, int Wo, int align,
+                                                            uint8_t* label, float* label_f32) {
+  __shared__ __attribute__((aligned(16))) float src[LT_SRC * 16];
+  const int tiles_x = (Wo + LT_W - 1) / LT_W;
+  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+  const long total = (long)Ho * Wo;
+  lg += (long)blockIdx.y * Hi * Wi * 16;
+  if (label) label += (long)blockIdx.y * total;
+  if (label_f32) label_f32 += (long)blockIdx.y * total;
+  const int oy0 = ty * LT_H, ox0 = tx * LT_W;
+  const int oy1 = min(oy0 + LT_H, Ho) - 1, ox1 = min(ox0 + LT_W, Wo) - 1;
+  int ylo, yhi, xlo, xhi, t0, t1; float tw;
+  src_coord(oy0, Hi, Ho, align, ylo, t1, tw);
+  src_coord(oy1, Hi, Ho, align, t0, yhi, tw);
+  src_coord(ox0, Wi, Wo, align, xlo, t1, tw);
+  src_coord(ox1, Wi, Wo, align, t0, xhi, tw);
+  const int ncols = xhi - xlo + 1, nrows = yhi - ylo + 1;      // (the host launches this kernel only where they fit LT_SRC)
+  for (int i = threadIdx.x; i < nrows * ncols * 4; i += 256) {
+    const int pix = i >> 2, q = i & 3;
+    const int r = pix / ncols, c = pix - r * ncols;
+    *reinterpret_cast<f32x4*>(&src[pix * 16 + 4 * q]) = *reinterpret_cast<const f32x4*>(lg + ((long)(ylo + r) * Wi + xlo + c) * 16 + 4 * q);
+  }
+  __syncthreads();
+  const int oy = oy0 + (threadIdx.x >> 4), oxb = ox0 + (threadIdx.x & 15) * 4;
+  if (oy >= Ho) return;
+  int y0, y1; float wy;
+  src_coord(oy, Hi, Ho, align, y0, y1, wy);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int ox = oxb + k;
+    if (ox >= Wo) break;
+    int x0, x1; float wx;
+    src_coord(ox, Wi, Wo, align, x0, x1, wx);
+    const float* a = &src[((y0 - ylo) * ncols + (x0 - xlo)) * 16];
+    const float* b = &src[((y0 - ylo) * ncols + (x1 - xlo)) * 16];
+    const float* c = &src[((y1 - ylo) * ncols + (x0 - xlo)) * 16];
+    const float* d = &src[((y1 - ylo) * ncols + (x1 - xlo)) * 16];
+    float best = -3.0e38f; int arg = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 ta = *reinterpret_cast<const f32x4*>(a + 4 * q), tb = *reinterpret_cast<const f32x4*>(b + 4 * q);
+      const f32x4 tc = *reinterpret_cast<const f32x4*>(c + 4 * q), td = *reinterpret_cast<const f32x4*>(d + 4 * q);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int ch = 4 * q + j;
+        if (ch < nc) {
+          float v;
+          if (ch > keep) v = -1.0e10f;
+          else {
+            const float top = ta[j] * (1.f - wx) + tb[j] * wx;
+            const float bot = tc[j] * (1.f - wx) + td[j] * wx;
+            v = top * (1.f - wy) + bot * wy;
+          }
+          if (v > best) { best = v; arg = ch; }
+        }
+      }
+    }
+    const long i = (long)oy * Wo + ox;
+    if (label) label[i] = (uint8_t)arg;
+    if (label_f32) label_f32[i] = (float)arg;
+  }
+}
+
 // logits NHWC fp32 [Hi][Wi][ldl] -> NCHW fp32 [nc][Ho][Wo] (optional) + argmax labels (optional)
 __global__ __launch_bounds__(256) void k_logits_post(const float* lg, int ldl, int nc, int keep, int Hi, int Wi, int Ho, int Wo,
                                                      int align, float* out, uint8_t* label, float* label_f32) {
@@ -487,7 +554,10 @@ extern "C" int rmem_logits_post_images(const float* logits_nhwc, int images, int
   RMEM_REQUIRE(logits_nhwc && images >= 1 && num_classes >= 1 && num_classes <= 16 && ldl >= num_classes, "rmem_logits_post: bad argument");
   RMEM_REQUIRE(out_nchw || label_u8 || label_f32, "rmem_logits_post: no output requested");
   RMEM_REQUIRE(images == 1 || !out_nchw, "rmem_logits_post: a batch of images produces labels only");
-  if (ldl == 16 && !out_nchw && ((uintptr_t)logits_nhwc % 16) == 0)
+  if (ldl == 16 && !out_nchw && ((uintptr_t)logits_nhwc % 16) == 0 && Ho >= 2 * Hi && Wo >= 2 * Wi)
+    hipLaunchKernelGGL(k_logits_labels_tile, dim3(((Ho + LT_H - 1) / LT_H) * ((Wo + LT_W - 1) / LT_W), images), dim3(256), 0, (hipStream_t)stream,
+                       logits_nhwc, num_classes, keep_max_id, Hi, Wi, Ho, Wo, align_corners, label_u8, label_f32);
+  else if (ldl == 16 && !out_nchw && ((uintptr_t)logits_nhwc % 16) == 0)
     hipLaunchKernelGGL(k_logits_labels4, dim3(nblk((long)Ho * ((Wo + 3) / 4)), images), dim3(256), 0, (hipStream_t)stream, logits_nhwc,
                        num_classes, keep_max_id, Hi, Wi, Ho, Wo, align_corners, label_u8, label_f32);
   else
