@@ -71,6 +71,16 @@ WORKLOADS = {
                                 dtype='fp16'),
     # cfg 2 geometry with a skewed clip list (mixed lengths): exercises the feeder's length buckets and queue
     'davis17_480p_r50_N8_mixed': dict(model='r50_aotl', video=(480, 854), lengths=(100, 80, 60, 40), clips_per_gpu=64, objs=3, former=1, latter=7, net=None),
+    # cfg 3 geometry and protocol: 720p -> network size 577x1041 (HW = 2442), 36-frame clips, a NEW OBJECT's mask arrives at frame
+    # 15 of every clip (managers/evaluator.py:484-508: the frame is re-added as a reference frame, the bank restarts at one entry)
+    'ytvos_720p_r50_N8_inject': dict(model='r50_aotl', video=(720, 1280), lengths=(36,), clips_per_gpu=64, objs=2, former=1, latter=7, net=None,
+                                     inject_at=15),
+    # cfg 4 geometry: 1080p -> 577x1041, 600-frame clips (gap = 20), one object; restricted bank N = 8 against the unbounded bank
+    # (tools/eval.py:92, latter_mem_len = 9999: T grows to 30) -- the stress case of the memory-read kernel
+    'vost_1080p_r50_N8': dict(model='r50_aotl', video=(1080, 1920), lengths=(600,), clips_per_gpu=24, objs=1, former=1, latter=7, net=None,
+                              distinct_frames=100),
+    'vost_1080p_r50_unbounded': dict(model='r50_aotl', video=(1080, 1920), lengths=(600,), clips_per_gpu=24, objs=1, former=1, latter=9999,
+                                     net=None, distinct_frames=100, roofline_T=(8, 30)),
 }
 
 
@@ -156,6 +166,9 @@ def parse_args(argv=None):
     ap.add_argument('--dtype', default=None, choices=['bf16', 'fp16'],
                     help="16-bit operand type of the kernels (cfg.MODEL_DTYPE); default: the workload's (bf16; fp16 for the cfg-5 workload)")
     ap.add_argument('--roofline-launches', type=int, default=32, help='isolated T = 8 memory-read launches timed after the timed region')
+    ap.add_argument('--drain', action='store_true',
+                    help='run the WHOLE job once instead of a --steps window (non-cyclic clip list: a rank that finds the list empty '
+                         'idles): value = propagated frames of all ranks / the slowest rank\'s seconds, tail and imbalance included')
     return ap.parse_args(argv)
 
 
@@ -177,17 +190,19 @@ def main():
     local_rank %= ndev                      # RMEM_SHARE_GPU=1: rehearse the N > 1 code path on fewer GPUs (gloo backend)
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    dist = None
+    dist, store = None, None
     if world > 1:
         import torch.distributed as dist
+        from rmem_ocu_amd.clip_runner import open_job_store
+        store = open_job_store(rank, world)     # one explicit c10d store: the process group's and the clip queue's
         backend = os.environ.get('RMEM_DIST_BACKEND', 'nccl')       # nccl == RCCL over xGMI on ROCm
         if backend == 'nccl':
-            dist.init_process_group('nccl', device_id=dev)
+            dist.init_process_group('nccl', store=store, rank=rank, world_size=world, device_id=dev)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, store=store, rank=rank, world_size=world)
 
     from rmem_ocu_amd import _lib, build_engine, build_vos_model, get_config
-    from rmem_ocu_amd.clip_runner import ClipFeeder, ClipSlot, pump
+    from rmem_ocu_amd.clip_runner import DRAIN, ClipFeeder, ClipSlot, pump
     from rmem_ocu_amd.synth import make_clip, network_size
     from rmem_ocu_amd.weights import synth_state_dict
 
@@ -206,12 +221,14 @@ def main():
     # ---- the job: clips_per_gpu * world clips, lengths cycling through wl['lengths'] (whole groups per length) ----
     per_len = max(G, (wl['clips_per_gpu'] * world // len(wl['lengths'])) // G * G)
     lengths = [n for n in wl['lengths'] for _ in range(per_len)]
-    feeder = ClipFeeder(lengths, rank, world, group=G, mode=args.feeder, cyclic=True)
+    feeder = ClipFeeder(lengths, rank, world, group=G, mode=args.feeder, store=store, cyclic=True)
     max_len = max(lengths)
 
     # clip CONTENT: two distinct synthetic clips per rank at the longest length (a clip id maps to one of them, truncated to
     # its own length): an 80-frame fp32 clip is 392 MB on the device, the clip list itself is only ids and lengths
-    clips_host = [make_clip(1000 * rank + j, max_len, net_hw[0], net_hw[1], NUM_OBJS) for j in range(2)]
+    # (long clips: wl['distinct_frames'] generated frames played forwards and backwards up to the clip length)
+    n_gen = min(max_len, wl.get('distinct_frames', max_len))
+    clips_host = [make_clip(1000 * rank + j, n_gen, net_hw[0], net_hw[1], NUM_OBJS) for j in range(2)]
     if args.host_frames:
         # decoded video frames as a loader would hand them over: uint8 RGB [n, Hs, Ws, 3] at the VIDEO size in pinned memory;
         # every frame crosses PCIe (1.2 MB) and is resized + normalised on the device (rmem_ingest_rgb8)
@@ -223,10 +240,22 @@ def main():
             clips.append((u8, m.to(dev)))
     else:
         clips = [(f.to(dev), m.to(dev)) for f, m in clips_host]
+    if n_gen < max_len:
+        pingpong = (list(range(n_gen)) + list(range(n_gen - 2, 0, -1))) * (max_len // n_gen + 1)
+        idx = torch.tensor(pingpong[:max_len])
+        clips = [(f[idx] if f.is_cuda else f[idx].pin_memory(), m) for f, m in clips]
 
     def clip_data(cid):
         f, m = clips[cid % 2]
         return f[:lengths[cid]], m
+
+    inject_at = wl.get('inject_at')
+    new_obj = None
+    if inject_at is not None:           # the new object's label map at the output size: one rectangle, label objs + 1
+        if G <= 1 or args.host_frames:
+            raise SystemExit(f'--workload {args.workload}: the new-object protocol runs on clip groups fed from HBM')
+        new_obj = torch.zeros(VIDEO_HW[0], VIDEO_HW[1], dtype=torch.uint8, device=dev)
+        new_obj[VIDEO_HW[0] // 2:VIDEO_HW[0] // 2 + VIDEO_HW[0] // 4, VIDEO_HW[1] // 8:VIDEO_HW[1] // 8 + VIDEO_HW[1] // 5] = NUM_OBJS + 1
 
     # frames the encoder runs ahead (0 = default: 2 with clip groups -- 8 images per launch --, 4 for single clips)
     lookahead = args.encoder_lookahead or (2 if G > 1 else 4)      # ResNet-50: encoder_batch.BatchEncoder, Swin-B: SwinBatchEncoder
@@ -243,8 +272,12 @@ def main():
 
         def start(s):
             ids = feeder.next_unit()
+            if ids is None:
+                return False                     # the job's list is drained (--drain): this slot idles
             data = [clip_data(i) for i in ids]
-            s.start([d[0] for d in data], [d[1] for d in data], NUM_OBJS)
+            s.start([d[0] for d in data], [d[1] for d in data], NUM_OBJS,
+                    new_objects=None if new_obj is None else {c: (inject_at, new_obj) for c in range(len(ids))})
+            return True
     else:
         for j in range(C):
             eng = build_engine(cfg.MODEL_ENGINE, phase='eval', aot_model=model, gpu_id=local_rank, long_term_mem_gap=5)
@@ -253,7 +286,11 @@ def main():
         inner_of = lambda s: s.engine.aot_engines[0]                             # noqa: E731
 
         def start(s):
-            s.start(*clip_data(feeder.next_unit()[0]), NUM_OBJS)
+            ids = feeder.next_unit()
+            if ids is None:
+                return False
+            s.start(*clip_data(ids[0]), NUM_OBJS)
+            return True
 
     # ---- priming (untimed setup): every slot runs one whole clip, interleaved exactly like the timed region, which builds
     # every launch list / hipGraph (T = 1..8); then the slots are staggered so they sit at different clip positions ----
@@ -263,33 +300,51 @@ def main():
         for s in slots:
             if not s.done:
                 s.step()
-    for s in slots:
-        start(s)
-    n0 = min(lengths)
-    for k in range(n0 - 1):
-        for j, s in enumerate(slots):
-            if k < (j * (n0 - 1)) // C and not s.done:
-                s.step()
-    torch.cuda.synchronize()
+    if args.drain:
+        # the whole job once, from empty slots: a fresh NON-cyclic list (its own ticket counter), every slot takes units until
+        # the list is empty and then idles; the priming pass above was the warm-up
+        feeder = ClipFeeder(lengths, rank, world, group=G, mode=args.feeder, store=store, cyclic=False)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        enc0 = sum(s.frames_encoded for s in slots)
+        t0 = time.perf_counter()
+        pump(slots, start, DRAIN, G)
+        # propagated frames this rank ran (frame 0 of a clip is its reference frame): from the units it actually took
+        args.steps = sum(len(feeder.units[u]) * (lengths[feeder.units[u][0]] - 1) for u in feeder.history)
+        host_enqueue = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+    else:
+        for s in slots:
+            start(s)
+        n0 = min(lengths)
+        for k in range(n0 - 1):
+            for j, s in enumerate(slots):
+                if k < (j * (n0 - 1)) // C and not s.done:
+                    s.step()
+        torch.cuda.synchronize()
 
-    def run_steps(n):
-        """n propagated frames in total (a group step propagates G frames); a finished slot takes the job's next unit."""
-        pump(slots, start, n, G)
+        def run_steps(n):
+            """n propagated frames in total (a group step propagates G frames); a finished slot takes the job's next unit."""
+            pump(slots, start, n, G)
 
-    run_steps(args.warmup)
-    torch.cuda.synchronize()
+        run_steps(args.warmup)
+        torch.cuda.synchronize()
 
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    enc0 = sum(s.frames_encoded for s in slots)
-    t0 = time.perf_counter()
-    run_steps(args.steps)
-    host_enqueue = time.perf_counter() - t0
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        enc0 = sum(s.frames_encoded for s in slots)
+        t0 = time.perf_counter()
+        run_steps(args.steps)
+        host_enqueue = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
     enc_in_window = sum(s.frames_encoded for s in slots) - enc0
 
     checksum = float(sum(int(s.labels.sum().item()) for s in slots))
@@ -300,12 +355,14 @@ def main():
     # ---- roofline leg, after (and outside) the timed region: isolated launches of the dominant kernel under HIP events ----
     L = _lib.lib()
     roof = {'achieved': None, 'frac': None, 'launches_timed': 0, 'avg_launch_us': None, 't_mix': {}}
+    by_T = {}
     if rank == 0 and args.roofline_launches > 0:
         inner = inner_of(slots[0])
         inner.stream.synchronize()
         torch.cuda.synchronize()
         s_int = inner.stream.cuda_stream
         ms, fl, nl = ctypes.c_double(), ctypes.c_double(), ctypes.c_int()
+        by_T = {}
         if deaot:       # the dominant kernel of this workload is the value-side GEMM of the long-term gated attention
             T = wl['former'] + wl['latter']
             op, _ = inner.rt.mem_read_probe(T)
@@ -318,16 +375,22 @@ def main():
                 inner.stream.synchronize()
             _lib.check(L.rmem_gated_profile_stop(ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(nl)), 'rmem_gated_profile_stop')
         else:
-            T = wl['former'] + wl['latter']
-            op, _ = inner.rt.mem_read_probe(T)
-            for _ in range(3):              # untimed: instruction cache, TLB
-                op(s_int)
-            inner.stream.synchronize()
-            _lib.check(L.rmem_profile_start(args.roofline_launches + 4), 'rmem_profile_start')
-            for _ in range(args.roofline_launches):
-                op(s_int)
-                inner.stream.synchronize()      # alone on the GPU: the event bracket is the kernel's own duration
-            _lib.check(L.rmem_profile_stop(ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(nl)), 'rmem_profile_stop')
+            # bank sizes the workload actually reaches: N for a restricted bank; (8, 30) for the unbounded cfg-4 workload.  The LAST
+            # one measured is the line's `roofline` (the steady state / the stress case), all of them are in roofline.by_T
+            Ts = wl.get('roofline_T') or (wl['former'] + wl['latter'],)
+            for T in Ts:
+                op, _ = inner.rt.mem_read_probe(T)
+                for _ in range(3):              # untimed: instruction cache, TLB
+                    op(s_int)
+                inner.stream.synchronize()
+                _lib.check(L.rmem_profile_start(args.roofline_launches + 4), 'rmem_profile_start')
+                for _ in range(args.roofline_launches):
+                    op(s_int)
+                    inner.stream.synchronize()      # alone on the GPU: the event bracket is the kernel's own duration
+                _lib.check(L.rmem_profile_stop(ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(nl)), 'rmem_profile_stop')
+                if nl.value and ms.value > 0:
+                    by_T[str(T)] = {'achieved': round(fl.value / (ms.value * 1e-3) / 1e12, 2), 'avg_launch_us': round(1e3 * ms.value / nl.value, 2),
+                                    'launches_timed': nl.value}
         if nl.value and ms.value > 0:
             ach = (fl.value / (ms.value * 1e-3)) / 1e12
             roof = {'achieved': round(ach, 2), 'frac': round(ach / PEAK_BF16_TFLOPS, 4), 'launches_timed': nl.value,
@@ -340,7 +403,7 @@ def main():
         out = {
             'metric': 'frames/sec (whole node) 480p VOS, N=8 memory bank' if args.workload == 'davis17_480p_r50_N8'
             else f'frames/sec (whole node) {args.workload}', 'value': round(total_steps / elapsed, 2), 'unit': 'frames/s',
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * elapsed / args.steps, 4),
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * elapsed / max(args.steps, 1), 4),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': cfg.MODEL_DTYPE, 'data': 'synthetic',
             'config': {'workload': args.workload, 'clip_frames': list(wl['lengths']) if len(wl['lengths']) > 1 else wl['lengths'][0],
                        'job_clips': len(lengths), 'clip_feeder': feeder.mode, 'video_hw': list(VIDEO_HW), 'network_hw': list(net_hw),
@@ -350,12 +413,15 @@ def main():
                        'frames_encoded_in_timed_region': enc_in_window,
                        'parallelism': f'clip-parallel x{world}', 'weights': 'synthetic (no checkpoint offline)',
                        'hipgraphs': not args.no_graphs, 'frames_from': 'pinned host uint8 (PCIe-inclusive)' if args.host_frames else 'HBM',
-                       'encoder_lookahead': lookahead, 'host_enqueue_ms_per_step': round(1e3 * host_enqueue / args.steps, 4)},
+                       'encoder_lookahead': lookahead, 'host_enqueue_ms_per_step': round(1e3 * host_enqueue / max(args.steps, 1), 4),
+                       'timed_region': 'whole job, drained (non-cyclic list)' if args.drain else 'window of --steps frames of a cyclic job',
+                       **({'new_object_at_frame': inject_at} if inject_at is not None else {})},
             'roofline': {'bound': 'mfma', 'kernel': 'k_gp_pv<1, true>' if deaot else 'k_attn_partial<true, true>',
                          'achieved': roof['achieved'], 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s', 'frac': roof['frac'],
                          'traffic': traffic, 'traffic_source': traffic_src, 'launches_timed': roof['launches_timed'],
                          'avg_launch_us': roof['avg_launch_us'], 't_mix': roof['t_mix'],
-                         'clips_per_launch': G, 'sampled': 'after the timed region, isolated direct launches'},
+                         'clips_per_launch': G, 'sampled': 'after the timed region, isolated direct launches',
+                         **({'by_T': by_T} if len(by_T) > 1 else {})},
         }
         if world == 1 and not args.no_cpu_baseline and args.workload == 'davis17_480p_r50_N8':
             out['cpu_baseline'] = cpu_baseline(*clips_host[0], VIDEO_HW)

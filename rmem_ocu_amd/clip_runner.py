@@ -57,21 +57,30 @@ class ClipFeeder:
                of tail (host-side work stealing; one ~50 us store round trip per CLIP, never per frame);
       'static' the longest-first greedy split of ``shard_clips`` computed identically on every rank (no store traffic).
 
-    ``cyclic``: after the last unit the list starts over (bench.py measures a fixed-length window of a long job)."""
+    ``cyclic``: after the last unit the list starts over (bench.py measures a fixed-length window of a long job).
+
+    ``store``: any c10d store shared by the ranks (bench.py passes the TCPStore its process group was initialised with); the
+    feeder works inside its own PrefixStore namespace, ``<key>/<n>`` for the n-th feeder this process created -- every rank
+    creates its feeders in the same order, so the n-th feeders of all ranks share one ticket counter that starts at zero, and
+    a second job in the same process group does not inherit the first one's tickets."""
+
+    _instances = 0
 
     def __init__(self, lengths: Sequence[int], rank: int = 0, world: int = 1, group: int = 1, mode: Optional[str] = None,
                  store=None, cyclic: bool = False, key: str = 'rmem_clip_queue'):
         self.lengths = [int(n) for n in lengths]
         self.units = group_units(self.lengths, group)
-        self.rank, self.world, self.cyclic, self.key = rank, world, cyclic, key
+        self.rank, self.world, self.cyclic = rank, world, cyclic
+        self.key = f'{key}/{ClipFeeder._instances}'
+        ClipFeeder._instances += 1
         self.mode = mode or ('queue' if world > 1 else 'static')
         if self.mode not in ('queue', 'static'):
             raise ValueError(f'ClipFeeder mode {self.mode!r}: expected "queue" or "static"')
         if self.mode == 'queue' and world > 1:
             if store is None:
-                import torch.distributed as dist
-                store = dist.distributed_c10d._get_default_store()
-            self.store = store
+                raise ValueError('ClipFeeder: the job-wide queue needs the c10d store the ranks share (store=...)')
+            import torch.distributed as dist
+            self.store = dist.PrefixStore(self.key, store)
         else:
             self.store = None
         unit_len = [self.lengths[u[0]] * len(u) for u in self.units]
@@ -83,7 +92,7 @@ class ClipFeeder:
         """Clip ids of the next unit for this rank, or None when the list is drained."""
         n = len(self.units)
         if self.store is not None:
-            t = int(self.store.add(self.key, 1)) - 1                  # job-wide ticket
+            t = int(self.store.add('ticket', 1)) - 1                  # job-wide ticket
             if t >= n and not self.cyclic:
                 return None
             u = t % n
@@ -96,12 +105,24 @@ class ClipFeeder:
         return self.units[u]
 
 
+def open_job_store(rank: int, world: int):
+    """The c10d store of this job, opened explicitly from MASTER_ADDR / MASTER_PORT (``env://`` rendezvous: under
+    torch.distributed.run it is a client of the launcher's TCPStore, otherwise rank 0 hosts it).  bench.py hands the SAME store
+    to ``init_process_group(store=...)`` and to ClipFeeder, so nothing reaches into the process group's internals."""
+    import torch.distributed as dist
+    store, _, _ = next(iter(dist.rendezvous('env://', rank, world)))
+    return store
+
+
+DRAIN = 1 << 62
+
+
 def pump(slots: Sequence, start_fn, steps: int, frames_per_step: int = 1) -> int:
     """Advance the slots round-robin until ``steps`` propagated frames have been enqueued (one slot step = ``frames_per_step``
     frames: the clips of a group move together).  A slot whose clip has ended takes the next unit of the job through
     ``start_fn(slot)`` (reference frames: executed, not counted); start_fn returns False when the list is drained, the slot then
-    idles.  Returns the frames actually enqueued (< steps only if every slot ran dry).  Host-side only: nothing here waits for
-    the GPU."""
+    idles.  Returns the frames actually enqueued (< steps only if every slot ran dry: ``steps = DRAIN`` runs the job to its end,
+    bench.py --drain).  Host-side only: nothing here waits for the GPU."""
     done, j, idle = 0, 0, 0
     n = len(slots)
     while done < steps and idle < n:
@@ -111,6 +132,7 @@ def pump(slots: Sequence, start_fn, steps: int, frames_per_step: int = 1) -> int
             idle += 1
             continue
         if s.done:                      # a unit of single-frame clips: nothing to propagate
+            idle = 0
             continue
         idle = 0
         s.step()
@@ -316,7 +338,10 @@ class GroupSlot:
                 for k in range(m):
                     ops.copy_async(dst[k * B + c], self.frames[c][i + k], fb)(s)
 
-    def step(self):
+    def step(self, feed: Optional[torch.Tensor] = None):
+        """Propagate frame ``cursor`` of every clip, deliver its labels and update the memories.  feed: uint8 [B, Ho, Wo] device
+        labels that go into the memory update INSTEAD of the prediction (the delivered labels stay the prediction): given masks,
+        e.g. the reference's own in the parity tests, so that every frame is an independent comparison."""
         eng, B, i = self.engine, self.B, self.cursor
         la = eng.lookahead
         s = eng.stream.cuda_stream
@@ -335,6 +360,10 @@ class GroupSlot:
                     imgs = torch.cat([f[i:i + 1] for f in self.frames], 0)
             eng.propagate_to_labels(self.cur_label, imgs=imgs)
         inject = [c for c, (fi, _) in self.new_objects.items() if fi == i]
+        nb = self.cur_label[0].numel()                # frame i of every clip's label stack: one pitched copy
+        if feed is not None:                          # deliver the prediction, then continue from the given labels
+            ops.copy2d_async(self.labels.view(-1)[i * nb:], self.labels.shape[1] * nb, self.cur_label, nb, nb, B)(s)
+            ops.copy_async(self.cur_label, feed.contiguous(), B * nb)(s)
         if inject:
             with torch.cuda.stream(eng.stream):
                 for c in inject:                      # the new object's label over the prediction (evaluator.py:484-497)
@@ -343,7 +372,7 @@ class GroupSlot:
         eng.update_from_labels(self.cur_label, skip=inject)
         for c in inject:
             eng.add_reference_frame_for(c, self.frames[c][i], self.cur_label[c])
-        nb = self.cur_label[0].numel()                # frame i of every clip's label stack: one pitched copy
-        ops.copy2d_async(self.labels.view(-1)[i * nb:], self.labels.shape[1] * nb, self.cur_label, nb, nb, B)(s)
+        if feed is None:
+            ops.copy2d_async(self.labels.view(-1)[i * nb:], self.labels.shape[1] * nb, self.cur_label, nb, nb, B)(s)
         self.cursor += 1
         self.done = self.cursor >= self.frames[0].shape[0]

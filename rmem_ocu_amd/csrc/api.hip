@@ -91,6 +91,7 @@ struct ProfState {
   std::vector<hipEvent_t> ev;   // pairs
   std::vector<double> flops;
   size_t used = 0;
+  size_t cap = 0;               // launches this start() allows (the event pool may be larger from an earlier start)
 };
 ProfState g_prof[2];
 
@@ -104,6 +105,7 @@ int prof_start(ProfState& st, int max_launches, const char* who) {
   }
   st.flops.assign(max_launches, 0.0);
   st.used = 0;
+  st.cap = (size_t)max_launches;
   // calibrate what two event records around ONE launch cost by themselves: bracket an empty kernel on an idle stream,
   // keep the minimum of 32 trials; stop() subtracts it from every timed launch
   hipStream_t cs;
@@ -145,6 +147,7 @@ int prof_stop(ProfState& st, double* total_ms, double* total_flops, int* launche
 }  // namespace
 
 int rmem_prof_begin(int channel, void* stream, double flops) {
+  if (channel < 0 || channel > 1) return -1;
   ProfState& st = g_prof[channel];
   if (!st.on.load(std::memory_order_relaxed)) return -1;
   hipStream_t s = (hipStream_t)stream;
@@ -154,14 +157,14 @@ int rmem_prof_begin(int channel, void* stream, double flops) {
   int slot = -1;
   {
     std::lock_guard<std::mutex> lk(st.mu);
-    if (st.on.load() && st.used * 2 + 1 < st.ev.size()) { slot = (int)st.used++; st.flops[slot] = flops; }
+    if (st.on.load() && st.used < st.cap) { slot = (int)st.used++; st.flops[slot] = flops; }
   }
   if (slot >= 0) (void)hipEventRecord(st.ev[2 * slot], s);
   return slot;
 }
 
 void rmem_prof_end(int channel, int slot, void* stream) {
-  if (slot >= 0) (void)hipEventRecord(g_prof[channel].ev[2 * slot + 1], (hipStream_t)stream);
+  if (channel >= 0 && channel <= 1 && slot >= 0) (void)hipEventRecord(g_prof[channel].ev[2 * slot + 1], (hipStream_t)stream);
 }
 
 extern "C" int rmem_profile_start(int max_launches) { return prof_start(g_prof[RMEM_PROF_MEM_READ], max_launches, "rmem_profile_start: hipEventCreate failed"); }

@@ -52,12 +52,12 @@ __device__ __forceinline__ float wave_max(float v) {
 
 // source coordinate of destination index d of a bilinear resize (PyTorch upsample_bilinear2d semantics)
 // (explicit fmaf: every caller must get the same coordinates and blend whatever -ffp-contract chooses around the call)
-__device__ __forceinline__ void rmem_src_coord(int d, int in, int out, int align, int& i0, int& i1, float& w1) {
+__host__ __device__ __forceinline__ void rmem_src_coord(int d, int in, int out, int align, int& i0, int& i1, float& w1) {
   float s;
   if (align) s = out > 1 ? (float)d * ((float)(in - 1) / (float)(out - 1)) : 0.f;
-  else s = fmaxf(__builtin_fmaf((float)d + 0.5f, (float)in / (float)out, -0.5f), 0.f);
-  i0 = min((int)s, in - 1);
-  i1 = min(i0 + 1, in - 1);
+  else s = __builtin_fmaxf(__builtin_fmaf((float)d + 0.5f, (float)in / (float)out, -0.5f), 0.f);
+  i0 = (int)s < in - 1 ? (int)s : in - 1;
+  i1 = i0 + 1 < in - 1 ? i0 + 1 : in - 1;
   w1 = s - (float)i0;
 }
 // bilinear blend of the four taps, one fixed operation sequence (rmem_bilinear_nhwc and the GEMM's resized residual)

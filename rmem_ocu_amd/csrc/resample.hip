@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void k_logits_labels_tile(const float* lg, int
   src_coord(oy1, Hi, Ho, align, t0, yhi, tw);
   src_coord(ox0, Wi, Wo, align, xlo, t1, tw);
   src_coord(ox1, Wi, Wo, align, t0, xhi, tw);
-  const int ncols = xhi - xlo + 1, nrows = yhi - ylo + 1;      // (the host launches this kernel only where they fit LT_SRC)
+  const int ncols = xhi - xlo + 1, nrows = yhi - ylo + 1;      // <= LT_SRC source pixels: lt_tiles_fit() on the host checked every tile
   for (int i = threadIdx.x; i < nrows * ncols * 4; i += 256) {
     const int pix = i >> 2, q = i & 3;
     const int r = pix / ncols, c = pix - r * ncols;
@@ -206,6 +206,22 @@ __global__ __launch_bounds__(256) void k_logits_labels_tile(const float* lg, int
     if (label) label[i] = (uint8_t)arg;
     if (label_f32) label_f32[i] = (float)arg;
   }
+}
+
+// host side of k_logits_labels_tile: the source pixels under EVERY output tile (same rmem_src_coord as the kernel) fit its LDS tile
+bool lt_tiles_fit(int Hi, int Wi, int Ho, int Wo, int align) {
+  int rows = 0, cols = 0, lo, hi, t; float w;
+  for (int o0 = 0; o0 < Ho; o0 += LT_H) {
+    rmem_src_coord(o0, Hi, Ho, align, lo, t, w);
+    rmem_src_coord((o0 + LT_H < Ho ? o0 + LT_H : Ho) - 1, Hi, Ho, align, t, hi, w);
+    rows = hi - lo + 1 > rows ? hi - lo + 1 : rows;
+  }
+  for (int o0 = 0; o0 < Wo; o0 += LT_W) {
+    rmem_src_coord(o0, Wi, Wo, align, lo, t, w);
+    rmem_src_coord((o0 + LT_W < Wo ? o0 + LT_W : Wo) - 1, Wi, Wo, align, t, hi, w);
+    cols = hi - lo + 1 > cols ? hi - lo + 1 : cols;
+  }
+  return rows * cols <= LT_SRC;
 }
 
 // logits NHWC fp32 [Hi][Wi][ldl] -> NCHW fp32 [nc][Ho][Wo] (optional) + argmax labels (optional)
@@ -554,7 +570,7 @@ extern "C" int rmem_logits_post_images(const float* logits_nhwc, int images, int
   RMEM_REQUIRE(logits_nhwc && images >= 1 && num_classes >= 1 && num_classes <= 16 && ldl >= num_classes, "rmem_logits_post: bad argument");
   RMEM_REQUIRE(out_nchw || label_u8 || label_f32, "rmem_logits_post: no output requested");
   RMEM_REQUIRE(images == 1 || !out_nchw, "rmem_logits_post: a batch of images produces labels only");
-  if (ldl == 16 && !out_nchw && ((uintptr_t)logits_nhwc % 16) == 0 && Ho >= 2 * Hi && Wo >= 2 * Wi)
+  if (ldl == 16 && !out_nchw && ((uintptr_t)logits_nhwc % 16) == 0 && Ho >= 2 * Hi && Wo >= 2 * Wi && lt_tiles_fit(Hi, Wi, Ho, Wo, align_corners))
     hipLaunchKernelGGL(k_logits_labels_tile, dim3(((Ho + LT_H - 1) / LT_H) * ((Wo + LT_W - 1) / LT_W), images), dim3(256), 0, (hipStream_t)stream,
                        logits_nhwc, num_classes, keep_max_id, Hi, Wi, Ho, Wo, align_corners, label_u8, label_f32);
   else if (ldl == 16 && !out_nchw && ((uintptr_t)logits_nhwc % 16) == 0)

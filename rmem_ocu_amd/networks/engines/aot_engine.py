@@ -190,12 +190,13 @@ class AOTEngine:
         if mask is None:
             print('No mask for reference frame!')
             exit()
+        # a deferred eviction belongs to the bank that is about to be reset, but its effect on long_memories_indexes
+        # (the reference keeps that list across the reset, aot_engine.py:323) and on the policy state must still happen --
+        # against the runtime it was issued on: a frame of another size replaces self.rt below
+        self._resolve_pending()
         rt = self._ensure_runtime(img)
         if self.input_size_2d is None:
             self.update_size(img.shape[2:], (rt.H16, rt.W16))
-        # a deferred eviction belongs to the bank that is about to be reset, but its effect on long_memories_indexes
-        # (the reference keeps that list across the reset, aot_engine.py:323) and on the policy state must still happen
-        self._resolve_pending()
         with self._scope():
             self._copy_in(self.img_in, img.reshape(3, rt.H, rt.W))
             self._set_label(mask)

@@ -7,7 +7,7 @@ O=gpurun_out/final
 timeout -k 10 900 python -m pytest tests -m gpu -q > $O/gpu_tests.log 2>&1
 rc=$?
 tail -4 $O/gpu_tests.log
-if [ $rc -gt 1 ]; then exit $rc; fi
+if [ $rc -ne 0 ]; then echo "GPU tier failed (rc $rc): no evidence is recorded from a tree whose tests fail"; exit $rc; fi
 timeout -k 10 300 python bench.py --steps 20 --warmup 5 > $O/bench_driver_form.json 2> $O/bench_driver_form.err || { echo bench failed; tail -20 $O/bench_driver_form.err; exit 1; }
 cat $O/bench_driver_form.json
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o bench -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_driver_form_under_rocprof.json 2> $O/rocprof.err || { echo rocprof bench failed; tail -20 $O/rocprof.err; exit 1; }

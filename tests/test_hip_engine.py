@@ -626,6 +626,68 @@ def test_group_engine_matches_per_clip_engines():
         assert (ge.long_memories_indexes(c), ge.drop_trace[c]) == ref_traces[c]
 
 
+@pytest.mark.parametrize('name', ['clip_full.npz', 'clip_full_fitted.npz'])
+def test_group_engine_bench_path_vs_reference_fixture(name):
+    """The path bench.py times -- GroupEngine + GroupSlot, 4 clips per group, hipGraphs, encoder look-ahead 2 on the side stream,
+    label-only post-processing -- at BENCH GEOMETRY (480x854 -> 481x849, bank N = 8) against the reference's own golden clip
+    (managers/evaluator.py:385-441, 509-523; engines/aot_engine.py:438-465).  All four clips of the group are the fixture's clip;
+    the reference's labels are fed back (GroupSlot.step(feed=...)), so every frame is an independent comparison: per-frame labels,
+    mask IoU, the 1/4-resolution logits resized like the reference does (at the fixture's sample points) and the bank index trace
+    must match the fixture with the per-clip tests' tolerances, for every clip of the group."""
+    if not os.path.exists(os.path.join(GOLDEN, name)):
+        pytest.skip(f'{name} not generated')
+    fitted = 'fitted' in name
+    if fitted and not os.path.exists(os.path.join(GOLDEN, 'trained_delta.pt')):
+        pytest.skip('fitted weights missing')
+    from rmem_ocu_amd import build_vos_model, get_config
+    from rmem_ocu_amd.clip_runner import GroupSlot
+    from rmem_ocu_amd.networks.engines.group_engine import GroupEngine
+    from rmem_ocu_amd.weights import fitted_state_dict, synth_state_dict
+    g, frames, mask, (former, latter, n, h, w, oh, ow, gap, objs) = _load(name)
+    assert (h, w, oh, ow, former + latter) == (481, 849, 480, 854, 8)
+    dev = torch.device('cuda', 0)
+    B = 4
+    cfg = get_config('pre_vost', 'test', 'r50_aotl')
+    cfg.FORMER_MEM_LEN, cfg.LATTER_MEM_LEN = former, latter
+    model = build_vos_model(cfg.MODEL_VOS, cfg).cuda(0)
+    model.load_state_dict(fitted_state_dict(0) if fitted else synth_state_dict(0))
+    ge = GroupEngine(model, B, 0, gap, lookahead=2)
+    assert ge.use_graphs
+    gs = GroupSlot(ge, (oh, ow), dev)
+    fd = frames.to(dev)
+    gs.start([fd] * B, [mask.to(dev)] * B, int(mask.max()))
+    ge.long_term_mem_gap = gap              # (GroupSlot.start sets the evaluator's gap for the clip length; the fixture names its own)
+    ys, xs = torch.from_numpy(g['sample_y']).to(dev), torch.from_numpy(g['sample_x']).to(dev)
+    gold = torch.from_numpy(g['labels']).to(dev)[:, None].expand(-1, B, -1, -1).contiguous()     # [n - 1, B, oh, ow]
+    torch.cuda.synchronize()                # (the engine reads `feed` on its own stream)
+    samples, traces = [], [[] for _ in range(B)]
+    rt = ge.rt
+    while not gs.done:
+        i = gs.cursor
+        gs.step(feed=gold[i - 1])
+        ge.synchronize()
+        lg = rt.logits.view(B, rt.H4, rt.W4, 16)[..., :11].permute(0, 3, 1, 2)
+        up = F.interpolate(lg, size=(oh, ow), mode='bilinear', align_corners=True)       # aot_engine.py:455-458
+        samples.append(up[:, :, ys, xs].cpu().numpy())
+        for c in range(B):
+            traces[c].append(list(ge.long_memories_indexes(c)))
+    got = gs.labels[:, 1:n].cpu().numpy()
+    samples = np.stack(samples, 1)                      # [B, n - 1, 11, points]
+    ref = g['logit_samples']
+    for c in range(B):
+        assert (_trace_matrix(traces[c], g['indexes']) == g['indexes']).all(), c
+        err = np.abs(samples[c] - ref).max()
+        agree = (got[c] == g['labels']).mean()
+        ious = [_iou(a, b) for a, b in zip(g['labels'], got[c])]
+        print(f'{name} group clip {c}: max |dlogit| {err:.4f} at logit std {ref.std():.2f}, label agreement {agree:.5f}, mean IoU {np.mean(ious):.5f}')
+        if fitted:
+            assert err < 0.035 * ref.std() and np.mean(ious) >= 0.99 and agree >= 0.999
+        else:
+            assert err < 0.065 * ref.std() and agree > 0.97
+    # the four clips ran the same inputs through one launch: identical labels
+    assert all(np.array_equal(got[0], got[c]) for c in range(1, B))
+
+
 def _per_clip_reference(former, latter, gap, frames, mask, objs, out_hw, new_object=None):
     """One clip through the drop-in per-clip engine with the evaluator's protocol (propagate -> argmax -> update, or re-add the
     frame as a reference frame when a new object's mask arrives, managers/evaluator.py:484-508): labels and the bank trace."""

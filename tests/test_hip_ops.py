@@ -446,6 +446,43 @@ def test_resample_kernels(dev):
     torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize('geom', [(121, 213, 480, 854, True), (41, 49, 160, 192, True), (120, 214, 480, 856, False),
+                                  (25, 33, 40, 50, True)])
+def test_logits_label_only_routes_vs_fp32(dev, geom):
+    """The LABEL-ONLY route of rmem_logits_post_images -- what every group step of the throughput path runs (k_logits_labels_tile
+    for >= 2x upsampling, k_logits_labels4 below that) -- against F.interpolate + argmax in fp32 (engines/aot_engine.py:450-463,
+    managers/evaluator.py:430-441): 4 images per launch, ids above `keep` masked, bench geometry 121x213 -> 480x854 included.
+    Labels must be equal except where the two best interpolated logits are within fp32 rounding of each other (the kernel blends
+    rows then columns with its own operation order)."""
+    from rmem_ocu_amd import ops
+    Hi, Wi, Ho, Wo, ac = geom
+    B, nc, keep = 4, 11, 6
+    lg = seeded(97 + Hi, (B, nc, Hi, Wi)) * 3.0
+    lgn = torch.zeros(B, Hi * Wi, 16)
+    lgn[:, :, :nc] = lg.permute(0, 2, 3, 1).reshape(B, -1, nc)
+    lab = torch.full((B, Ho, Wo), 255, dtype=torch.uint8, device=dev)
+    labf = torch.full((B, Ho, Wo), -1.0, dtype=F32, device=dev)
+    ops.run(ops.logits_post(lgn.to(dev), ldl=16, nc=nc, keep=keep, Hi=Hi, Wi=Wi, Ho=Ho, Wo=Wo, align_corners=ac, label_u8=lab,
+                            label_f32=labf, images=B))
+    torch.cuda.synchronize()
+    ref = lg.clone()
+    ref[:, keep + 1:] = -1e10
+    up = F.interpolate(ref.double(), size=(Ho, Wo), mode='bilinear', align_corners=ac)
+    top2 = up.topk(2, dim=1).values
+    tie = (top2[:, 0] - top2[:, 1]) < 1e-5 * up[:, :keep + 1].abs().amax(1).clamp_min(1.0)
+    got = lab.cpu().long()
+    assert (got <= keep).all()
+    assert torch.equal(got.float(), labf.cpu())
+    bad = (got != up.argmax(1)) & ~tie
+    assert not bad.any(), f'{int(bad.sum())} labels differ away from ties ({int(tie.sum())} near-ties among {tie.numel()})'
+    # one image at a time gives the same labels (clip c of a group = the per-clip engine's call)
+    one = torch.zeros(Ho, Wo, dtype=torch.uint8, device=dev)
+    for c in (0, B - 1):
+        ops.run(ops.logits_post(lgn[c].to(dev), ldl=16, nc=nc, keep=keep, Hi=Hi, Wi=Wi, Ho=Ho, Wo=Wo, align_corners=ac, label_u8=one))
+        assert torch.equal(one, lab[c])
+    torch.cuda.synchronize()
+
+
 def test_label_onehot_and_id_bank(dev, synth_weights):
     """a11: label -> nearest resize -> one-hot -> 17x17 s16 conv against the oracle's assign_identity."""
     from oracle import ref_cpu as O

@@ -42,9 +42,13 @@ class _StubSlot:
 
 def _worker(rank, world, port, lengths, group, mode, q):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    dist.init_process_group('gloo', rank=rank, world_size=world)
-    from rmem_ocu_amd.clip_runner import ClipFeeder, gather_stats, pump
-    feeder = ClipFeeder(lengths, rank, world, group=group, mode=mode)
+    from rmem_ocu_amd.clip_runner import DRAIN, ClipFeeder, gather_stats, open_job_store, pump
+    store = open_job_store(rank, world)                # the way bench.py does it: one explicit store for the group and the queue
+    dist.init_process_group('gloo', store=store, rank=rank, world_size=world)
+    first = ClipFeeder(lengths, rank, world, group=group, mode=mode, store=store)
+    if mode == 'queue':                                # an earlier job of the same process group must not eat this job's tickets
+        assert first.next_unit() is not None
+    feeder = ClipFeeder(lengths, rank, world, group=group, mode=mode, store=store)
     slots = [_StubSlot(0.002 * (1 + 3 * rank)) for _ in range(2)]       # rank 1 is 4x slower
     frames = [0]
 
@@ -56,14 +60,18 @@ def _worker(rank, world, port, lengths, group, mode, q):
         frames[0] += sum(lengths[i] - 1 for i in ids)                   # propagated frames (frame 0 is the reference frame)
         return True
 
+    import time
     dist.barrier()
-    pump(slots, start, 10 ** 9, group)
+    t0 = time.perf_counter()
+    ran = pump(slots, start, DRAIN, group)              # bench.py --drain: the whole list once, idle when it is empty
+    busy = time.perf_counter() - t0
+    assert ran >= frames[0]                             # pump counts whole groups; a remainder unit holds fewer clips
     mine = [i for s in slots for u in s.ran for i in u]
     checksum = float(sum((i + 1) * lengths[i] for i in mine))
     dist.barrier()
     out = gather_stats(float(frames[0]), 1.0 + rank, checksum, dist, rank, world, torch.device('cpu'))
     counts = [None] * world
-    dist.all_gather_object(counts, (len(mine), sorted(mine)))
+    dist.all_gather_object(counts, (len(mine), sorted(mine), busy))
     if rank == 0:
         q.put((out, counts))
     dist.destroy_process_group()
@@ -72,7 +80,14 @@ def _worker(rank, world, port, lengths, group, mode, q):
 @pytest.mark.parametrize('mode', ['queue', 'static'])
 def test_two_rank_feeder_pump_and_gather(mode):
     # static: a skewed list (one clip is 40 % of the job); queue: many similar units, so the faster rank must end up with more
-    lengths = [36, 80, 600, 12, 90, 300, 45, 45, 80, 80, 36, 36] if mode == 'static' else [40, 36] * 16
+    _run_two_ranks(mode, [36, 80, 600, 12, 90, 300, 45, 45, 80, 80, 36, 36] if mode == 'static' else [40, 36] * 16)
+
+
+def _drain_rate(mode):
+    return _run_two_ranks(mode, [40, 36] * 16)
+
+
+def _run_two_ranks(mode, lengths):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
@@ -93,6 +108,17 @@ def test_two_rank_feeder_pump_and_gather(mode):
         f0 = sum(lengths[i] for i in counts[0][1])
         f1 = sum(lengths[i] for i in counts[1][1])
         assert f0 > f1, (f0, f1)
+    return total_frames / max(c[2] for c in counts)               # bench.py --drain's value: all frames / the slowest rank's seconds
+
+
+def test_drained_job_shows_what_the_queue_buys():
+    """The same list of similar clips drained by a fast and a 4x slower rank: with the static split both get half of the frames
+    and the slow rank sets the time; with the ticket queue the fast rank takes most of the list.  Only a drain-the-job
+    measurement (bench.py --drain) can show that -- a fixed window per rank cannot."""
+    static = _drain_rate('static')
+    queue = _drain_rate('queue')
+    print(f'drained job: static {static:.0f} frames/s, queue {queue:.0f} frames/s')
+    assert queue > 1.3 * static, (queue, static)
 
 
 def test_group_units_and_static_feeder_single_rank():

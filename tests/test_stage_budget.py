@@ -37,11 +37,17 @@ def _nhwc(t: torch.Tensor) -> torch.Tensor:
     return t[0].permute(1, 2, 0).reshape(-1, t.shape[1]).contiguous()
 
 
-# (stage, max bound, rms bound) = ~1.5x the MI355X measurement of this build
-BOUNDS = {
-    'clip_small_fitted.npz': None,
-    'clip_full_fitted.npz': None,
-}
+def _committed_budget(name: str, dtype: str):
+    """The newest committed MI355X measurement of this clip / flavour (profiles/rNN/stage_budget_<clip>_<dtype>.json, written by this
+    test itself into gpurun_out/ and copied from there): every stage's cumulative and intrinsic error is held to 1.5x its rms
+    and 2x its maximum (the maximum of a few million elements moves more from run to run than the rms)."""
+    prof = os.path.join(ROOT, 'profiles')
+    for rnd in sorted((d for d in os.listdir(prof) if d.startswith('r')), reverse=True):
+        f = os.path.join(prof, rnd, f'stage_budget_{name[:-4]}_{dtype}.json')
+        if os.path.exists(f):
+            with open(f) as fh:
+                return json.load(fh)['stages'], f
+    return None, None
 
 
 @pytest.mark.parametrize('dtype', ['bf16', 'fp16'])
@@ -156,11 +162,12 @@ def test_stage_error_budget(name, dtype):
     with open(os.path.join(out, f'stage_budget_{name[:-4]}_{dtype}.json'), 'w') as fjs:
         json.dump({'clip': name, 'dtype': dtype, 'frame': n_run - 1, 'T': T, 'logit_std': ref_logits4.std().item(), 'label_flips': flips_cum,
                    'stages': table}, fjs, indent=1)
-    bounds = BOUNDS.get(name)
-    if bounds:
-        for st, (mx, rms) in bounds.items():
-            got = table[st]['cumulative']
-            assert got['max'] <= mx and got['rms'] <= rms, (st, got, mx, rms)
+    committed, src = _committed_budget(name, dtype)
+    assert committed is not None, f'no committed stage budget for {name} [{dtype}] under profiles/'
+    for st, r in committed.items():
+        for kind, ref in r.items():
+            got = table[st][kind]
+            assert got['rms'] <= 1.5 * ref['rms'] + 1e-5 and got['max'] <= 2.0 * ref['max'] + 1e-4, (st, kind, got, ref, src)
     # every stage must be at bf16 level: nothing may add more than 10 % rms of its own output scale
     for st, r in table.items():
         for kind, v in r.items():
