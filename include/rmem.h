@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define RMEM_ABI_VERSION 6
+#define RMEM_ABI_VERSION 7
 
 int rmem_abi_version(void);
 const char* rmem_last_error_string(void);
@@ -128,6 +128,20 @@ int rmem_mem_read_attn_clips(const void* q, int ldq, const void* k_bank, const v
                              long long q_clip_stride, long long kv_clip_stride, long long out_clip_stride,
                              void* workspace, void* stream);
 
+/* The long-term memory read AND the short-term attention of an LSTT block (layers/transformer.py:632-635, 656-662) as ONE launch:
+ * both use the same queries (curr_Q) and are independent of each other, so the short-term attention's workgroups ride behind the
+ * memory read's as extra grid slices (every XCD gets its share of both) instead of a second launch that starts on an empty
+ * GPU.  The memory read is exactly rmem_mem_read_attn_clips with a chunk table (out_long, attn_mass); the second attention
+ * is softmax(Q K_short^T / sqrt(32)) V_short over lk_short keys of one frame per clip ([lk_short][ldkv] rows, clip c at
+ * c * kv_short_clip_stride), no temporal embedding, written to out_short ([Lq][ldo] rows, clip c at c * out_short_clip_stride).
+ * Results are bit-identical to the two separate launches. */
+int rmem_lstt_attn_pair_clips(const void* q, int ldq, const void* k_bank, const void* v_bank, long long slot_stride, int ldkv,
+                              const rmem_attn_chunk* chunks, int nchunks, int lk_total, const float* pe_cur, const float* pe_mem,
+                              int Lq, int heads, void* out_long, int ldo, float* attn_mass, int T, int nclips,
+                              long long q_clip_stride, long long out_clip_stride,
+                              const void* k_short, const void* v_short, int lk_short, long long kv_short_clip_stride,
+                              void* out_short, long long out_short_clip_stride, void* workspace, void* stream);
+
 /* Optional timing of the memory-read launches (chunks != NULL) with HIP events on the launch stream:
  * between start and stop every such launch outside a graph capture is bracketed by two events;
  * start() also calibrates what an event bracket costs around an empty kernel and stop() subtracts that per launch;
@@ -149,6 +163,54 @@ int rmem_layernorm256(const void* a, int a_is_f32, int lda, const void* b, int b
  * [M][256] bf16 contiguous.  Replaces the two norm4 calls of layers/transformer.py:659-660. */
 int rmem_layernorm256_pair(const void* a0, const void* b0, void* y0, const void* a1, const void* b1, void* y1,
                            const float* gamma, const float* beta, float eps, int M, void* stream);
+
+/* ------------------------------------------------------------------ LSTT block chains (row-local sequences as ONE launch)
+ * Between its three attentions an LSTT block (layers/transformer.py:553-692) is a sequence of row-local operations on the
+ * [tokens][256] residual stream.  Each entry point below runs one such sequence for all rows of `clips` clips of L tokens
+ * (rows are [clip][token], everything contiguous unless a leading dimension is given), a workgroup owning 32 consecutive
+ * tokens of one clip with the rows resident in LDS; results are bit-identical to the same sequence of rmem_conv2d_nhwc /
+ * rmem_layernorm256 / rmem_layernorm256_pair launches (same accumulation order, same points of rounding).
+ * Weights are 16-bit [N][K] matrices (nn.Linear layout) re-packed once in FRAGMENT ORDER: [N / 256][4][K / 32][4][64][8] =
+ * [column block][wave][k chunk][column tile j][lane][8 consecutive k], element (n, k) with n = 256 nb + 64 wave + 16 j + (lane & 15),
+ * k = 32 kc + 8 (lane >> 4) + e (rmem_ocu_amd/pack.py::pack_frag), so that a wave reads one MFMA B fragment as 1 KiB of
+ * contiguous memory.  Biases and LayerNorm parameters are fp32; every pointer must be 16-byte aligned.
+ *
+ * chain A, after the self attention (transformer.py:571-576, 659-660):
+ *   x += att . w_proj^T + b_proj;  curr_v = LN2(x);  curr_q = curr_v . w_q^T + b_q;
+ *   k4 = LN4(short_k + curr_q);  v4 = LN4(short_v + curr_v) */
+typedef struct rmem_chain_a_desc {
+  int L, clips; float eps; int reserved;
+  const void* att; float* x;
+  const void* w_proj; const float* b_proj; const float* ln2_g; const float* ln2_b; void* curr_v;
+  const void* w_q; const float* b_q; void* curr_q;
+  const void* short_k; const void* short_v; const float* ln4_g; const float* ln4_b; void* k4; void* v4;
+} rmem_chain_a_desc;
+int rmem_lstt_chain_a(const rmem_chain_a_desc* d, void* stream);
+
+/* chain B, after the long-term and the short-term attention (transformer.py:635, 662, 673-685):
+ *   x += att_long . w_long^T + b_long;  tgt3 = att_short . w_short^T + b_short;  x += tgt3;  h1 = LN3(x) . w1^T + b1   ([rows][1024])
+ * gn_partial (optional): per-row-block (sum, sum of squares) of h1 over each of the 32 GroupNorm groups of 32 channels,
+ * fp32 [clips][32][gn_splits][2], entry `split` = the row block (gn_splits >= ceil(L / 32); the caller keeps the unused
+ * entries zero): the statistics rmem_gn_act_dwconv5x5_partials_nhwc_images finalises (layers/basic.py:27-35). */
+typedef struct rmem_chain_b_desc {
+  int L, clips; float eps; int gn_splits;
+  const void* att_long; const void* att_short; float* x;
+  const void* w_long; const float* b_long; const void* w_short; const float* b_short; void* tgt3;
+  const float* ln3_g; const float* ln3_b; const void* w1; const float* b1; void* h1; float* gn_partial;
+} rmem_chain_b_desc;
+int rmem_lstt_chain_b(const rmem_chain_b_desc* d, void* stream);
+
+/* chain C, after GroupNorm + GELU + depth-wise 5x5 (transformer.py:685-687, 250-259; 565-569 of the NEXT block):
+ *   h3 != NULL:     x += h3 . w2^T + b2  (h3 [rows][1024]);  dec_out[row * ld_dec + 0..255] = LN_dec(x)
+ *   w_qkv != NULL:  qkv = LN1'(x) . w_qkv^T + b_qkv + pos_qk  ([rows][768]; pos_qk fp32 [rows][768]) of the next block
+ * (h3 == NULL: the first block of the stack, x as the projector left it; w_qkv == NULL: the last block). */
+typedef struct rmem_chain_c_desc {
+  int L, clips; float eps; int ld_dec;
+  float* x;
+  const void* h3; const void* w2; const float* b2; const float* dec_g; const float* dec_b; void* dec_out;
+  const float* ln1_g; const float* ln1_b; const void* w_qkv; const float* b_qkv; const float* pos_qk; void* qkv;
+} rmem_chain_c_desc;
+int rmem_lstt_chain_c(const rmem_chain_c_desc* d, void* stream);
 
 /* LayerNorm over C in {128, 256, 512, 1024} channels; bf16 and/or fp32 output.  Replaces the nn.LayerNorm call sites of the
  * Swin-B encoder (encoders/swin/swin_transformer.py:266, 318, 354, 538, 704).  Rows move as 8 / 16-byte vectors: lda, ldy, ldyf
@@ -342,6 +404,7 @@ int rmem_graph_destroy(void* graph_exec);
 int rmem_conv2d_nhwc_f16(const rmem_conv_desc* desc, const void* x, const void* w, const float* bias, const void* residual, void* y, void* y2, void* workspace, void* stream);
 int rmem_mem_read_attn_f16(const void* q, int ldq, const void* k_bank, const void* v_bank, long long slot_stride, int ldkv, const rmem_attn_chunk* chunks, int nchunks, int lk_single, const float* pe_cur, const float* pe_mem, int Lq, int heads, void* out, int ldo, float* attn_mass, int T, void* workspace, void* stream);
 int rmem_mem_read_attn_clips_f16(const void* q, int ldq, const void* k_bank, const void* v_bank, long long slot_stride, int ldkv, const rmem_attn_chunk* chunks, int nchunks, int lk_single, const float* pe_cur, const float* pe_mem, int Lq, int heads, void* out, int ldo, float* attn_mass, int T, int nclips, long long q_clip_stride, long long kv_clip_stride, long long out_clip_stride, void* workspace, void* stream);
+int rmem_lstt_attn_pair_clips_f16(const void* q, int ldq, const void* k_bank, const void* v_bank, long long slot_stride, int ldkv, const rmem_attn_chunk* chunks, int nchunks, int lk_total, const float* pe_cur, const float* pe_mem, int Lq, int heads, void* out_long, int ldo, float* attn_mass, int T, int nclips, long long q_clip_stride, long long out_clip_stride, const void* k_short, const void* v_short, int lk_short, long long kv_short_clip_stride, void* out_short, long long out_short_clip_stride, void* workspace, void* stream);
 int rmem_layernorm256_f16(const void* a, int a_is_f32, int lda, const void* b, int b_is_f32, int ldb, const float* gamma, const float* beta, float eps, int M, void* y_bf16, int ldy, const float* pos, void* ypos_bf16, int ldyp, float* y_f32, int ldyf, void* stream);
 int rmem_layernorm_f16(const void* a, int a_is_f32, int lda, const float* gamma, const float* beta, float eps, int M, int C, void* y_bf16, int ldy, float* y_f32, int ldyf, void* stream);
 int rmem_patch_merge_ln_f16(const float* x, int H, int W, int C, const float* gamma, const float* beta, float eps, void* y_bf16, void* stream);
@@ -350,6 +413,9 @@ int rmem_window_attn_images_f16(const void* qkv, const float* qkv_bias, const fl
 int rmem_patch_merge_ln_images_f16(const float* x, int images, int H, int W, int C, const float* gamma, const float* beta, float eps, void* y_bf16, void* stream);
 int rmem_add16_f16(const void* a, const void* b, void* y, long long n, void* stream);
 int rmem_add16_grouped_f16(int n, const void* const* a, const void* const* b, void* const* y, long long count, void* stream);
+int rmem_lstt_chain_a_f16(const rmem_chain_a_desc* d, void* stream);
+int rmem_lstt_chain_b_f16(const rmem_chain_b_desc* d, void* stream);
+int rmem_lstt_chain_c_f16(const rmem_chain_c_desc* d, void* stream);
 int rmem_layernorm256_pair_f16(const void* a0, const void* b0, void* y0, const void* a1, const void* b1, void* y1, const float* gamma, const float* beta, float eps, int M, void* stream);
 int rmem_conv1x1_dual_nhwc_f16(const rmem_conv_desc* desc, const void* x, const void* x2, int H2, int W2, int Cin2, int stride2, const void* w_cat, const float* bias, void* y, void* stream);
 int rmem_linear_grouped_f16(const rmem_conv_desc* desc, int n, const void* const* x, const void* const* w, const float* const* bias, const void* const* residual, void* const* y, void* stream);

@@ -11,7 +11,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('RMEM_LIB_PATH') or os.path.join(_HERE, 'librmem_hip.so')   # override: kernel experiments only
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class RmemError(RuntimeError):
@@ -30,6 +30,21 @@ class AttnChunk(C.Structure):
 
 
 _vp, _i, _ll, _f = C.c_void_p, C.c_int, C.c_longlong, C.c_float
+
+
+def _desc(name, ints, ptrs):
+    """ctypes mirror of an rmem_chain_*_desc: (int, int, float, int) header + device pointers, in include/rmem.h's order."""
+    return type(name, (C.Structure,), {'_fields_': [(ints[0], _i), (ints[1], _i), ('eps', _f), (ints[2], _i)] + [(n, _vp) for n in ptrs]})
+
+
+ChainA = _desc('ChainA', ('L', 'clips', 'reserved'),
+               ('att', 'x', 'w_proj', 'b_proj', 'ln2_g', 'ln2_b', 'curr_v', 'w_q', 'b_q', 'curr_q', 'short_k', 'short_v', 'ln4_g', 'ln4_b',
+                'k4', 'v4'))
+ChainB = _desc('ChainB', ('L', 'clips', 'gn_splits'),
+               ('att_long', 'att_short', 'x', 'w_long', 'b_long', 'w_short', 'b_short', 'tgt3', 'ln3_g', 'ln3_b', 'w1', 'b1', 'h1',
+                'gn_partial'))
+ChainC = _desc('ChainC', ('L', 'clips', 'ld_dec'),
+               ('x', 'h3', 'w2', 'b2', 'dec_g', 'dec_b', 'dec_out', 'ln1_g', 'ln1_b', 'w_qkv', 'b_qkv', 'pos_qk', 'qkv'))
 # name -> (restype, argtypes); the list is checked against include/rmem.h by tests/test_abi.py
 SIGNATURES = {
     'rmem_abi_version': (_i, []),
@@ -49,6 +64,9 @@ SIGNATURES = {
     'rmem_add16': (_i, [_vp, _vp, _vp, _ll, _vp]),
     'rmem_add16_grouped': (_i, [_i, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), _ll, _vp]),
     'rmem_layernorm256_pair': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _vp]),
+    'rmem_lstt_chain_a': (_i, [C.POINTER(ChainA), _vp]),
+    'rmem_lstt_chain_b': (_i, [C.POINTER(ChainB), _vp]),
+    'rmem_lstt_chain_c': (_i, [C.POINTER(ChainC), _vp]),
     'rmem_conv1x1_dual_nhwc': (_i, [C.POINTER(ConvDesc), _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     'rmem_linear_grouped': (_i, [C.POINTER(ConvDesc), _i, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), _vp]),
     'rmem_groupnorm_workspace_bytes': (C.c_size_t, [_i]),
@@ -59,6 +77,8 @@ SIGNATURES = {
     'rmem_gn_act_dwconv5x5_nhwc_images': (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _f, _i, _vp, _vp, _vp, _vp]),
     'rmem_bilinear_nhwc_images': (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     'rmem_mem_read_attn_clips': (_i, [_vp, _i, _vp, _vp, _ll, _i, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _i, _ll, _ll, _ll, _vp, _vp]),
+    'rmem_lstt_attn_pair_clips': (_i, [_vp, _i, _vp, _vp, _ll, _i, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _i, _ll, _ll,
+                                       _vp, _vp, _i, _ll, _vp, _ll, _vp, _vp]),
     'rmem_gn_act_dwconv5x5_nhwc': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _f, _i, _vp, _vp, _vp, _vp]),
     'rmem_dwconv5x5_nhwc': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     'rmem_image_to_nhwc8': (_i, [_vp, _vp, _i, _i, _vp]),
@@ -92,8 +112,8 @@ SIGNATURES = {
 }
 
 # entry points with 16-bit operands exist twice: <name> (bfloat16) and <name>_f16 (IEEE half), same signature (include/rmem.h)
-F16_TWINS = ('rmem_conv2d_nhwc', 'rmem_mem_read_attn', 'rmem_mem_read_attn_clips', 'rmem_layernorm256', 'rmem_layernorm', 'rmem_patch_merge_ln',
-             'rmem_window_attn', 'rmem_window_attn_images', 'rmem_patch_merge_ln_images', 'rmem_add16', 'rmem_add16_grouped', 'rmem_layernorm256_pair', 'rmem_conv1x1_dual_nhwc', 'rmem_linear_grouped',
+F16_TWINS = ('rmem_conv2d_nhwc', 'rmem_mem_read_attn', 'rmem_mem_read_attn_clips', 'rmem_lstt_attn_pair_clips', 'rmem_layernorm256', 'rmem_layernorm', 'rmem_patch_merge_ln',
+             'rmem_window_attn', 'rmem_window_attn_images', 'rmem_patch_merge_ln_images', 'rmem_add16', 'rmem_add16_grouped', 'rmem_layernorm256_pair', 'rmem_lstt_chain_a', 'rmem_lstt_chain_b', 'rmem_lstt_chain_c', 'rmem_conv1x1_dual_nhwc', 'rmem_linear_grouped',
              'rmem_groupnorm_nhwc', 'rmem_groupnorm_f32_nhwc', 'rmem_groupnorm_nhwc_images', 'rmem_groupnorm_head_nhwc_images',
              'rmem_gn_act_dwconv5x5_nhwc_images', 'rmem_gn_act_dwconv5x5_nhwc', 'rmem_dwconv5x5_nhwc', 'rmem_image_to_nhwc8',
              'rmem_image_to_nhwc8_images', 'rmem_ingest_rgb8', 'rmem_maxpool3x3s2_nhwc', 'rmem_maxpool3x3s2_nhwc_images', 'rmem_bilinear_nhwc',

@@ -68,6 +68,11 @@ struct AttnParams {
   e16* out; int ldo;             // normalised e16 output (written here when ngroups == 1)
   // several clips in one launch (identical shapes; clip c's operands sit c * stride further, its table rows at c * nchunks)
   int nclips; long q_cs, kv_cs, out_cs, opart_cs, mlg_cs, ml_cs;
+  // a SECOND, independent attention of the same queries in the same launch (MEM flavour only): one plain key frame per clip
+  // (the short-term attention of an LSTT block, layers/transformer.py:656-662: same curr_Q, keys / values = the norm4 outputs),
+  // no temporal embedding, its own output.  n2 = clips of it (0: none); its workgroups are extra grid slices behind the
+  // memory read's, so the launch's tail is filled with them instead of a second launch starting from an empty GPU.
+  int n2; const e16* k2; const e16* v2; int lk2; long kv2_cs; e16* out2; long out2_cs;
 };
 
 struct Row { int slot, kb, kn, pe_slot; };
@@ -166,30 +171,55 @@ __global__ __launch_bounds__(256, RMEM_ATTN_WGS_PER_CU) void k_attn_partial(Attn
   // L2 each), so ids that are congruent mod 8 are made to walk (head, group) pairs contiguously -- all query tiles that
   // read the same K/V rows run on one XCD and share its L2 (speed only; any placement is correct).
   int qt, head, g;
+  bool second = false;                 // this workgroup belongs to the second (plain, one-frame) attention of the launch
   {
-    const int nq = p.nq, total = nq * p.heads * p.ngroups * p.nclips;
+    const int nq = p.nq, total1 = nq * p.heads * p.ngroups * p.nclips;
     const int b = blockIdx.x, xcd = b & 7, j = b >> 3;
-    const int qd = total >> 3, rm = total & 7;
-    const int idx = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + j;
+    const int qd = total1 >> 3, rm = total1 & 7;
+    int idx = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + j;
+    if (MEM && p.n2 > 0) {
+      // every XCD gets its share of BOTH kinds: first its memory-read workgroups (j < n1), then second-attention ones; the
+      // launch has cnt(x) = total / 8 (+ 1) blocks on XCD x, of which n1(x) = total1 / 8 (+ 1) are memory-read blocks
+      const int total = total1 + nq * p.heads * p.n2, td = total >> 3, tr = total & 7;
+      const int n1 = qd + (xcd < rm ? 1 : 0);
+      if (j >= n1) {
+        second = true;
+        int start2 = 0;
+        for (int y = 0; y < xcd; ++y) start2 += td + (y < tr ? 1 : 0) - (qd + (y < rm ? 1 : 0));
+        idx = start2 + (j - n1);
+      }
+    }
     const int pair = idx / nq;
     qt = idx - pair * nq;
     head = pair % p.heads;
     const int rest = pair / p.heads;
-    g = rest % p.ngroups;
-    const int clip = rest / p.ngroups;
+    int clip;
+    if (second) {
+      g = 0; clip = rest;
+      p.k = p.k2 + clip * p.kv2_cs; p.v = p.v2 + clip * p.kv2_cs;
+      p.out = p.out2 + clip * p.out2_cs;
+      p.ml = nullptr; p.pe_cur = nullptr; p.pe_mem = nullptr;
+      p.nchunks = 1; p.rpg = 1;
+    } else {
+      g = rest % p.ngroups;
+      clip = rest / p.ngroups;
+      if (!MEM) { p.k += clip * p.kv_cs; p.v += clip * p.kv_cs; }
+      else p.chunks += clip * p.nchunks;          // bank slots in the table are global (clip * slots + slot)
+      p.opart += clip * p.opart_cs;
+      p.mlg += clip * p.mlg_cs;
+      if (p.ml) p.ml += clip * p.ml_cs;
+      p.out += clip * p.out_cs;
+    }
     p.q += clip * p.q_cs;
-    if (!MEM) { p.k += clip * p.kv_cs; p.v += clip * p.kv_cs; }
-    else p.chunks += clip * p.nchunks;          // bank slots in the table are global (clip * slots + slot)
-    p.opart += clip * p.opart_cs;
-    p.mlg += clip * p.mlg_cs;
-    if (p.ml) p.ml += clip * p.ml_cs;
-    p.out += clip * p.out_cs;
   }
+  const int ngroups = second ? 1 : p.ngroups;
   const int c0 = g * p.rpg, c1 = min(c0 + p.rpg, p.nchunks);
 
   auto row_info = [&](int c) -> Row {
     Row r;
-    if (MEM) {
+    if (MEM && second) {
+      r.slot = 0; r.kb = 0; r.kn = p.lk2; r.pe_slot = -1;
+    } else if (MEM) {
       // the table row is the same for the whole workgroup; say so (the row's descriptors must live in SGPRs, otherwise every
       // DMA is wrapped in a waterfall loop)
       const rmem_attn_chunk ch = p.chunks[c];
@@ -545,7 +575,7 @@ __global__ __launch_bounds__(256, RMEM_ATTN_WGS_PER_CU) void k_attn_partial(Attn
 #endif
   if (!wave_active) return;
 
-  if (p.ngroups == 1) {
+  if (ngroups == 1) {
     if (qg < p.Lq) {
       const float inv = 1.f / ltot;
       e16* o = p.out + (long)qg * p.ldo + head * D + 4 * lh;
@@ -694,11 +724,12 @@ static int attn_target_wgs() {
   return x > 0 ? x : 1792;
 }
 
-extern "C" int RMEM_API(rmem_mem_read_attn_clips)(const void* q, int ldq, const void* k_bank, const void* v_bank, long long slot_stride,
-                                        int ldkv, const rmem_attn_chunk* chunks, int nchunks, int lk_single,
-                                        const float* pe_cur, const float* pe_mem, int Lq, int heads, void* out, int ldo,
-                                        float* attn_mass, int T, int nclips, long long q_clip_stride, long long kv_clip_stride,
-                                        long long out_clip_stride, void* workspace, void* stream) {
+static int attn_launch(const void* q, int ldq, const void* k_bank, const void* v_bank, long long slot_stride,
+                       int ldkv, const rmem_attn_chunk* chunks, int nchunks, int lk_single,
+                       const float* pe_cur, const float* pe_mem, int Lq, int heads, void* out, int ldo,
+                       float* attn_mass, int T, int nclips, long long q_clip_stride, long long kv_clip_stride,
+                       long long out_clip_stride, void* workspace, void* stream,
+                       const void* k2, const void* v2, int lk2, long long kv2_clip_stride, void* out2, long long out2_clip_stride) {
   RMEM_REQUIRE(nclips >= 1 && nclips <= 64, "rmem_mem_read_attn: 1..64 clips");
   RMEM_REQUIRE(q_clip_stride % 8 == 0 && kv_clip_stride % 8 == 0 && out_clip_stride % 8 == 0, "rmem_mem_read_attn: clip strides must be multiples of 8 elements");
   const long long prof_keys = chunks ? (long long)lk_single : 0;   // with a row table lk_single carries the total key count (timing only)
@@ -734,7 +765,16 @@ extern "C" int RMEM_API(rmem_mem_read_attn_clips)(const void* q, int ldq, const 
   p.opart = (float*)workspace; p.mlg = p.opart + (size_t)nclips * p.opart_cs;
   p.ml = attn_mass ? p.mlg + (size_t)nclips * p.mlg_cs : nullptr;
   p.out = (e16*)out; p.ldo = ldo;
-  dim3 grid(p.nq * heads * p.ngroups * nclips);
+  p.n2 = 0; p.k2 = p.v2 = nullptr; p.lk2 = 0; p.kv2_cs = 0; p.out2 = nullptr; p.out2_cs = 0;
+  if (k2) {
+    RMEM_REQUIRE(chunks && v2 && out2 && lk2 > 0, "rmem_lstt_attn_pair: the second attention rides on a memory read (chunk table) and needs k2, v2, out2, lk2 > 0");
+    RMEM_REQUIRE(kv2_clip_stride % 8 == 0 && out2_clip_stride % 8 == 0 && ((uintptr_t)k2 % 16) == 0 && ((uintptr_t)v2 % 16) == 0,
+                 "rmem_lstt_attn_pair: second attention operands must be 16-byte aligned, strides multiples of 8 elements");
+    RMEM_REQUIRE(p.nq * heads * nclips >= 8, "rmem_lstt_attn_pair: launch too small for the per-XCD split");
+    p.n2 = nclips; p.k2 = (const e16*)k2; p.v2 = (const e16*)v2; p.lk2 = lk2; p.kv2_cs = kv2_clip_stride;
+    p.out2 = (e16*)out2; p.out2_cs = out2_clip_stride;
+  }
+  dim3 grid(p.nq * heads * (p.ngroups * nclips + p.n2));
   if (chunks) {
     // time this launch if asked to (rmem_profile_start; never while the stream is being captured into a graph)
     const int slot_i = prof_keys > 0 ? rmem_prof_begin(RMEM_PROF_MEM_READ, s, 4.0 * (double)Lq * (double)prof_keys * (double)(heads * D) * nclips)
@@ -752,6 +792,27 @@ extern "C" int RMEM_API(rmem_mem_read_attn_clips)(const void* q, int ldq, const 
   if (p.ngroups > 1) hipLaunchKernelGGL(k_attn_combine, dim3((Lq + 63) / 64, 16, nclips), dim3(256), 0, s, cp);
   if (attn_mass) hipLaunchKernelGGL(k_attn_mass, dim3((Lq + 63) / 64, 1, nclips), dim3(256), 0, s, cp);
   return rmem_check_launch("rmem_mem_read_attn");
+}
+
+extern "C" int RMEM_API(rmem_mem_read_attn_clips)(const void* q, int ldq, const void* k_bank, const void* v_bank, long long slot_stride,
+                                        int ldkv, const rmem_attn_chunk* chunks, int nchunks, int lk_single,
+                                        const float* pe_cur, const float* pe_mem, int Lq, int heads, void* out, int ldo,
+                                        float* attn_mass, int T, int nclips, long long q_clip_stride, long long kv_clip_stride,
+                                        long long out_clip_stride, void* workspace, void* stream) {
+  return attn_launch(q, ldq, k_bank, v_bank, slot_stride, ldkv, chunks, nchunks, lk_single, pe_cur, pe_mem, Lq, heads, out, ldo, attn_mass, T,
+                     nclips, q_clip_stride, kv_clip_stride, out_clip_stride, workspace, stream, nullptr, nullptr, 0, 0, nullptr, 0);
+}
+
+extern "C" int RMEM_API(rmem_lstt_attn_pair_clips)(const void* q, int ldq, const void* k_bank, const void* v_bank, long long slot_stride,
+                                         int ldkv, const rmem_attn_chunk* chunks, int nchunks, int lk_total,
+                                         const float* pe_cur, const float* pe_mem, int Lq, int heads, void* out_long, int ldo,
+                                         float* attn_mass, int T, int nclips, long long q_clip_stride, long long out_clip_stride,
+                                         const void* k_short, const void* v_short, int lk_short, long long kv_short_clip_stride,
+                                         void* out_short, long long out_short_clip_stride, void* workspace, void* stream) {
+  RMEM_REQUIRE(chunks && k_short && v_short && out_short, "rmem_lstt_attn_pair: null argument");
+  return attn_launch(q, ldq, k_bank, v_bank, slot_stride, ldkv, chunks, nchunks, lk_total, pe_cur, pe_mem, Lq, heads, out_long, ldo, attn_mass, T,
+                     nclips, q_clip_stride, 0, out_clip_stride, workspace, stream, k_short, v_short, lk_short, kv_short_clip_stride, out_short,
+                     out_short_clip_stride);
 }
 
 extern "C" int RMEM_API(rmem_mem_read_attn)(const void* q, int ldq, const void* k_bank, const void* v_bank, long long slot_stride,

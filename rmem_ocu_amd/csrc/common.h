@@ -50,6 +50,16 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// LayerNorm over a 256-channel row held by one wave, 4 consecutive channels per lane (rmem_layernorm256 and the LSTT chain
+// kernels share this one operation sequence, so fused and unfused routes round identically)
+__device__ __forceinline__ f32x4 rmem_ln256_row(f32x4 v, f32x4 g, f32x4 bt, float eps) {
+  const float mean = wave_sum(v[0] + v[1] + v[2] + v[3]) * (1.f / 256.f);
+  const f32x4 dv = v - mean;
+  const float var = wave_sum(dv[0] * dv[0] + dv[1] * dv[1] + dv[2] * dv[2] + dv[3] * dv[3]) * (1.f / 256.f);
+  const float rstd = rsqrtf(var + eps);
+  return dv * rstd * g + bt;
+}
+
 // source coordinate of destination index d of a bilinear resize (PyTorch upsample_bilinear2d semantics)
 // (explicit fmaf: every caller must get the same coordinates and blend whatever -ffp-contract chooses around the call)
 __host__ __device__ __forceinline__ void rmem_src_coord(int d, int in, int out, int align, int& i0, int& i1, float& w1) {

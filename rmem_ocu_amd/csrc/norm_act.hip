@@ -36,13 +36,9 @@ __device__ __forceinline__ void layernorm256_body(const LnParams& p) {
     const f32x4 w = load4(p.b, p.b_f32, (long)row * p.ldb + c0);
     v += w;
   }
-  const float mean = wave_sum(v[0] + v[1] + v[2] + v[3]) * (1.f / 256.f);
-  const f32x4 dv = v - mean;
-  const float var = wave_sum(dv[0] * dv[0] + dv[1] * dv[1] + dv[2] * dv[2] + dv[3] * dv[3]) * (1.f / 256.f);
-  const float rstd = rsqrtf(var + p.eps);
   const f32x4 g = *reinterpret_cast<const f32x4*>(p.gamma + c0);
   const f32x4 bt = *reinterpret_cast<const f32x4*>(p.beta + c0);
-  const f32x4 o = dv * rstd * g + bt;
+  const f32x4 o = rmem_ln256_row(v, g, bt, p.eps);
   if (p.y) *reinterpret_cast<e16x4*>(p.y + (long)row * p.ldy + c0) = e16x4{(e16)o[0], (e16)o[1], (e16)o[2], (e16)o[3]};
   if (p.yf) *reinterpret_cast<f32x4*>(p.yf + (long)row * p.ldyf + c0) = o;
   if (p.ypos) {

@@ -1,0 +1,403 @@
+// Row-block chains of the LSTT block for gfx950 (CDNA4).
+//
+// Between its three attentions an LSTT block (layers/transformer.py:553-692) is a sequence of ROW-LOCAL operations on the
+// [tokens, 256] residual stream: Linear 256 -> 256 (+ residual), LayerNorm, Linear, LayerNorm of a sum, Linear 256 -> 1024 ...
+// As separate launches (rmem_conv2d_nhwc, rmem_layernorm256, ...) every one of them is a 5 - 20 us kernel over 6696 rows whose
+// arithmetic takes under a microsecond per CU: a group step spent ~54 launches and as many HBM round trips of the activations on
+// them.  Here a workgroup owns 32 consecutive tokens of one clip and walks a whole chain with the rows resident in LDS:
+//
+//   chain A  (after the self attention)   x += att . Wp^T + bp ; curr_V = LN2(x) ; curr_Q = curr_V . Wq^T + bq ;
+//                                         k4 = LN4(short_K + curr_Q) ; v4 = LN4(short_V + curr_V)         (transformer.py:571-576, 659-660)
+//   chain B  (after the long- and short-term attention)
+//                                         x += attL . Wl^T + bl ; tgt3 = attS . Ws^T + bs ; x += tgt3 ; h1 = LN3(x) . W1^T + b1
+//                                         (+ the GroupNorm partial sums of h1)                             (transformer.py:635, 662, 681-685)
+//   chain C  (after GroupNorm + GELU + depth-wise 5x5)
+//                                         x += h3 . W2^T + b2 ; dec_in[:, slice] = LN_dec(x) ; and, unless this is the last
+//                                         block, qkv' = LN1'(x) . Wqkv'^T + bqkv' + pos_qk' of the NEXT block      (transformer.py:685-687, 250-259, 565-569)
+//
+// Arithmetic is the unfused route's, operation for operation: the same v_mfma_f32_16x16x32 accumulation order over k, the same
+// epilogue order (accumulator + bias, then residual), the same LayerNorm reduction (rmem_ln256_row in common.h), the same
+// points of rounding to e16 -- the fused and unfused LSTT give bit-identical x / curr_Q / k4 / v4 / h1 / qkv
+// (tests/test_hip_ops.py::test_lstt_chains_are_bit_identical); only the GroupNorm partial sums are added in another order.
+//
+// GEMM form.  M = 32 rows per workgroup is far too few to amortise a weight tile through LDS per workgroup; instead the A
+// operand (the 32 rows, <= 1024 deep) lives in LDS for the whole chain and the WEIGHTS stream straight from L2 into registers,
+// each wave taking its own 64 output columns: they are packed once at model load in fragment order (pack.py::pack_frag:
+// [N / 256][wave][K / 32][4 column tiles][64 lanes][8]), so a wave-instruction reads 1 KiB of contiguous memory that is exactly
+// one B fragment, no LDS, no barrier, no address arithmetic; a ring of 4 k-chunks (16 KiB per workgroup) stays in flight.
+// All workgroups read the same weights (128 KiB - 512 KiB per matrix): they are L2 hits after the first workgroup of an XCD.
+#include "common.h"
+#include "../../include/rmem.h"
+
+namespace {
+
+constexpr int BM = 32;            // rows per workgroup
+constexpr int XS = 260;           // fp32 staging row stride (floats): 4 rows apart = 16 banks apart, conflict-free ds_write_b32
+constexpr int PANEL = BM * 64;    // elements of one [32 rows][64 k] A panel (128-byte rows, XOR-swizzled 16-byte chunks)
+constexpr int PF = 4;             // k-chunks (of 32) of B fragments in flight per wave
+
+__device__ __forceinline__ int swz(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 1) & 7)) << 3); }
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ f32x4 ld4(const e16* p) {
+  const e16x4 v = *reinterpret_cast<const e16x4*>(p);
+  return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+}
+__device__ __forceinline__ e16x4 cvt4(f32x4 v) { return e16x4{(e16)v[0], (e16)v[1], (e16)v[2], (e16)v[3]}; }
+__device__ __forceinline__ f32x4 up4(e16x4 v) { return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]}; }
+
+// [nrows <= 32][64 * NP] e16 rows of stride ld at src -> A panels p0 .. p0 + NP - 1 (rows beyond nrows: zeros)
+template <int NP>
+__device__ __forceinline__ void stage_tile(e16* A16, int p0, const e16* src, long ld, int nrows) {
+  const int row = threadIdx.x >> 3, ch = threadIdx.x & 7;
+  const e16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+  e16x8 v[NP];
+#pragma unroll
+  for (int p = 0; p < NP; ++p) v[p] = row < nrows ? *reinterpret_cast<const e16x8*>(src + row * ld + p * 64 + ch * 8) : zero;
+#pragma unroll
+  for (int p = 0; p < NP; ++p) *reinterpret_cast<e16x8*>(&A16[(p0 + p) * PANEL + swz(row, ch)]) = v[p];
+}
+
+// 4 consecutive channels c0 .. c0 + 3 of row `row` as e16 into the A panels p0 .. (the LayerNorm output that feeds the next GEMM)
+__device__ __forceinline__ void put_a(e16* A16, int p0, int row, int lane, e16x4 v) {
+  *reinterpret_cast<e16x4*>(&A16[(p0 + (lane >> 4)) * PANEL + swz(row, (lane & 15) >> 1) + (lane & 1) * 4]) = v;
+}
+
+struct BRing { e16x8 b[PF][4]; };
+
+// this wave's weight stream of column block nb: [K / 32][4][64 lanes][8]
+__device__ __forceinline__ const e16* wstream(const e16* w, int nb, int wave, int KC) { return w + (long)(nb * 4 + wave) * KC * 2048; }
+
+__device__ __forceinline__ void b_preload(BRing& r, const e16* wp, int lane) {
+#pragma unroll
+  for (int u = 0; u < PF; ++u)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r.b[u][j] = *reinterpret_cast<const e16x8*>(wp + ((u * 4 + j) * 64 + lane) * 8);
+}
+
+// acc[2][4] (32 rows x this wave's 64 columns) += A[32][64 * NP] (panels p0 ..) . W^T, k ascending in chunks of 32: the
+// accumulation order of the 64x64-tile GEMM kernel (two MFMAs per 64-deep k-step).  The ring holds chunks 0 .. PF - 1 on entry.
+template <int NP>
+__device__ __forceinline__ void gemm32(const e16* A16, int p0, const e16* wp, BRing& r, f32x4 (&acc)[2][4], int lane) {
+  constexpr int KC = NP * 2;
+  const int fr = lane & 15, fc = lane >> 4;
+#pragma unroll
+  for (int kc = 0; kc < KC; ++kc) {
+    const e16* Ap = A16 + (p0 + (kc >> 1)) * PANEL;
+    const e16x8 a0 = *reinterpret_cast<const e16x8*>(&Ap[swz(fr, 4 * (kc & 1) + fc)]);
+    const e16x8 a1 = *reinterpret_cast<const e16x8*>(&Ap[swz(16 + fr, 4 * (kc & 1) + fc)]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      acc[0][j] = RMEM_MFMA_16x16x32(a0, r.b[kc % PF][j], acc[0][j], 0, 0, 0);
+      acc[1][j] = RMEM_MFMA_16x16x32(a1, r.b[kc % PF][j], acc[1][j], 0, 0, 0);
+    }
+    if (kc + PF < KC) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) r.b[kc % PF][j] = *reinterpret_cast<const e16x8*>(wp + (((kc + PF) * 4 + j) * 64 + lane) * 8);
+    }
+  }
+}
+
+__device__ __forceinline__ void zero_acc(f32x4 (&acc)[2][4]) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
+// raw accumulators -> fp32 staging tile [32][XS] (C/D map of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg)
+__device__ __forceinline__ void dump_acc(float* X, const f32x4 (&acc)[2][4], int wave, int lane) {
+  const int fr = lane & 15, fc = lane >> 4;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) X[(i * 16 + fc * 4 + q) * XS + wave * 64 + j * 16 + fr] = acc[i][j][q];
+}
+
+struct Blk { int nrows; long g0; };      // rows this workgroup owns: g0 .. g0 + nrows - 1 of the [clips * L] row space
+__device__ __forceinline__ Blk my_rows(int L) {
+  Blk b;
+  const int r0 = blockIdx.x * BM;
+  b.nrows = min(BM, L - r0);
+  b.g0 = (long)blockIdx.y * L + r0;
+  return b;
+}
+
+// ------------------------------------------------------------------------------------------------------------ chain A
+__global__ __launch_bounds__(256) void k_chain_a(rmem_chain_a_desc d) {
+  __shared__ __attribute__((aligned(16))) char smem[4 * PANEL * 2 + BM * XS * 4];
+  e16* A16 = reinterpret_cast<e16*>(smem);
+  float* X = reinterpret_cast<float*>(smem + 4 * PANEL * 2);
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const Blk blk = my_rows(d.L);
+  const int c0 = lane * 4;
+  BRing ring;
+  f32x4 acc[2][4];
+  const e16* wp = wstream((const e16*)d.w_proj, 0, wave, 8);
+  b_preload(ring, wp, lane);                                     // weights do not depend on anything: in flight before the rows arrive
+  stage_tile<4>(A16, 0, (const e16*)d.att + blk.g0 * 256, 256, blk.nrows);
+  __syncthreads();
+  zero_acc(acc);
+  gemm32<4>(A16, 0, wp, ring, acc, lane);
+  dump_acc(X, acc, wave, lane);
+  const e16* wq = wstream((const e16*)d.w_q, 0, wave, 8);
+  b_preload(ring, wq, lane);
+  __syncthreads();
+  // x += self_proj(att) ; curr_V = LN2(x)
+  const f32x4 bp = ld4(d.b_proj + c0), g2 = ld4(d.ln2_g + c0), b2 = ld4(d.ln2_b + c0);
+  e16x4 cv[8];
+#pragma unroll
+  for (int rr = 0; rr < 8; ++rr) {
+    const int row = wave * 8 + rr;
+    const bool ok = row < blk.nrows;
+    f32x4 v = ld4(&X[row * XS + c0]);
+    v += bp;
+    if (ok) {
+      float* xr = d.x + (blk.g0 + row) * 256 + c0;
+      v += ld4(xr);
+      *reinterpret_cast<f32x4*>(xr) = v;
+    }
+    const f32x4 o = rmem_ln256_row(v, g2, b2, d.eps);
+    cv[rr] = cvt4(o);
+    if (ok) *reinterpret_cast<e16x4*>((e16*)d.curr_v + (blk.g0 + row) * 256 + c0) = cv[rr];
+    put_a(A16, 0, row, lane, cv[rr]);
+  }
+  __syncthreads();
+  zero_acc(acc);
+  gemm32<4>(A16, 0, wq, ring, acc, lane);
+  dump_acc(X, acc, wave, lane);
+  __syncthreads();
+  // curr_Q ; k4 = LN4(short_K + curr_Q) ; v4 = LN4(short_V + curr_V)
+  const f32x4 bq = ld4(d.b_q + c0), g4 = ld4(d.ln4_g + c0), b4 = ld4(d.ln4_b + c0);
+#pragma unroll
+  for (int rr = 0; rr < 8; ++rr) {
+    const int row = wave * 8 + rr;
+    if (row >= blk.nrows) continue;
+    const long off = (blk.g0 + row) * 256 + c0;
+    f32x4 q = ld4(&X[row * XS + c0]);
+    q += bq;
+    const e16x4 cq = cvt4(q);
+    *reinterpret_cast<e16x4*>((e16*)d.curr_q + off) = cq;
+    f32x4 kk = ld4((const e16*)d.short_k + off);
+    kk += up4(cq);
+    *reinterpret_cast<e16x4*>((e16*)d.k4 + off) = cvt4(rmem_ln256_row(kk, g4, b4, d.eps));
+    f32x4 vv = ld4((const e16*)d.short_v + off);
+    vv += up4(cv[rr]);
+    *reinterpret_cast<e16x4*>((e16*)d.v4 + off) = cvt4(rmem_ln256_row(vv, g4, b4, d.eps));
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------ chain B
+__global__ __launch_bounds__(256) void k_chain_b(rmem_chain_b_desc d) {
+  __shared__ __attribute__((aligned(16))) char smem[8 * PANEL * 2 + 2 * BM * XS * 4];
+  e16* A16 = reinterpret_cast<e16*>(smem);
+  float* Xa = reinterpret_cast<float*>(smem + 8 * PANEL * 2);
+  float* Xb = Xa + BM * XS;
+  __shared__ float gsum[4][8][2];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const Blk blk = my_rows(d.L);
+  const int c0 = lane * 4;
+  BRing ring;
+  f32x4 acc[2][4];
+  const e16* wl = wstream((const e16*)d.w_long, 0, wave, 8);
+  b_preload(ring, wl, lane);
+  stage_tile<4>(A16, 0, (const e16*)d.att_long + blk.g0 * 256, 256, blk.nrows);
+  stage_tile<4>(A16, 4, (const e16*)d.att_short + blk.g0 * 256, 256, blk.nrows);
+  __syncthreads();
+  zero_acc(acc);
+  gemm32<4>(A16, 0, wl, ring, acc, lane);
+  dump_acc(Xa, acc, wave, lane);
+  const e16* ws = wstream((const e16*)d.w_short, 0, wave, 8);
+  b_preload(ring, ws, lane);
+  zero_acc(acc);
+  gemm32<4>(A16, 4, ws, ring, acc, lane);
+  dump_acc(Xb, acc, wave, lane);
+  const e16* w1 = wstream((const e16*)d.w1, 0, wave, 8);
+  b_preload(ring, w1, lane);
+  __syncthreads();
+  // x += long_proj(attL) ; tgt3 = short_proj(attS) ; x += tgt3 ; LN3(x) -> A panels 0..3
+  {
+    const f32x4 bl = ld4(d.b_long + c0), bs = ld4(d.b_short + c0), g3 = ld4(d.ln3_g + c0), b3 = ld4(d.ln3_b + c0);
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+      const int row = wave * 8 + rr;
+      const bool ok = row < blk.nrows;
+      f32x4 v1 = ld4(&Xa[row * XS + c0]);
+      v1 += bl;
+      f32x4 t = ld4(&Xb[row * XS + c0]);
+      t += bs;
+      if (ok) {
+        float* xr = d.x + (blk.g0 + row) * 256 + c0;
+        v1 += ld4(xr);                                  // x after the long-term projection (what the unfused route stores)
+        *reinterpret_cast<e16x4*>((e16*)d.tgt3 + (blk.g0 + row) * 256 + c0) = cvt4(t);
+        t += v1;
+        *reinterpret_cast<f32x4*>(xr) = t;
+      }
+      put_a(A16, 0, row, lane, cvt4(rmem_ln256_row(t, g3, b3, d.eps)));
+    }
+  }
+  __syncthreads();
+  // h1 = linear1(LN3(x)): four column blocks of 256, staged alternately through Xa / Xb (one barrier per block)
+  float gs = 0.f, gss = 0.f;            // this lane's channels belong to ONE GroupNorm group (32 channels = 8 lanes) per block
+#pragma unroll
+  for (int nb = 0; nb < 4; ++nb) {
+    float* X = (nb & 1) ? Xb : Xa;
+    zero_acc(acc);
+    gemm32<4>(A16, 0, w1, ring, acc, lane);
+    dump_acc(X, acc, wave, lane);
+    if (nb < 3) { w1 = wstream((const e16*)d.w1, nb + 1, wave, 8); b_preload(ring, w1, lane); }
+    __syncthreads();
+    const f32x4 b1 = ld4(d.b1 + nb * 256 + c0);
+    gs = 0.f; gss = 0.f;
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+      const int row = wave * 8 + rr;
+      if (row >= blk.nrows) continue;
+      f32x4 v = ld4(&X[row * XS + c0]);
+      v += b1;
+      const e16x4 h = cvt4(v);
+      *reinterpret_cast<e16x4*>((e16*)d.h1 + (blk.g0 + row) * 1024 + nb * 256 + c0) = h;
+      const f32x4 hf = up4(h);
+      gs += hf[0] + hf[1] + hf[2] + hf[3];
+      gss += hf[0] * hf[0] + hf[1] * hf[1] + hf[2] * hf[2] + hf[3] * hf[3];
+    }
+    if (d.gn_partial) {
+      // (sum, sum of squares) of this block's rows per group: 8 lanes -> wave -> workgroup, fixed order
+      gs += __shfl_xor(gs, 1); gss += __shfl_xor(gss, 1);
+      gs += __shfl_xor(gs, 2); gss += __shfl_xor(gss, 2);
+      gs += __shfl_xor(gs, 4); gss += __shfl_xor(gss, 4);
+      if ((lane & 7) == 0) { gsum[wave][lane >> 3][0] = gs; gsum[wave][lane >> 3][1] = gss; }
+      __syncthreads();
+      if (threadIdx.x < 8) {
+        const int g = threadIdx.x;
+        const float a = gsum[0][g][0] + gsum[1][g][0] + gsum[2][g][0] + gsum[3][g][0];
+        const float b = gsum[0][g][1] + gsum[1][g][1] + gsum[2][g][1] + gsum[3][g][1];
+        // workspace [clip][group 0..31][split][2] with d.gn_splits splits per group (this workgroup is split blockIdx.x)
+        float* o = d.gn_partial + (((long)blockIdx.y * 32 + nb * 8 + g) * d.gn_splits + blockIdx.x) * 2;
+        o[0] = a; o[1] = b;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------ chain C
+// FFN2: x += linear2(h3) first (else the rows are read from x as they are: the first block of the stack);
+// NEXT: LN1' + fused QKV projection of the next block
+template <bool FFN2, bool NEXT>
+__global__ __launch_bounds__(256) void k_chain_c(rmem_chain_c_desc d) {
+  constexpr int NPA = FFN2 ? 16 : 4;
+  __shared__ __attribute__((aligned(16))) char smem[NPA * PANEL * 2 + 2 * BM * XS * 4];
+  e16* A16 = reinterpret_cast<e16*>(smem);
+  float* Xa = reinterpret_cast<float*>(smem + NPA * PANEL * 2);
+  float* Xb = Xa + BM * XS;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const Blk blk = my_rows(d.L);
+  const int c0 = lane * 4;
+  BRing ring;
+  f32x4 acc[2][4];
+  const e16* wq = NEXT ? wstream((const e16*)d.w_qkv, 0, wave, 8) : nullptr;
+  if (FFN2) {
+    const e16* w2 = wstream((const e16*)d.w2, 0, wave, 32);
+    b_preload(ring, w2, lane);
+    stage_tile<16>(A16, 0, (const e16*)d.h3 + blk.g0 * 1024, 1024, blk.nrows);
+    __syncthreads();
+    zero_acc(acc);
+    gemm32<16>(A16, 0, w2, ring, acc, lane);
+    dump_acc(Xa, acc, wave, lane);
+    if (NEXT) b_preload(ring, wq, lane);
+    __syncthreads();
+  } else if (NEXT) {
+    b_preload(ring, wq, lane);
+  }
+  {
+    f32x4 b2 = {0.f, 0.f, 0.f, 0.f}, gd = b2, bd = b2, g1 = b2, b1 = b2;
+    if (FFN2) { b2 = ld4(d.b2 + c0); gd = ld4(d.dec_g + c0); bd = ld4(d.dec_b + c0); }
+    if (NEXT) { g1 = ld4(d.ln1_g + c0); b1 = ld4(d.ln1_b + c0); }
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+      const int row = wave * 8 + rr;
+      const bool ok = row < blk.nrows;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      float* xr = d.x + (blk.g0 + row) * 256 + c0;
+      if (FFN2) {
+        v = ld4(&Xa[row * XS + c0]);
+        v += b2;
+        if (ok) {
+          v += ld4(xr);
+          *reinterpret_cast<f32x4*>(xr) = v;
+          *reinterpret_cast<e16x4*>((e16*)d.dec_out + (blk.g0 + row) * d.ld_dec + c0) = cvt4(rmem_ln256_row(v, gd, bd, d.eps));
+        }
+      } else if (ok) {
+        v = ld4(xr);
+      }
+      if (NEXT) put_a(A16, 0, row, lane, cvt4(rmem_ln256_row(v, g1, b1, d.eps)));
+    }
+  }
+  if (!NEXT) return;
+  __syncthreads();
+#pragma unroll
+  for (int nb = 0; nb < 3; ++nb) {
+    float* X = (nb & 1) ? Xb : Xa;
+    zero_acc(acc);
+    gemm32<4>(A16, 0, wq, ring, acc, lane);
+    dump_acc(X, acc, wave, lane);
+    if (nb < 2) { wq = wstream((const e16*)d.w_qkv, nb + 1, wave, 8); b_preload(ring, wq, lane); }
+    __syncthreads();
+    const f32x4 bq = ld4(d.b_qkv + nb * 256 + c0);
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+      const int row = wave * 8 + rr;
+      if (row >= blk.nrows) continue;
+      f32x4 v = ld4(&X[row * XS + c0]);
+      v += bq;
+      v += ld4(d.pos_qk + (blk.g0 + row) * 768 + nb * 256 + c0);
+      *reinterpret_cast<e16x4*>((e16*)d.qkv + (blk.g0 + row) * 768 + nb * 256 + c0) = cvt4(v);
+    }
+  }
+}
+
+bool al16(const void* p) { return p == nullptr || ((uintptr_t)p % 16) == 0; }
+
+}  // namespace
+
+extern "C" int RMEM_API(rmem_lstt_chain_a)(const rmem_chain_a_desc* d, void* stream) {
+  RMEM_REQUIRE(d && d->L > 0 && d->clips >= 1, "rmem_lstt_chain_a: bad geometry");
+  RMEM_REQUIRE(d->att && d->x && d->w_proj && d->b_proj && d->ln2_g && d->ln2_b && d->curr_v && d->w_q && d->b_q && d->curr_q && d->short_k &&
+               d->short_v && d->ln4_g && d->ln4_b && d->k4 && d->v4, "rmem_lstt_chain_a: null argument");
+  RMEM_REQUIRE(al16(d->att) && al16(d->x) && al16(d->w_proj) && al16(d->w_q) && al16(d->curr_v) && al16(d->curr_q) && al16(d->short_k) &&
+               al16(d->short_v) && al16(d->k4) && al16(d->v4) && al16(d->b_proj) && al16(d->b_q) && al16(d->ln2_g) && al16(d->ln2_b) &&
+               al16(d->ln4_g) && al16(d->ln4_b), "rmem_lstt_chain_a: operands must be 16-byte aligned");
+  hipLaunchKernelGGL(k_chain_a, dim3((d->L + BM - 1) / BM, d->clips), dim3(256), 0, (hipStream_t)stream, *d);
+  return rmem_check_launch("rmem_lstt_chain_a");
+}
+
+extern "C" int RMEM_API(rmem_lstt_chain_b)(const rmem_chain_b_desc* d, void* stream) {
+  RMEM_REQUIRE(d && d->L > 0 && d->clips >= 1, "rmem_lstt_chain_b: bad geometry");
+  RMEM_REQUIRE(d->att_long && d->att_short && d->x && d->w_long && d->b_long && d->w_short && d->b_short && d->tgt3 && d->ln3_g && d->ln3_b &&
+               d->w1 && d->b1 && d->h1, "rmem_lstt_chain_b: null argument");
+  RMEM_REQUIRE(al16(d->att_long) && al16(d->att_short) && al16(d->x) && al16(d->w_long) && al16(d->w_short) && al16(d->tgt3) && al16(d->w1) &&
+               al16(d->h1) && al16(d->b_long) && al16(d->b_short) && al16(d->b1) && al16(d->ln3_g) && al16(d->ln3_b),
+               "rmem_lstt_chain_b: operands must be 16-byte aligned");
+  RMEM_REQUIRE(!d->gn_partial || d->gn_splits >= (d->L + BM - 1) / BM, "rmem_lstt_chain_b: gn_splits must cover the row blocks of a clip");
+  hipLaunchKernelGGL(k_chain_b, dim3((d->L + BM - 1) / BM, d->clips), dim3(256), 0, (hipStream_t)stream, *d);
+  return rmem_check_launch("rmem_lstt_chain_b");
+}
+
+extern "C" int RMEM_API(rmem_lstt_chain_c)(const rmem_chain_c_desc* d, void* stream) {
+  RMEM_REQUIRE(d && d->L > 0 && d->clips >= 1 && d->x, "rmem_lstt_chain_c: bad geometry");
+  const bool ffn2 = d->h3 != nullptr, next = d->w_qkv != nullptr;
+  RMEM_REQUIRE(ffn2 || next, "rmem_lstt_chain_c: nothing to do (neither h3 nor w_qkv)");
+  RMEM_REQUIRE(!ffn2 || (d->w2 && d->b2 && d->dec_g && d->dec_b && d->dec_out && d->ld_dec >= 256 && d->ld_dec % 8 == 0),
+               "rmem_lstt_chain_c: the linear2 stage needs w2, b2, the decoder norm and dec_out (ld_dec >= 256, multiple of 8)");
+  RMEM_REQUIRE(!next || (d->ln1_g && d->ln1_b && d->b_qkv && d->pos_qk && d->qkv), "rmem_lstt_chain_c: the QKV stage needs ln1, b_qkv, pos_qk, qkv");
+  RMEM_REQUIRE(al16(d->x) && al16(d->h3) && al16(d->w2) && al16(d->b2) && al16(d->dec_g) && al16(d->dec_b) && al16(d->dec_out) && al16(d->ln1_g) &&
+               al16(d->ln1_b) && al16(d->w_qkv) && al16(d->b_qkv) && al16(d->pos_qk) && al16(d->qkv), "rmem_lstt_chain_c: operands must be 16-byte aligned");
+  const dim3 grid((d->L + BM - 1) / BM, d->clips);
+  hipStream_t s = (hipStream_t)stream;
+  if (ffn2 && next) hipLaunchKernelGGL((k_chain_c<true, true>), grid, dim3(256), 0, s, *d);
+  else if (ffn2) hipLaunchKernelGGL((k_chain_c<true, false>), grid, dim3(256), 0, s, *d);
+  else hipLaunchKernelGGL((k_chain_c<false, true>), grid, dim3(256), 0, s, *d);
+  return rmem_check_launch("rmem_lstt_chain_c");
+}

@@ -41,6 +41,8 @@ class GroupRuntime:
         if ('g0.qvu.w' in P) != self.deaot:
             raise ops.RmemError('GroupRuntime covers the AOTL paths (ResNet-50 / Swin-B), group_runtime_deaot.GroupRuntimeDeAOT the R50-DeAOTL path')
         self.swin = 'pe.w' in P
+        self.chain = not __import__('os').environ.get('RMEM_NO_CHAIN')      # 1: the unfused launch list (A/B runs, identity tests)
+        self.pair_attn = not __import__('os').environ.get('RMEM_NO_PAIR_ATTN')   # 1: memory read and short-term attention as two launches
         self.P, self.dev, self.NL, self.B = P, device, num_lstt, clips
         self.dt = P['proj.w'].dtype
         self.align, self.nc = align_corners, num_classes
@@ -108,6 +110,7 @@ class GroupRuntime:
         self.t1b = e(R, D_MODEL)
         self.qkv = e(R, 3 * D_MODEL)
         self.att = e(R, D_MODEL)
+        self.att2 = e(R, D_MODEL)           # short-term attention output (the chained route keeps both attentions' outputs)
         self.t3 = e(R, D_MODEL)
         self.k4, self.v4 = e(R, D_MODEL), e(R, D_MODEL)
         self.h1, self.h3 = e(R, FFN), e(R, FFN)
@@ -247,6 +250,9 @@ class GroupRuntime:
         C = D_MODEL
         R = B * L
         _, nchunks = self.chunk_plan(1 if ref_mode else T)
+        if not ref_mode and self.chain:
+            self._prog[key] = self._prog_lstt_chained(T, nchunks, want_mass)
+            return self._prog[key]
         for i in range(self.NL):
             d = f'l{i}'
             o.append(ops.layernorm256(self.x, P[d + '.ln1.g'], P[d + '.ln1.b'], M=R, y=self.t1b))
@@ -284,6 +290,51 @@ class GroupRuntime:
             o.append(ops.layernorm256(self.x, P[f'dec_norm{i}.g'], P[f'dec_norm{i}.b'], M=R,
                                       y=self.dec_in.view(-1)[(i + 1) * C:], ldy=4 * C))
         self._prog[key] = o
+        return o
+
+    def _prog_lstt_chained(self, T: int, nchunks: int, want_mass: bool) -> list:
+        """Propagate-mode LSTT with the row-local sequences between the attentions as ONE launch each (csrc/rowchain.hip):
+        7 launches per block instead of 16, bit-identical buffers (x, curr_Q, curr_V, k4, v4, tgt3, h1, qkv, dec_in) to the
+        unfused list of prog_lstt.  The long-term projection moves behind the short-term attention (which does not read x)."""
+        P, L, B, C, o = self.P, self.L, self.B, D_MODEL, []
+        ln = lambda n: (P[n + '.g'], P[n + '.b'])       # noqa: E731
+
+        def chain_c(i_done, i_next):
+            kw = {}
+            if i_done is not None:
+                d = f'l{i_done}'
+                kw.update(h3=self.h3, w2=P[d + '.linear2.wf'], b2=P[d + '.linear2.b'], dec_norm=ln(f'dec_norm{i_done}'),
+                          dec_out=self.dec_in.view(-1)[(i_done + 1) * C:], ld_dec=self.dec_cin)
+            if i_next is not None:
+                d = f'l{i_next}'
+                kw.update(ln1=ln(d + '.ln1'), w_qkv=P[d + '.self_qkv.wf'], b_qkv=P[d + '.self_qkv.b'], pos_qk=self.pos_qk[i_next], qkv=self.qkv)
+            return ops.lstt_chain_c(L=L, clips=B, x=self.x, dt=self.dt, **kw)
+
+        o.append(chain_c(None, 0))
+        for i in range(self.NL):
+            d = f'l{i}'
+            cq = self.curr_Q[i]
+            o.append(self._attn(self.qkv, 3 * C, self.qkv.view(-1)[C:], self.qkv.view(-1)[2 * C:], 3 * C, self.att,
+                                nchunks=PLAIN_CHUNKS, lk_single=L, kv_cs=L * 3 * C))
+            o.append(ops.lstt_chain_a(L=L, clips=B, att=self.att, x=self.x, w_proj=P[d + '.self_proj.wf'], b_proj=P[d + '.self_proj.b'],
+                                      ln2=ln(d + '.ln2'), curr_v=self.curr_V[i], w_q=P[d + '.linear_Q.wf'], b_q=P[d + '.linear_Q.b'], curr_q=cq,
+                                      short_k=self.short_K[i], short_v=self.short_V[i], ln4=ln(d + '.ln4'), k4=self.k4, v4=self.v4))
+            mass = self.mass if (i == 0 and want_mass) else None
+            if self.pair_attn:       # long-term memory read + short-term attention: one launch (same queries, independent keys)
+                o.append(ops.lstt_attn_pair(cq, self.bank_K[i], self.bank_V[i], self.att, self.k4, self.v4, self.att2, self.attn_ws, Lq=L,
+                                            heads=HEADS, ldq=C, ldkv=C, ldo=C, slot_stride=L * C, chunks=self.chunks, nchunks=nchunks,
+                                            lk_total=T * L, pe_cur=P['pe_cur'], pe_mem=P['pe_mem'], mass=mass, T=T, nclips=B, q_cs=L * C,
+                                            out_cs=L * C, lk_short=L, kv_short_cs=L * C, out_short_cs=L * C))
+            else:
+                o.append(self._attn(cq, C, self.bank_K[i], self.bank_V[i], C, self.att, slot_stride=L * C, chunks=self.chunks,
+                                    nchunks=nchunks, lk_single=T * L, pe_cur=P['pe_cur'], pe_mem=P['pe_mem'], mass=mass, T=T))
+                o.append(self._attn(cq, C, self.k4, self.v4, C, self.att2, nchunks=PLAIN_CHUNKS, lk_single=L, kv_cs=L * C))
+            o.append(ops.lstt_chain_b(L=L, clips=B, att_long=self.att, att_short=self.att2, x=self.x, w_long=P[d + '.long_proj.wf'],
+                                      b_long=P[d + '.long_proj.b'], w_short=P[d + '.short_proj.wf'], b_short=P[d + '.short_proj.b'],
+                                      tgt3=self.tgt3[i], ln3=ln(d + '.ln3'), w1=P[d + '.linear1.wf'], b1=P[d + '.linear1.b'], h1=self.h1))
+            o.append(ops.gn_act_dwconv5x5(self.h1, P[d + '.gn.g'], P[d + '.gn.b'], P[d + '.dw.w'], self.h3, self.gn_ws, H=self.H16,
+                                          W=self.W16, C=FFN, groups=32, act=2, images=B))
+            o.append(chain_c(i, i + 1 if i + 1 < self.NL else None))
         return o
 
     def prog_decode(self, e: Optional[int]) -> list:

@@ -160,6 +160,55 @@ def layernorm256_pair(a0, b0, y0, a1, b1, y1, gamma, beta, *, M, eps=1e-5) -> Op
     return Op(_fn('rmem_layernorm256_pair', dt), args, 'rmem_layernorm256_pair', (a0, b0, y0, a1, b1, y1, gamma, beta))
 
 
+def _chain(name, cls, ints, ptrs, dt):
+    """An rmem_lstt_chain_* launch: ints = (L, clips, eps, third int), ptrs = {field: tensor or None} in the struct's order."""
+    ts = list(ptrs.values())
+    _dev(*ts)
+    for k, t in ptrs.items():
+        if t is not None and t.data_ptr() % 16:
+            raise RmemError(f'{name}: {k} must be 16-byte aligned')
+    d = cls(int(ints[0]), int(ints[1]), float(ints[2]), int(ints[3]), *[_ptr(t) for t in ts])
+    return Op(_fn(name, dt), (C.byref(d),), name, (d, ts))
+
+
+def lstt_chain_a(*, L, clips, att, x, w_proj, b_proj, ln2, curr_v, w_q, b_q, curr_q, short_k, short_v, ln4, k4, v4, eps=1e-5) -> Op:
+    """x += att @ Wp^T + bp; curr_v = LN2(x); curr_q = curr_v @ Wq^T + bq; k4 = LN4(short_k + curr_q); v4 = LN4(short_v + curr_v)
+    over [clips * L, 256] rows (weights in pack.pack_frag order; ln2 / ln4 = (gamma, beta))."""
+    dt = att.dtype
+    R = clips * L
+    assert x.dtype == F32 and x.numel() >= R * 256 and all(t.dtype == dt and t.numel() >= R * 256 for t in (att, curr_v, curr_q, short_k, short_v, k4, v4))
+    assert w_proj.dtype == dt and w_q.dtype == dt and w_proj.numel() == 65536 and w_q.numel() == 65536
+    return _chain('rmem_lstt_chain_a', _lib.ChainA, (L, clips, eps, 0),
+                  dict(att=att, x=x, w_proj=w_proj, b_proj=b_proj, ln2_g=ln2[0], ln2_b=ln2[1], curr_v=curr_v, w_q=w_q, b_q=b_q, curr_q=curr_q,
+                       short_k=short_k, short_v=short_v, ln4_g=ln4[0], ln4_b=ln4[1], k4=k4, v4=v4), dt)
+
+
+def lstt_chain_b(*, L, clips, att_long, att_short, x, w_long, b_long, w_short, b_short, tgt3, ln3, w1, b1, h1, gn_partial=None,
+                 gn_splits=0, eps=1e-5) -> Op:
+    """x += att_long @ Wl^T + bl; tgt3 = att_short @ Ws^T + bs; x += tgt3; h1 = LN3(x) @ W1^T + b1 ([rows, 1024])
+    (+ per-row-block GroupNorm partial sums of h1: fp32 [clips, 32, gn_splits, 2])."""
+    dt = att_long.dtype
+    R = clips * L
+    assert x.dtype == F32 and all(t.dtype == dt and t.numel() >= R * 256 for t in (att_long, att_short, tgt3)) and h1.dtype == dt and h1.numel() >= R * 1024
+    assert w_long.numel() == 65536 and w_short.numel() == 65536 and w1.numel() == 262144 and b1.numel() == 1024
+    assert gn_partial is None or (gn_partial.dtype == F32 and gn_splits * 32 >= L and gn_partial.numel() >= clips * 32 * gn_splits * 2)
+    return _chain('rmem_lstt_chain_b', _lib.ChainB, (L, clips, eps, gn_splits),
+                  dict(att_long=att_long, att_short=att_short, x=x, w_long=w_long, b_long=b_long, w_short=w_short, b_short=b_short, tgt3=tgt3,
+                       ln3_g=ln3[0], ln3_b=ln3[1], w1=w1, b1=b1, h1=h1, gn_partial=gn_partial), dt)
+
+
+def lstt_chain_c(*, L, clips, x, dt, h3=None, w2=None, b2=None, dec_norm=(None, None), dec_out=None, ld_dec=0, ln1=(None, None), w_qkv=None,
+                 b_qkv=None, pos_qk=None, qkv=None, eps=1e-5) -> Op:
+    """(h3 given) x += h3 @ W2^T + b2; dec_out[:, :256] (row stride ld_dec) = LN_dec(x);  (w_qkv given) qkv = LN1'(x) @ Wqkv^T + b_qkv + pos_qk."""
+    R = clips * L
+    assert x.dtype == F32 and x.numel() >= R * 256
+    assert h3 is None or (h3.dtype == dt and h3.numel() >= R * 1024 and w2.numel() == 262144 and dec_out.numel() >= (R - 1) * ld_dec + 256)
+    assert w_qkv is None or (w_qkv.numel() == 196608 and pos_qk.dtype == F32 and pos_qk.numel() >= R * 768 and qkv.dtype == dt and qkv.numel() >= R * 768)
+    return _chain('rmem_lstt_chain_c', _lib.ChainC, (L, clips, eps, ld_dec),
+                  dict(x=x, h3=h3, w2=w2, b2=b2, dec_g=dec_norm[0], dec_b=dec_norm[1], dec_out=dec_out, ln1_g=ln1[0], ln1_b=ln1[1], w_qkv=w_qkv,
+                       b_qkv=b_qkv, pos_qk=pos_qk, qkv=qkv), dt)
+
+
 def attn_workspace(Lq: int, heads: int, nchunks: int, device, nclips: int = 1) -> torch.Tensor:
     n = nclips * _lib.lib().rmem_attn_workspace_bytes(Lq, heads, nchunks)
     return torch.empty(n // 4, dtype=F32, device=device)
@@ -187,6 +236,23 @@ def mem_read_attn(q, k_bank, v_bank, out, workspace, *, Lq, heads=8, ldq, ldkv, 
             _ptr(pe_cur), _ptr(pe_mem), Lq, heads, _ptr(out), ldo, _ptr(mass), T, nclips, q_cs, kv_cs, out_cs, _ptr(workspace))
     return Op(_fn('rmem_mem_read_attn_clips', dt), args, 'rmem_mem_read_attn',
               (q, k_bank, v_bank, out, workspace, chunks, pe_cur, pe_mem, mass))
+
+
+def lstt_attn_pair(q, k_bank, v_bank, out_long, k_short, v_short, out_short, workspace, *, Lq, heads=8, ldq, ldkv, ldo, slot_stride, chunks,
+                   nchunks, lk_total, pe_cur, pe_mem, mass=None, T=0, nclips=1, q_cs=0, out_cs=0, lk_short, kv_short_cs=0, out_short_cs=0) -> Op:
+    """The long-term memory read (mem_read_attn with a chunk table) and the short-term attention of the same queries as one launch."""
+    _dev(q, k_bank, v_bank, out_long, k_short, v_short, out_short, workspace, chunks, pe_cur, pe_mem, mass)
+    dt = q.dtype
+    assert all(t.dtype == dt for t in (k_bank, v_bank, out_long, k_short, v_short, out_short))
+    assert workspace.numel() * 4 >= nclips * _lib.lib().rmem_attn_workspace_bytes(Lq, heads, nchunks)
+    assert chunks.dtype == torch.int32 and chunks.numel() >= nclips * nchunks * 8
+    assert mass is None or (mass.dtype == F32 and mass.numel() >= nclips * Lq * T)
+    assert k_short.numel() >= (nclips - 1) * kv_short_cs + (lk_short - 1) * ldkv + heads * 32
+    args = (_ptr(q), ldq, _ptr(k_bank), _ptr(v_bank), slot_stride, ldkv, _ptr(chunks), nchunks, lk_total, _ptr(pe_cur), _ptr(pe_mem), Lq, heads,
+            _ptr(out_long), ldo, _ptr(mass), T, nclips, q_cs, out_cs, _ptr(k_short), _ptr(v_short), lk_short, kv_short_cs, _ptr(out_short),
+            out_short_cs, _ptr(workspace))
+    return Op(_fn('rmem_lstt_attn_pair_clips', dt), args, 'rmem_lstt_attn_pair',
+              (q, k_bank, v_bank, out_long, k_short, v_short, out_short, workspace, chunks, pe_cur, pe_mem, mass))
 
 
 def layernorm256(a, gamma, beta, *, M, lda=256, b=None, ldb=256, y=None, ldy=256, pos=None, ypos=None, ldyp=256,

@@ -29,6 +29,16 @@ def _conv_w(w: torch.Tensor, cin_pad: int = 0) -> torch.Tensor:
     return w.contiguous().to(_DT)
 
 
+def pack_frag(w: torch.Tensor) -> torch.Tensor:
+    """[N, K] 16-bit weight (nn.Linear layout, N % 256 == 0, K % 32 == 0) -> the fragment order the LSTT chain kernels stream
+    (include/rmem.h, rmem_lstt_chain_*): [N / 256][4 waves][K / 32][4 column tiles][64 lanes][8], element (n, k) with
+    n = 256 nb + 64 wave + 16 j + (lane & 15), k = 32 kc + 8 (lane >> 4) + e -- one MFMA B fragment per KiB."""
+    N, K = w.shape
+    assert N % 256 == 0 and K % 32 == 0, (N, K)
+    v = w.reshape(N // 256, 4, 4, 16, K // 32, 4, 8)          # nb, wave, j, fr, kc, fc, e
+    return v.permute(0, 1, 4, 2, 5, 3, 6).contiguous().reshape(-1)   # nb, wave, kc, j, fc, fr, e  (lane = 16 fc + fr)
+
+
 def _fold_bn(sd, conv_key: str, bn_prefix: str, cin_pad: int = 0):
     w = sd[conv_key].float()
     scale = sd[bn_prefix + '.weight'].float() * (sd[bn_prefix + '.running_var'].float() + BN_EPS).rsqrt()
@@ -181,6 +191,8 @@ def _pack_state_dict(sd: Dict[str, torch.Tensor], device, num_lstt: int) -> Dict
         lin(d + '.long_proj', s + '.long_term_attn.projection')
         lin(d + '.short_proj', s + '.short_term_attn.projection')
         norm(d + '.ln3', s + '.norm3')
+        for nm in ('self_proj', 'linear_Q', 'long_proj', 'short_proj', 'linear1', 'linear2', 'self_qkv'):
+            put(f'{d}.{nm}.wf', pack_frag(P[f'{d}.{nm}.w']))     # fragment order for the row-chain kernels
         norm(d + '.gn', s + '.activation.gn')
         put(d + '.dw.w', sd[s + '.activation.conv.weight'].float().view(-1, 25).t())
         norm(f'dec_norm{i}', f'LSTT.decoder_norms.{i}')

@@ -134,3 +134,16 @@ def test_oracle_iou_metric_matches_reference_fixture():
         v = void if void.size else None
         for k, j in enumerate(js, start=1):
             assert abs(O.db_eval_iou(gt == k, pred == k, v) - j) < 1e-12, (i, k)
+
+
+def test_pack_frag_layout():
+    """pack.pack_frag: element (n, k) of an [N, K] weight sits where include/rmem.h says the chain kernels read it."""
+    import torch
+    from rmem_ocu_amd.pack import pack_frag
+    N, K = 512, 64
+    w = (torch.arange(N)[:, None] * 1000 + torch.arange(K)[None, :]).float()
+    f = pack_frag(w).reshape(N // 256, 4, K // 32, 4, 64, 8)
+    for nb, wave, kc, j, lane, e in [(0, 0, 0, 0, 0, 0), (1, 3, 1, 2, 37, 5), (0, 2, 1, 3, 63, 7), (1, 0, 0, 1, 16, 0)]:
+        n = 256 * nb + 64 * wave + 16 * j + (lane & 15)
+        k = 32 * kc + 8 * (lane >> 4) + e
+        assert f[nb, wave, kc, j, lane, e].item() == n * 1000 + k
