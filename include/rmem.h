@@ -191,7 +191,7 @@ int rmem_lstt_chain_a(const rmem_chain_a_desc* d, void* stream);
  *   x += att_long . w_long^T + b_long;  tgt3 = att_short . w_short^T + b_short;  x += tgt3;  h1 = LN3(x) . w1^T + b1   ([rows][1024])
  * gn_partial (optional): per-row-block (sum, sum of squares) of h1 over each of the 32 GroupNorm groups of 32 channels,
  * fp32 [clips][32][gn_splits][2], entry `split` = the row block (gn_splits >= ceil(L / 32); the caller keeps the unused
- * entries zero): the statistics rmem_gn_act_dwconv5x5_partials_nhwc_images finalises (layers/basic.py:27-35). */
+ * entries zero): with gn_splits = 64 the statistics rmem_gn_act_dwconv5x5_prestats_nhwc_images consumes (layers/basic.py:27-35). */
 typedef struct rmem_chain_b_desc {
   int L, clips; float eps; int gn_splits;
   const void* att_long; const void* att_short; float* x;
@@ -269,6 +269,12 @@ int rmem_groupnorm_head_nhwc_images(const void* x, int images, int M, int C, int
 int rmem_gn_act_dwconv5x5_nhwc_images(const void* x, int images, int H, int W, int C, int groups, const float* gamma,
                                       const float* beta, float eps, int act, const float* w_t, void* y, float* workspace, void* stream);
 int rmem_bilinear_nhwc_images(const void* x, void* y, int images, int Hi, int Wi, int Ho, int Wo, int C, int align_corners, void* stream);
+/* rmem_gn_act_dwconv5x5_nhwc_images without its statistics launch: `stats` already holds, per image and group, the (sum, sum of
+ * squares) of up to 64 row ranges -- fp32 [images][groups][64][2], unused entries zero -- written by the producer of x
+ * (rmem_lstt_chain_b: gn_partial with gn_splits = 64, i.e. at most 2048 rows per image). */
+int rmem_gn_act_dwconv5x5_prestats_nhwc_images(const void* x, int images, int H, int W, int C, int groups, const float* gamma,
+                                               const float* beta, float eps, int act, const float* w_t, void* y, const float* stats,
+                                               void* stream);
 
 /* Depth-wise 5x5, pad 2, NHWC bf16; w_t is [25][C] fp32.  Replaces layers/basic.py:19-25, 33. */
 int rmem_dwconv5x5_nhwc(const void* x, const float* w_t, void* y, int H, int W, int C, void* stream);
@@ -424,6 +430,7 @@ int rmem_groupnorm_f32_nhwc_f16(const float* x, int M, int C, int groups, const 
 int rmem_groupnorm_nhwc_images_f16(const void* x, int images, int M, int C, int groups, const float* gamma, const float* beta, float eps, int act, void* y, float* workspace, void* stream);
 int rmem_groupnorm_head_nhwc_images_f16(const void* x, int images, int M, int C, int groups, const float* gamma, const float* beta, float eps, int act, const void* w, const float* bias, int N, float* y, int ldy, float* workspace, void* stream);
 int rmem_gn_act_dwconv5x5_nhwc_images_f16(const void* x, int images, int H, int W, int C, int groups, const float* gamma, const float* beta, float eps, int act, const float* w_t, void* y, float* workspace, void* stream);
+int rmem_gn_act_dwconv5x5_prestats_nhwc_images_f16(const void* x, int images, int H, int W, int C, int groups, const float* gamma, const float* beta, float eps, int act, const float* w_t, void* y, const float* stats, void* stream);
 int rmem_gn_act_dwconv5x5_nhwc_f16(const void* x, int H, int W, int C, int groups, const float* gamma, const float* beta, float eps, int act, const float* w_t, void* y, float* workspace, void* stream);
 int rmem_dwconv5x5_nhwc_f16(const void* x, const float* w_t, void* y, int H, int W, int C, void* stream);
 int rmem_image_to_nhwc8_f16(const float* img_chw, void* out, int H, int W, void* stream);

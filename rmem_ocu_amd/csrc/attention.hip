@@ -5,38 +5,42 @@
 //   long-term : Q = curr_Q + cur_pe, keys = the restricted memory bank (T frames x HW
 //               tokens, K[t] + mem_pe[slot(t)]), optional per-memory-frame probability
 //               mass side output (transformer.py:636-643);
-//   short-term and self attention : one key frame, no temporal embedding.
+//   short-term and self attention : one key frame, no temporal embedding -- as launches of their own (MEM = false) or, for the
+//               short-term attention, as extra grid slices of the memory-read launch (rmem_lstt_attn_pair_clips: same queries,
+//               independent keys, second output).
 //
-// Decomposition: grid = (query tiles of 128) x heads x key GROUPS x clips.  The keys are described by a
-// device-resident table of ROWS (a row = a contiguous key range of ONE memory frame: slot, range, temporal-PE
-// slot), so a captured hipGraph stays valid while the bank's slot table changes.  A workgroup walks a GROUP of
-// consecutive rows (several memory frames when enough workgroups exist without splitting further) and keeps ONE
-// running (m_ref, l, O) for all of them; at every row end it records that row's (m_ref, l_row) pair, from which
-// k_attn_mass derives the per-memory-frame probability mass (transformer.py:636-643) without ever materialising
-// the attention matrix.  With one group the normalised e16 output is written by this kernel itself; with several,
-// each group leaves an unnormalised fp32 partial + (m, l) and k_attn_combine merges them.
+// Decomposition: grid = (query tiles of 128) x heads x key GROUPS x clips (+ the second attention's tiles x heads x clips).  The
+// keys are described by a device-resident table of ROWS (a row = a contiguous key range of ONE memory frame: slot, range,
+// temporal-PE slot), so a captured hipGraph stays valid while the bank's slot table changes.  A workgroup walks a GROUP of
+// consecutive rows (several memory frames when enough workgroups exist without splitting further) and keeps ONE running
+// (m_ref, l, O) for all of them; at every row end it records that row's (m_ref, l_row) pair, from which k_attn_mass derives the
+// per-memory-frame probability mass (transformer.py:636-643) without ever materialising the attention matrix.  With one group
+// the normalised e16 output is written by this kernel itself; with several, each group leaves a partial normalised by its own
+// sum (stored as e16) + (m, l) in fp32, and k_attn_combine merges them (a convex combination).
 //
-// Per workgroup: 4 waves x 32 query rows.  K/V tiles of 64 keys go global -> registers -> LDS (double buffered, one
-// barrier per tile, prefetch runs across row boundaries); K stays row-major [key][32] with an XOR chunk swizzle
-// (conflict-free ds_read_b128), V row-major and read TRANSPOSED (ds_read_b64_tr_b16).
-//   S^T = K . Q^T   : v_mfma_f32_32x32x16_bf16, A = K rows (keys), B = Q^T held in
-//                     registers for the whole kernel; the query sits on the lane,
-//                     so row max / row sum are in-lane plus one exchange with lane^32.
-//                     The temporal-PE term q'.pe[slot] is the accumulator's initial value.
-//   O^T += V^T . P^T: the S^T accumulator (exp2'd, packed to e16) IS the B operand:
-//                     registers 8s..8s+7 of lane half h are keys 16s+8(j>>2)+4h+(j&3),
-//                     and the V^T A-fragment is read in that same key order.
+// Per workgroup: 4 waves x 32 query rows.  K/V tiles of 64 keys go global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds: no
+// VGPR staging, no ds_write) into a ring of NB = 4 tiles, three tiles in flight, the DMA cursor running across row boundaries
+// ahead of the arithmetic; one counted s_waitcnt vmcnt + one bare s_barrier per tile.  The buffer descriptor is rebuilt per tile
+// so that it ends with the row: lanes beyond the row's last key read zeros from the hardware range check (the ragged tail costs
+// no per-lane test).  K stays row-major [key][32] with an XOR chunk swizzle applied to the DMA's SOURCE address (conflict-free
+// ds_read_b128), V row-major and read TRANSPOSED (ds_read_b64_tr_b16); the loop's LDS reads are inline asm with counted
+// lgkmcnt waits (the compiler would drain the DMA ring in front of every read).
+//   S^T = K . Q^T   : v_mfma_f32_32x32x16, A = K rows (keys), B = Q^T held in registers for the whole kernel; the query sits
+//                     on the lane, so row max / row sum are in-lane plus one exchange with lane ^ 32.  The reference m_ref and
+//                     the temporal-PE term q'.pe[slot] are the accumulator's INITIAL value (a persistent C-operand block).
+//   O^T += V^T . P^T: the S^T accumulator (exp2'd, packed to e16) IS the B operand: registers 8s..8s+7 of lane half h are
+//                     keys 16s+8(j>>2)+4h+(j&3), and the V^T A-fragment is read in that same key order.  P never touches LDS.
+//   row sums        : v_dot2c_f32 (packed pair . (1, 1) + acc) on the SAME rounded probabilities the P.V MFMAs consume.
 // Logits live in the log2 domain: Q is pre-scaled by log2(e)/sqrt(32).
 //
-// Softmax reference.  With d = 32 the VALU (one v_exp_f32 per score) is the limiter, so the loop carries no per-score
-// work besides exp2 + e16 packing: the reference m_ref and the temporal-PE bias are the C operand of the first QK MFMA
-// (S' = S - m_ref comes out of the matrix pipe), row sums come from a ones-A-operand MFMA on the same P fragments, and
-// the FAST pass fixes m_ref = the maximum of the group's FIRST tile and never looks at a maximum again: floating point
-// keeps the relative precision of P = 2^(S - m_ref), O and l whatever the offset, so a later, larger score is harmless
-// until 2^(S - m_ref) leaves the fp32 range.  That case is detected after the walk (l above 2^64, inf or NaN for any
-// query of the workgroup) and the whole group is redone by the SAFE pass, the classic online softmax (tile maximum,
-// m_ref moved and O / l rescaled whenever a tile exceeds it by 2^8).  Both passes give the same result to fp32 rounding;
-// tests force the fallback with a key 2^100 above the first tile.
+// Softmax reference.  With d = 32 every score costs one v_exp_f32 against 128 MFMA FLOPs, so the loop carries nothing else per
+// score.  The FAST pass fixes m_ref at the maximum of the group's FIRST tile and never computes a maximum again: floating point
+// keeps the relative precision of P = 2^(S - m_ref), O and l whatever the offset, so a later, larger score is harmless until
+// 2^(S - m_ref) leaves the fp32 range.  That case is detected after the walk (l above 2^64, inf or NaN for any query of the
+// workgroup) and the whole group is redone by the SAFE pass, the classic online softmax (tile maximum, m_ref moved and O / l
+// rescaled whenever a tile exceeds it by 2^8).  Both give the same result to fp32 rounding; tests force the fallback with a key
+// 2^100 above the first tile.  The padded keys of a row's ragged last tile get the score -1e30 in THAT tile only (behind a real
+// branch): they score q.0 + (bias - m_ref), which can lie far ABOVE every real score.  The IEEE-half build always takes SAFE.
 #include "common.h"
 #include "../../include/rmem.h"
 #include <type_traits>

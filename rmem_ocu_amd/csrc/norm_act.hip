@@ -761,9 +761,22 @@ extern "C" int RMEM_API(rmem_gn_act_dwconv5x5_nhwc)(const void* x, int H, int W,
   return RMEM_API(rmem_gn_act_dwconv5x5_nhwc_images)(x, 1, H, W, C, groups, gamma, beta, eps, act, w_t, y, workspace, stream);
 }
 
+static int gn_act_dwconv_launch(const void* x, int images, int H, int W, int C, int groups, const float* gamma, const float* beta, float eps,
+                                int act, const float* w_t, void* y, float* workspace, void* stream, bool with_stats);
 extern "C" int RMEM_API(rmem_gn_act_dwconv5x5_nhwc_images)(const void* x, int images, int H, int W, int C, int groups, const float* gamma,
                                                  const float* beta, float eps, int act, const float* w_t, void* y, float* workspace,
                                                  void* stream) {
+  return gn_act_dwconv_launch(x, images, H, W, C, groups, gamma, beta, eps, act, w_t, y, workspace, stream, true);
+}
+// the same with the statistics partials ALREADY in the workspace ([image][group][64 splits][2]: (sum, sum of squares) of up to 64
+// row ranges per group, unused splits zero) -- written by the producer of x (rmem_lstt_chain_b's gn_partial)
+extern "C" int RMEM_API(rmem_gn_act_dwconv5x5_prestats_nhwc_images)(const void* x, int images, int H, int W, int C, int groups, const float* gamma,
+                                                          const float* beta, float eps, int act, const float* w_t, void* y,
+                                                          const float* stats, void* stream) {
+  return gn_act_dwconv_launch(x, images, H, W, C, groups, gamma, beta, eps, act, w_t, y, const_cast<float*>(stats), stream, false);
+}
+static int gn_act_dwconv_launch(const void* x, int images, int H, int W, int C, int groups, const float* gamma, const float* beta, float eps,
+                                int act, const float* w_t, void* y, float* workspace, void* stream, bool with_stats) {
   RMEM_REQUIRE(images >= 1, "rmem_gn_act_dwconv5x5_nhwc: images must be >= 1");
   RMEM_REQUIRE(x && y && gamma && beta && w_t && workspace && H > 0 && W > 0, "rmem_gn_act_dwconv5x5_nhwc: bad argument");
   RMEM_REQUIRE(groups >= 1 && groups <= 64 && C % groups == 0 && C % DT_C == 0, "rmem_gn_act_dwconv5x5_nhwc: C must be a multiple of 64 and of groups (<= 64)");
@@ -772,7 +785,7 @@ extern "C" int RMEM_API(rmem_gn_act_dwconv5x5_nhwc_images)(const void* x, int im
   RMEM_REQUIRE(act >= 0 && act <= 2, "rmem_gn_act_dwconv5x5_nhwc: bad act");
   const int M = H * W;
   hipStream_t s = (hipStream_t)stream;
-  gn_launch_stats((const e16*)x, images, M, C, cpg, workspace, s);
+  if (with_stats) gn_launch_stats((const e16*)x, images, M, C, cpg, workspace, s);
   const dim3 grid(((W + DT_W - 1) / DT_W) * ((H + DT_H - 1) / DT_H), C / DT_C, images);
   hipLaunchKernelGGL(k_gn_dwconv5, grid, dim3(256), 0, s, (const e16*)x, workspace, gamma, beta, eps, cpg, act, w_t, (e16*)y, H, W, C, M);
   return rmem_check_launch("rmem_gn_act_dwconv5x5_nhwc");

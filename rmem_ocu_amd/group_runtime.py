@@ -81,6 +81,9 @@ class GroupRuntime:
         self.onehot = e(B * H * W, 16)
         self._alloc_lstt(R, num_lstt)
         self.gn_ws = ops.groupnorm_workspace(32, device, images=B)
+        # GroupNorm partial sums of the FFN hidden written by the chained linear1 (one entry per 32-row block, the rest stays zero)
+        self.ffn_stats = torch.zeros(B * 32 * 64 * 2, dtype=F32, device=device)
+        self.chain_stats = self.chain and (self.L + 31) // 32 <= 64 and not __import__('os').environ.get('RMEM_NO_CHAIN_STATS')
         self.conv_ws = torch.empty(16 * R * D_MODEL, dtype=F32, device=device)
         self.mass = torch.zeros(B * L * MAX_CHUNKS, dtype=F32, device=device)          # [B][L][T] compact for the current T
         self.scores = torch.zeros(B, 32 + 64 * 32, dtype=F32, device=device)
@@ -331,9 +334,14 @@ class GroupRuntime:
                 o.append(self._attn(cq, C, self.k4, self.v4, C, self.att2, nchunks=PLAIN_CHUNKS, lk_single=L, kv_cs=L * C))
             o.append(ops.lstt_chain_b(L=L, clips=B, att_long=self.att, att_short=self.att2, x=self.x, w_long=P[d + '.long_proj.wf'],
                                       b_long=P[d + '.long_proj.b'], w_short=P[d + '.short_proj.wf'], b_short=P[d + '.short_proj.b'],
-                                      tgt3=self.tgt3[i], ln3=ln(d + '.ln3'), w1=P[d + '.linear1.wf'], b1=P[d + '.linear1.b'], h1=self.h1))
-            o.append(ops.gn_act_dwconv5x5(self.h1, P[d + '.gn.g'], P[d + '.gn.b'], P[d + '.dw.w'], self.h3, self.gn_ws, H=self.H16,
-                                          W=self.W16, C=FFN, groups=32, act=2, images=B))
+                                      tgt3=self.tgt3[i], ln3=ln(d + '.ln3'), w1=P[d + '.linear1.wf'], b1=P[d + '.linear1.b'], h1=self.h1,
+                                      gn_partial=self.ffn_stats if self.chain_stats else None, gn_splits=64 if self.chain_stats else 0))
+            if self.chain_stats:     # the GroupNorm statistics of the FFN hidden came out of linear1's epilogue (<= 64 row blocks per clip)
+                o.append(ops.gn_act_dwconv5x5_prestats(self.h1, P[d + '.gn.g'], P[d + '.gn.b'], P[d + '.dw.w'], self.h3, self.ffn_stats,
+                                                       H=self.H16, W=self.W16, C=FFN, groups=32, act=2, images=B))
+            else:
+                o.append(ops.gn_act_dwconv5x5(self.h1, P[d + '.gn.g'], P[d + '.gn.b'], P[d + '.dw.w'], self.h3, self.gn_ws, H=self.H16,
+                                              W=self.W16, C=FFN, groups=32, act=2, images=B))
             o.append(chain_c(i, i + 1 if i + 1 < self.NL else None))
         return o
 

@@ -346,6 +346,16 @@ def gn_act_dwconv5x5(x, gamma, beta, w_t, y, ws, *, H, W, C, groups, act=2, eps=
     return Op(_fn('rmem_gn_act_dwconv5x5_nhwc_images', dt), args, 'rmem_gn_act_dwconv5x5_nhwc', (x, gamma, beta, w_t, y, ws))
 
 
+def gn_act_dwconv5x5_prestats(x, gamma, beta, w_t, y, stats, *, H, W, C, groups, act=2, eps=1e-5, images=1) -> Op:
+    """gn_act_dwconv5x5 whose statistics partials (fp32 [images, groups, 64, 2]) were written by x's producer: one launch."""
+    _dev(x, gamma, beta, w_t, y, stats)
+    dt = x.dtype
+    assert x.dtype == dt and y.dtype == dt and w_t.dtype == F32 and w_t.numel() == 25 * C and gamma.numel() == C
+    assert stats.dtype == F32 and stats.numel() >= images * groups * 64 * 2
+    args = (_ptr(x), images, H, W, C, groups, _ptr(gamma), _ptr(beta), eps, act, _ptr(w_t), _ptr(y), _ptr(stats))
+    return Op(_fn('rmem_gn_act_dwconv5x5_prestats_nhwc_images', dt), args, 'rmem_gn_act_dwconv5x5_prestats_nhwc', (x, gamma, beta, w_t, y, stats))
+
+
 def dwconv5x5(x, w_t, y, *, H, W, C) -> Op:
     _dev(x, w_t, y)
     dt = x.dtype
