@@ -51,13 +51,62 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 // LayerNorm over a 256-channel row held by one wave, 4 consecutive channels per lane (rmem_layernorm256 and the LSTT chain
-// kernels share this one operation sequence, so fused and unfused routes round identically)
-__device__ __forceinline__ f32x4 rmem_ln256_row(f32x4 v, f32x4 g, f32x4 bt, float eps) {
-  const float mean = wave_sum(v[0] + v[1] + v[2] + v[3]) * (1.f / 256.f);
-  const f32x4 dv = v - mean;
-  const float var = wave_sum(dv[0] * dv[0] + dv[1] * dv[1] + dv[2] * dv[2] + dv[3] * dv[3]) * (1.f / 256.f);
+// kernels share this one operation sequence -- every product / sum spelled out, so that -ffp-contract cannot contract the two
+// call sites differently -- and fused and unfused routes round identically)
+// (#pragma clang fp contract(off): with -ffp-contract=fast the compiler decides per call site whether a * b + c becomes an fma;
+// two sites that must round identically may not leave that to it -- the IEEE-half build of the chain kernels differed from
+// rmem_layernorm256 by one fp32 ulp in `v - sum * (1 / 256)` until every fma here was spelled out)
+__device__ __forceinline__ float rmem_sum4(f32x4 v) {
+#pragma clang fp contract(off)
+  return ((v[0] + v[1]) + v[2]) + v[3];
+}
+__device__ __forceinline__ float rmem_sumsq4(f32x4 d) {
+#pragma clang fp contract(off)
+  return __builtin_fmaf(d[3], d[3], __builtin_fmaf(d[2], d[2], __builtin_fmaf(d[1], d[1], d[0] * d[0])));
+}
+__device__ __forceinline__ f32x4 rmem_ln_center(f32x4 v, float sum) {
+#pragma clang fp contract(off)
+  const float mean = sum * (1.f / 256.f);
+  return f32x4{v[0] - mean, v[1] - mean, v[2] - mean, v[3] - mean};
+}
+__device__ __forceinline__ f32x4 rmem_ln_apply(f32x4 dv, float sumsq, float eps, f32x4 g, f32x4 bt) {
+#pragma clang fp contract(off)
+  const float var = sumsq * (1.f / 256.f);
   const float rstd = rsqrtf(var + eps);
-  return dv * rstd * g + bt;
+  f32x4 o;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float t = dv[j] * rstd;
+    o[j] = __builtin_fmaf(t, g[j], bt[j]);
+  }
+  return o;
+}
+__device__ __forceinline__ f32x4 rmem_ln256_row(f32x4 v, f32x4 g, f32x4 bt, float eps) {
+  const f32x4 dv = rmem_ln_center(v, wave_sum(rmem_sum4(v)));
+  return rmem_ln_apply(dv, wave_sum(rmem_sumsq4(dv)), eps, g, bt);
+}
+// the same for NR rows at once (lane = the same 4 channels of every row): per row exactly rmem_ln256_row's operations, the NR
+// butterfly reductions interleaved so that their cross-lane latencies overlap instead of adding up
+template <int NR>
+__device__ __forceinline__ void rmem_ln256_rows(f32x4 (&v)[NR], f32x4 g, f32x4 bt, float eps) {
+  float s[NR];
+#pragma unroll
+  for (int r = 0; r < NR; ++r) s[r] = rmem_sum4(v[r]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+    for (int r = 0; r < NR; ++r) s[r] += __shfl_xor(s[r], o, 64);
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    v[r] = rmem_ln_center(v[r], s[r]);
+    s[r] = rmem_sumsq4(v[r]);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+    for (int r = 0; r < NR; ++r) s[r] += __shfl_xor(s[r], o, 64);
+#pragma unroll
+  for (int r = 0; r < NR; ++r) v[r] = rmem_ln_apply(v[r], s[r], eps, g, bt);
 }
 
 // source coordinate of destination index d of a bilinear resize (PyTorch upsample_bilinear2d semantics)

@@ -35,25 +35,42 @@ constexpr int BM = 32;            // rows per workgroup
 constexpr int XS = 260;           // fp32 staging row stride (floats): 4 rows apart = 16 banks apart, conflict-free ds_write_b32
 constexpr int PANEL = BM * 64;    // elements of one [32 rows][64 k] A panel (128-byte rows, XOR-swizzled 16-byte chunks)
 constexpr int PF = 4;             // k-chunks (of 32) of B fragments in flight per wave
+constexpr int OOB = (int)0x80000000;   // byte offset beyond every buffer: the hardware range check drops the store
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 1) & 7)) << 3); }
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
-__device__ __forceinline__ f32x4 ld4(const e16* p) {
-  const e16x4 v = *reinterpret_cast<const e16x4*>(p);
-  return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
-}
 __device__ __forceinline__ e16x4 cvt4(f32x4 v) { return e16x4{(e16)v[0], (e16)v[1], (e16)v[2], (e16)v[3]}; }
 __device__ __forceinline__ f32x4 up4(e16x4 v) { return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]}; }
 
-// [nrows <= 32][64 * NP] e16 rows of stride ld at src -> A panels p0 .. p0 + NP - 1 (rows beyond nrows: zeros)
+// Stores go through buffer descriptors: a row beyond the block's last one passes the offset OOB and the hardware drops the
+// store -- NO branch in the row loops.  (With `if (row < nrows) store` the compiler branches around every row, loses track of
+// the loads in flight at each join and drains them all -- s_waitcnt vmcnt(0), previous row's store included -- once per row.)
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const void* base, long bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ void st8(rsrc_t r, int off, e16x4 v) { __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, off, 0, 0); }
+__device__ __forceinline__ void st16(rsrc_t r, int off, f32x4 v) { __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, off, 0, 0); }
+#else
+struct rsrc_t {};
+__device__ inline rsrc_t make_rsrc(const void*, long) { return {}; }
+__device__ inline void st8(rsrc_t, int, e16x4) {}
+__device__ inline void st16(rsrc_t, int, f32x4) {}
+#endif
+
+// [nrows <= 32][64 * NP] e16 rows of stride ld at src -> A panels p0 .. p0 + NP - 1
 template <int NP>
 __device__ __forceinline__ void stage_tile(e16* A16, int p0, const e16* src, long ld, int nrows) {
   const int row = threadIdx.x >> 3, ch = threadIdx.x & 7;
-  const e16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+  // rows beyond the block's last one re-read that last row (their results are never stored): an unconditional load
+  const e16* sr = src + min(row, nrows - 1) * ld + ch * 8;
   e16x8 v[NP];
 #pragma unroll
-  for (int p = 0; p < NP; ++p) v[p] = row < nrows ? *reinterpret_cast<const e16x8*>(src + row * ld + p * 64 + ch * 8) : zero;
+  for (int p = 0; p < NP; ++p) v[p] = *reinterpret_cast<const e16x8*>(sr + p * 64);
 #pragma unroll
   for (int p = 0; p < NP; ++p) *reinterpret_cast<e16x8*>(&A16[(p0 + p) * PANEL + swz(row, ch)]) = v[p];
 }
@@ -68,11 +85,14 @@ struct BRing { e16x8 b[PF][4]; };
 // this wave's weight stream of column block nb: [K / 32][4][64 lanes][8]
 __device__ __forceinline__ const e16* wstream(const e16* w, int nb, int wave, int KC) { return w + (long)(nb * 4 + wave) * KC * 2048; }
 
+// (sched_barrier: the machine scheduler otherwise SINKS these loads down to their first use to save registers, which turns the
+// ring into load -> wait -> MFMA, one L2 round trip per k-chunk)
 __device__ __forceinline__ void b_preload(BRing& r, const e16* wp, int lane) {
 #pragma unroll
   for (int u = 0; u < PF; ++u)
 #pragma unroll
     for (int j = 0; j < 4; ++j) r.b[u][j] = *reinterpret_cast<const e16x8*>(wp + ((u * 4 + j) * 64 + lane) * 8);
+  __builtin_amdgcn_sched_barrier(0);
 }
 
 // acc[2][4] (32 rows x this wave's 64 columns) += A[32][64 * NP] (panels p0 ..) . W^T, k ascending in chunks of 32: the
@@ -94,6 +114,7 @@ __device__ __forceinline__ void gemm32(const e16* A16, int p0, const e16* wp, BR
     if (kc + PF < KC) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) r.b[kc % PF][j] = *reinterpret_cast<const e16x8*>(wp + (((kc + PF) * 4 + j) * 64 + lane) * 8);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
 }
@@ -125,6 +146,37 @@ __device__ __forceinline__ Blk my_rows(int L) {
   return b;
 }
 
+// Row phases.  A wave owns rows wave * 8 .. wave * 8 + 7 of the block, a lane 4 consecutive channels of each.  Everything a phase
+// reads from global memory is loaded into registers at the START of the kernel (x rows, short-term memory rows, biases, norm
+// parameters) or before the GEMM whose epilogue needs it: a load issued inside the phase costs one full memory latency PER ROW
+// (the phase is a dependent chain of cross-lane reductions; the first version of this file spent 12 us per phase that way).
+template <typename T>
+struct Rows8 { T r[8]; };
+
+__device__ __forceinline__ Rows8<f32x4> load_rows_f32(const float* base, int ld, const Blk& blk, int wave, int c0) {
+  Rows8<f32x4> o;
+#pragma unroll
+  for (int rr = 0; rr < 8; ++rr) {
+    const int row = min(wave * 8 + rr, blk.nrows - 1);      // (rows beyond the block: the last row again, unconditionally; never stored)
+    o.r[rr] = ld4(base + (blk.g0 + row) * ld + c0);
+  }
+  return o;
+}
+__device__ __forceinline__ Rows8<e16x4> load_rows_e16(const e16* base, int ld, const Blk& blk, int wave, int c0) {
+  Rows8<e16x4> o;
+#pragma unroll
+  for (int rr = 0; rr < 8; ++rr) {
+    const int row = min(wave * 8 + rr, blk.nrows - 1);
+    o.r[rr] = *reinterpret_cast<const e16x4*>(base + (blk.g0 + row) * ld + c0);
+  }
+  return o;
+}
+// byte offset of (row rr of this wave, channel c0) in a [rows][ld] array of `esz`-byte elements, or OOB beyond the block
+__device__ __forceinline__ int row_off(const Blk& blk, int wave, int rr, int ld, int c0, int esz) {
+  const int row = wave * 8 + rr;
+  return row < blk.nrows ? (int)(((blk.g0 + row) * ld + c0) * esz) : OOB;
+}
+
 // ------------------------------------------------------------------------------------------------------------ chain A
 __global__ __launch_bounds__(256) void k_chain_a(rmem_chain_a_desc d) {
   __shared__ __attribute__((aligned(16))) char smem[4 * PANEL * 2 + BM * XS * 4];
@@ -133,11 +185,19 @@ __global__ __launch_bounds__(256) void k_chain_a(rmem_chain_a_desc d) {
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const Blk blk = my_rows(d.L);
   const int c0 = lane * 4;
+  const long rows = (long)d.clips * d.L;
+  const rsrc_t rx = make_rsrc(d.x, rows * 1024), rcv = make_rsrc(d.curr_v, rows * 512), rcq = make_rsrc(d.curr_q, rows * 512),
+               rk4 = make_rsrc(d.k4, rows * 512), rv4 = make_rsrc(d.v4, rows * 512);
+  const f32x4 bp = ld4(d.b_proj + c0), g2 = ld4(d.ln2_g + c0), b2 = ld4(d.ln2_b + c0);
+  const f32x4 bq = ld4(d.b_q + c0), g4 = ld4(d.ln4_g + c0), b4 = ld4(d.ln4_b + c0);
+  const Rows8<f32x4> xo = load_rows_f32(d.x, 256, blk, wave, c0);
+  const Rows8<e16x4> sk = load_rows_e16((const e16*)d.short_k, 256, blk, wave, c0);
+  const Rows8<e16x4> sv = load_rows_e16((const e16*)d.short_v, 256, blk, wave, c0);
   BRing ring;
   f32x4 acc[2][4];
   const e16* wp = wstream((const e16*)d.w_proj, 0, wave, 8);
-  b_preload(ring, wp, lane);                                     // weights do not depend on anything: in flight before the rows arrive
   stage_tile<4>(A16, 0, (const e16*)d.att + blk.g0 * 256, 256, blk.nrows);
+  b_preload(ring, wp, lane);                                     // weights do not depend on anything: in flight before the rows arrive
   __syncthreads();
   zero_acc(acc);
   gemm32<4>(A16, 0, wp, ring, acc, lane);
@@ -146,23 +206,23 @@ __global__ __launch_bounds__(256) void k_chain_a(rmem_chain_a_desc d) {
   b_preload(ring, wq, lane);
   __syncthreads();
   // x += self_proj(att) ; curr_V = LN2(x)
-  const f32x4 bp = ld4(d.b_proj + c0), g2 = ld4(d.ln2_g + c0), b2 = ld4(d.ln2_b + c0);
   e16x4 cv[8];
+  {
+    f32x4 v[8];
 #pragma unroll
-  for (int rr = 0; rr < 8; ++rr) {
-    const int row = wave * 8 + rr;
-    const bool ok = row < blk.nrows;
-    f32x4 v = ld4(&X[row * XS + c0]);
-    v += bp;
-    if (ok) {
-      float* xr = d.x + (blk.g0 + row) * 256 + c0;
-      v += ld4(xr);
-      *reinterpret_cast<f32x4*>(xr) = v;
+    for (int rr = 0; rr < 8; ++rr) {
+      v[rr] = ld4(&X[(wave * 8 + rr) * XS + c0]);
+      v[rr] += bp;
+      v[rr] += xo.r[rr];
+      st16(rx, row_off(blk, wave, rr, 256, c0, 4), v[rr]);
     }
-    const f32x4 o = rmem_ln256_row(v, g2, b2, d.eps);
-    cv[rr] = cvt4(o);
-    if (ok) *reinterpret_cast<e16x4*>((e16*)d.curr_v + (blk.g0 + row) * 256 + c0) = cv[rr];
-    put_a(A16, 0, row, lane, cv[rr]);
+    rmem_ln256_rows<8>(v, g2, b2, d.eps);
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+      cv[rr] = cvt4(v[rr]);
+      st8(rcv, row_off(blk, wave, rr, 256, c0, 2), cv[rr]);
+      put_a(A16, 0, wave * 8 + rr, lane, cv[rr]);
+    }
   }
   __syncthreads();
   zero_acc(acc);
@@ -170,41 +230,55 @@ __global__ __launch_bounds__(256) void k_chain_a(rmem_chain_a_desc d) {
   dump_acc(X, acc, wave, lane);
   __syncthreads();
   // curr_Q ; k4 = LN4(short_K + curr_Q) ; v4 = LN4(short_V + curr_V)
-  const f32x4 bq = ld4(d.b_q + c0), g4 = ld4(d.ln4_g + c0), b4 = ld4(d.ln4_b + c0);
+  {
+    f32x4 kk[8], vv[8];
 #pragma unroll
-  for (int rr = 0; rr < 8; ++rr) {
-    const int row = wave * 8 + rr;
-    if (row >= blk.nrows) continue;
-    const long off = (blk.g0 + row) * 256 + c0;
-    f32x4 q = ld4(&X[row * XS + c0]);
-    q += bq;
-    const e16x4 cq = cvt4(q);
-    *reinterpret_cast<e16x4*>((e16*)d.curr_q + off) = cq;
-    f32x4 kk = ld4((const e16*)d.short_k + off);
-    kk += up4(cq);
-    *reinterpret_cast<e16x4*>((e16*)d.k4 + off) = cvt4(rmem_ln256_row(kk, g4, b4, d.eps));
-    f32x4 vv = ld4((const e16*)d.short_v + off);
-    vv += up4(cv[rr]);
-    *reinterpret_cast<e16x4*>((e16*)d.v4 + off) = cvt4(rmem_ln256_row(vv, g4, b4, d.eps));
+    for (int rr = 0; rr < 8; ++rr) {
+      f32x4 q = ld4(&X[(wave * 8 + rr) * XS + c0]);
+      q += bq;
+      const e16x4 cq = cvt4(q);
+      st8(rcq, row_off(blk, wave, rr, 256, c0, 2), cq);
+      kk[rr] = up4(sk.r[rr]);
+      kk[rr] += up4(cq);
+      vv[rr] = up4(sv.r[rr]);
+      vv[rr] += up4(cv[rr]);
+    }
+    rmem_ln256_rows<8>(kk, g4, b4, d.eps);
+    rmem_ln256_rows<8>(vv, g4, b4, d.eps);
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+      const int off = row_off(blk, wave, rr, 256, c0, 2);
+      st8(rk4, off, cvt4(kk[rr]));
+      st8(rv4, off, cvt4(vv[rr]));
+    }
   }
 }
 
 // ------------------------------------------------------------------------------------------------------------ chain B
+// STATS: also write the GroupNorm partial sums of h1 (d.gn_partial)
+template <bool STATS>
 __global__ __launch_bounds__(256) void k_chain_b(rmem_chain_b_desc d) {
-  __shared__ __attribute__((aligned(16))) char smem[8 * PANEL * 2 + 2 * BM * XS * 4];
+  __shared__ __attribute__((aligned(16))) char smem[8 * PANEL * 2 + 2 * BM * XS * 4 + 4 * 4 * 8 * 2 * 4];
   e16* A16 = reinterpret_cast<e16*>(smem);
   float* Xa = reinterpret_cast<float*>(smem + 8 * PANEL * 2);
   float* Xb = Xa + BM * XS;
-  __shared__ float gsum[4][8][2];
+  float* gsum = Xb + BM * XS;               // [column block][wave][group of the block][2]
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const Blk blk = my_rows(d.L);
   const int c0 = lane * 4;
+  const long rows = (long)d.clips * d.L;
+  const rsrc_t rx = make_rsrc(d.x, rows * 1024), rt3 = make_rsrc(d.tgt3, rows * 512), rh1 = make_rsrc(d.h1, rows * 2048);
+  const f32x4 bl = ld4(d.b_long + c0), bs = ld4(d.b_short + c0), g3 = ld4(d.ln3_g + c0), b3 = ld4(d.ln3_b + c0);
+  f32x4 b1[4];
+#pragma unroll
+  for (int nb = 0; nb < 4; ++nb) b1[nb] = ld4(d.b1 + nb * 256 + c0);
+  const Rows8<f32x4> xo = load_rows_f32(d.x, 256, blk, wave, c0);
   BRing ring;
   f32x4 acc[2][4];
   const e16* wl = wstream((const e16*)d.w_long, 0, wave, 8);
-  b_preload(ring, wl, lane);
   stage_tile<4>(A16, 0, (const e16*)d.att_long + blk.g0 * 256, 256, blk.nrows);
   stage_tile<4>(A16, 4, (const e16*)d.att_short + blk.g0 * 256, 256, blk.nrows);
+  b_preload(ring, wl, lane);
   __syncthreads();
   zero_acc(acc);
   gemm32<4>(A16, 0, wl, ring, acc, lane);
@@ -219,28 +293,24 @@ __global__ __launch_bounds__(256) void k_chain_b(rmem_chain_b_desc d) {
   __syncthreads();
   // x += long_proj(attL) ; tgt3 = short_proj(attS) ; x += tgt3 ; LN3(x) -> A panels 0..3
   {
-    const f32x4 bl = ld4(d.b_long + c0), bs = ld4(d.b_short + c0), g3 = ld4(d.ln3_g + c0), b3 = ld4(d.ln3_b + c0);
+    f32x4 t[8];
 #pragma unroll
     for (int rr = 0; rr < 8; ++rr) {
-      const int row = wave * 8 + rr;
-      const bool ok = row < blk.nrows;
-      f32x4 v1 = ld4(&Xa[row * XS + c0]);
+      f32x4 v1 = ld4(&Xa[(wave * 8 + rr) * XS + c0]);
       v1 += bl;
-      f32x4 t = ld4(&Xb[row * XS + c0]);
-      t += bs;
-      if (ok) {
-        float* xr = d.x + (blk.g0 + row) * 256 + c0;
-        v1 += ld4(xr);                                  // x after the long-term projection (what the unfused route stores)
-        *reinterpret_cast<e16x4*>((e16*)d.tgt3 + (blk.g0 + row) * 256 + c0) = cvt4(t);
-        t += v1;
-        *reinterpret_cast<f32x4*>(xr) = t;
-      }
-      put_a(A16, 0, row, lane, cvt4(rmem_ln256_row(t, g3, b3, d.eps)));
+      t[rr] = ld4(&Xb[(wave * 8 + rr) * XS + c0]);
+      t[rr] += bs;
+      v1 += xo.r[rr];                                   // x after the long-term projection (what the unfused route stores)
+      st8(rt3, row_off(blk, wave, rr, 256, c0, 2), cvt4(t[rr]));
+      t[rr] += v1;
+      st16(rx, row_off(blk, wave, rr, 256, c0, 4), t[rr]);
     }
+    rmem_ln256_rows<8>(t, g3, b3, d.eps);
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) put_a(A16, 0, wave * 8 + rr, lane, cvt4(t[rr]));
   }
   __syncthreads();
   // h1 = linear1(LN3(x)): four column blocks of 256, staged alternately through Xa / Xb (one barrier per block)
-  float gs = 0.f, gss = 0.f;            // this lane's channels belong to ONE GroupNorm group (32 channels = 8 lanes) per block
 #pragma unroll
   for (int nb = 0; nb < 4; ++nb) {
     float* X = (nb & 1) ? Xb : Xa;
@@ -249,35 +319,38 @@ __global__ __launch_bounds__(256) void k_chain_b(rmem_chain_b_desc d) {
     dump_acc(X, acc, wave, lane);
     if (nb < 3) { w1 = wstream((const e16*)d.w1, nb + 1, wave, 8); b_preload(ring, w1, lane); }
     __syncthreads();
-    const f32x4 b1 = ld4(d.b1 + nb * 256 + c0);
-    gs = 0.f; gss = 0.f;
+    float gs = 0.f, gss = 0.f;          // this lane's channels belong to ONE GroupNorm group (32 channels = 8 lanes) per block
 #pragma unroll
     for (int rr = 0; rr < 8; ++rr) {
-      const int row = wave * 8 + rr;
-      if (row >= blk.nrows) continue;
-      f32x4 v = ld4(&X[row * XS + c0]);
-      v += b1;
+      f32x4 v = ld4(&X[(wave * 8 + rr) * XS + c0]);
+      v += b1[nb];
       const e16x4 h = cvt4(v);
-      *reinterpret_cast<e16x4*>((e16*)d.h1 + (blk.g0 + row) * 1024 + nb * 256 + c0) = h;
-      const f32x4 hf = up4(h);
-      gs += hf[0] + hf[1] + hf[2] + hf[3];
-      gss += hf[0] * hf[0] + hf[1] * hf[1] + hf[2] * hf[2] + hf[3] * hf[3];
+      st8(rh1, row_off(blk, wave, rr, 1024, nb * 256 + c0, 2), h);
+      if (STATS) {
+        const f32x4 hf = up4(h);
+        const float okf = wave * 8 + rr < blk.nrows ? 1.f : 0.f;      // (a select, not a branch)
+        gs += okf * rmem_sum4(hf);
+        gss += okf * rmem_sumsq4(hf);
+      }
     }
-    if (d.gn_partial) {
-      // (sum, sum of squares) of this block's rows per group: 8 lanes -> wave -> workgroup, fixed order
+    if (STATS) {
+      // (sum, sum of squares) of this block's rows per group: 8 lanes -> wave; the waves are added after the last block
       gs += __shfl_xor(gs, 1); gss += __shfl_xor(gss, 1);
       gs += __shfl_xor(gs, 2); gss += __shfl_xor(gss, 2);
       gs += __shfl_xor(gs, 4); gss += __shfl_xor(gss, 4);
-      if ((lane & 7) == 0) { gsum[wave][lane >> 3][0] = gs; gsum[wave][lane >> 3][1] = gss; }
-      __syncthreads();
-      if (threadIdx.x < 8) {
-        const int g = threadIdx.x;
-        const float a = gsum[0][g][0] + gsum[1][g][0] + gsum[2][g][0] + gsum[3][g][0];
-        const float b = gsum[0][g][1] + gsum[1][g][1] + gsum[2][g][1] + gsum[3][g][1];
-        // workspace [clip][group 0..31][split][2] with d.gn_splits splits per group (this workgroup is split blockIdx.x)
-        float* o = d.gn_partial + (((long)blockIdx.y * 32 + nb * 8 + g) * d.gn_splits + blockIdx.x) * 2;
-        o[0] = a; o[1] = b;
-      }
+      if ((lane & 7) == 0) { gsum[((nb * 4 + wave) * 8 + (lane >> 3)) * 2] = gs; gsum[((nb * 4 + wave) * 8 + (lane >> 3)) * 2 + 1] = gss; }
+    }
+  }
+  if (STATS) {
+    __syncthreads();
+    if (threadIdx.x < 32) {
+      // workspace [clip][group 0..31][split][2] with d.gn_splits splits per group (this workgroup is split blockIdx.x)
+      const int nb = threadIdx.x >> 3, g = threadIdx.x & 7;
+      float a = 0.f, b = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) { a += gsum[((nb * 4 + w) * 8 + g) * 2]; b += gsum[((nb * 4 + w) * 8 + g) * 2 + 1]; }
+      float* o = d.gn_partial + (((long)blockIdx.y * 32 + threadIdx.x) * d.gn_splits + blockIdx.x) * 2;
+      o[0] = a; o[1] = b;
     }
   }
 }
@@ -295,13 +368,25 @@ __global__ __launch_bounds__(256) void k_chain_c(rmem_chain_c_desc d) {
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const Blk blk = my_rows(d.L);
   const int c0 = lane * 4;
+  const long rows = (long)d.clips * d.L;
+  const rsrc_t rx = make_rsrc(d.x, rows * 1024), rdec = make_rsrc(d.dec_out, FFN2 ? ((rows - 1) * d.ld_dec + 256) * 2 : 0),
+               rqkv = make_rsrc(d.qkv, NEXT ? rows * 1536 : 0);
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  const f32x4 b2 = FFN2 ? ld4(d.b2 + c0) : z4, gd = FFN2 ? ld4(d.dec_g + c0) : z4, bd = FFN2 ? ld4(d.dec_b + c0) : z4;
+  const f32x4 g1 = NEXT ? ld4(d.ln1_g + c0) : z4, b1 = NEXT ? ld4(d.ln1_b + c0) : z4;
+  f32x4 bq[3] = {z4, z4, z4};
+  if (NEXT) {
+#pragma unroll
+    for (int nb = 0; nb < 3; ++nb) bq[nb] = ld4(d.b_qkv + nb * 256 + c0);
+  }
+  const Rows8<f32x4> xo = load_rows_f32(d.x, 256, blk, wave, c0);
   BRing ring;
   f32x4 acc[2][4];
   const e16* wq = NEXT ? wstream((const e16*)d.w_qkv, 0, wave, 8) : nullptr;
   if (FFN2) {
     const e16* w2 = wstream((const e16*)d.w2, 0, wave, 32);
-    b_preload(ring, w2, lane);
     stage_tile<16>(A16, 0, (const e16*)d.h3 + blk.g0 * 1024, 1024, blk.nrows);
+    b_preload(ring, w2, lane);
     __syncthreads();
     zero_acc(acc);
     gemm32<16>(A16, 0, w2, ring, acc, lane);
@@ -312,27 +397,28 @@ __global__ __launch_bounds__(256) void k_chain_c(rmem_chain_c_desc d) {
     b_preload(ring, wq, lane);
   }
   {
-    f32x4 b2 = {0.f, 0.f, 0.f, 0.f}, gd = b2, bd = b2, g1 = b2, b1 = b2;
-    if (FFN2) { b2 = ld4(d.b2 + c0); gd = ld4(d.dec_g + c0); bd = ld4(d.dec_b + c0); }
-    if (NEXT) { g1 = ld4(d.ln1_g + c0); b1 = ld4(d.ln1_b + c0); }
+    f32x4 v[8];
+    if (FFN2) {
+      f32x4 vd[8];
 #pragma unroll
-    for (int rr = 0; rr < 8; ++rr) {
-      const int row = wave * 8 + rr;
-      const bool ok = row < blk.nrows;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      float* xr = d.x + (blk.g0 + row) * 256 + c0;
-      if (FFN2) {
-        v = ld4(&Xa[row * XS + c0]);
-        v += b2;
-        if (ok) {
-          v += ld4(xr);
-          *reinterpret_cast<f32x4*>(xr) = v;
-          *reinterpret_cast<e16x4*>((e16*)d.dec_out + (blk.g0 + row) * d.ld_dec + c0) = cvt4(rmem_ln256_row(v, gd, bd, d.eps));
-        }
-      } else if (ok) {
-        v = ld4(xr);
+      for (int rr = 0; rr < 8; ++rr) {
+        v[rr] = ld4(&Xa[(wave * 8 + rr) * XS + c0]);
+        v[rr] += b2;
+        v[rr] += xo.r[rr];
+        st16(rx, row_off(blk, wave, rr, 256, c0, 4), v[rr]);
+        vd[rr] = v[rr];
       }
-      if (NEXT) put_a(A16, 0, row, lane, cvt4(rmem_ln256_row(v, g1, b1, d.eps)));
+      rmem_ln256_rows<8>(vd, gd, bd, d.eps);
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr) st8(rdec, row_off(blk, wave, rr, d.ld_dec, c0, 2), cvt4(vd[rr]));
+    } else {
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr) v[rr] = xo.r[rr];
+    }
+    if (NEXT) {
+      rmem_ln256_rows<8>(v, g1, b1, d.eps);
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr) put_a(A16, 0, wave * 8 + rr, lane, cvt4(v[rr]));
     }
   }
   if (!NEXT) return;
@@ -340,20 +426,18 @@ __global__ __launch_bounds__(256) void k_chain_c(rmem_chain_c_desc d) {
 #pragma unroll
   for (int nb = 0; nb < 3; ++nb) {
     float* X = (nb & 1) ? Xb : Xa;
+    const Rows8<f32x4> pos = load_rows_f32(d.pos_qk + nb * 256, 768, blk, wave, c0);     // in flight under the GEMM
     zero_acc(acc);
     gemm32<4>(A16, 0, wq, ring, acc, lane);
     dump_acc(X, acc, wave, lane);
     if (nb < 2) { wq = wstream((const e16*)d.w_qkv, nb + 1, wave, 8); b_preload(ring, wq, lane); }
     __syncthreads();
-    const f32x4 bq = ld4(d.b_qkv + nb * 256 + c0);
 #pragma unroll
     for (int rr = 0; rr < 8; ++rr) {
-      const int row = wave * 8 + rr;
-      if (row >= blk.nrows) continue;
-      f32x4 v = ld4(&X[row * XS + c0]);
-      v += bq;
-      v += ld4(d.pos_qk + (blk.g0 + row) * 768 + nb * 256 + c0);
-      *reinterpret_cast<e16x4*>((e16*)d.qkv + (blk.g0 + row) * 768 + nb * 256 + c0) = cvt4(v);
+      f32x4 v = ld4(&X[(wave * 8 + rr) * XS + c0]);
+      v += bq[nb];
+      v += pos.r[rr];
+      st8(rqkv, row_off(blk, wave, rr, 768, nb * 256 + c0, 2), cvt4(v));
     }
   }
 }
@@ -363,7 +447,7 @@ bool al16(const void* p) { return p == nullptr || ((uintptr_t)p % 16) == 0; }
 }  // namespace
 
 extern "C" int RMEM_API(rmem_lstt_chain_a)(const rmem_chain_a_desc* d, void* stream) {
-  RMEM_REQUIRE(d && d->L > 0 && d->clips >= 1, "rmem_lstt_chain_a: bad geometry");
+  RMEM_REQUIRE(d && d->L > 0 && d->clips >= 1 && (long)d->L * d->clips < (1L << 20), "rmem_lstt_chain_a: bad geometry (rows must stay below 2^20)");
   RMEM_REQUIRE(d->att && d->x && d->w_proj && d->b_proj && d->ln2_g && d->ln2_b && d->curr_v && d->w_q && d->b_q && d->curr_q && d->short_k &&
                d->short_v && d->ln4_g && d->ln4_b && d->k4 && d->v4, "rmem_lstt_chain_a: null argument");
   RMEM_REQUIRE(al16(d->att) && al16(d->x) && al16(d->w_proj) && al16(d->w_q) && al16(d->curr_v) && al16(d->curr_q) && al16(d->short_k) &&
@@ -374,19 +458,20 @@ extern "C" int RMEM_API(rmem_lstt_chain_a)(const rmem_chain_a_desc* d, void* str
 }
 
 extern "C" int RMEM_API(rmem_lstt_chain_b)(const rmem_chain_b_desc* d, void* stream) {
-  RMEM_REQUIRE(d && d->L > 0 && d->clips >= 1, "rmem_lstt_chain_b: bad geometry");
+  RMEM_REQUIRE(d && d->L > 0 && d->clips >= 1 && (long)d->L * d->clips < (1L << 20), "rmem_lstt_chain_b: bad geometry (rows must stay below 2^20)");
   RMEM_REQUIRE(d->att_long && d->att_short && d->x && d->w_long && d->b_long && d->w_short && d->b_short && d->tgt3 && d->ln3_g && d->ln3_b &&
                d->w1 && d->b1 && d->h1, "rmem_lstt_chain_b: null argument");
   RMEM_REQUIRE(al16(d->att_long) && al16(d->att_short) && al16(d->x) && al16(d->w_long) && al16(d->w_short) && al16(d->tgt3) && al16(d->w1) &&
                al16(d->h1) && al16(d->b_long) && al16(d->b_short) && al16(d->b1) && al16(d->ln3_g) && al16(d->ln3_b),
                "rmem_lstt_chain_b: operands must be 16-byte aligned");
   RMEM_REQUIRE(!d->gn_partial || d->gn_splits >= (d->L + BM - 1) / BM, "rmem_lstt_chain_b: gn_splits must cover the row blocks of a clip");
-  hipLaunchKernelGGL(k_chain_b, dim3((d->L + BM - 1) / BM, d->clips), dim3(256), 0, (hipStream_t)stream, *d);
+  if (d->gn_partial) hipLaunchKernelGGL(k_chain_b<true>, dim3((d->L + BM - 1) / BM, d->clips), dim3(256), 0, (hipStream_t)stream, *d);
+  else hipLaunchKernelGGL(k_chain_b<false>, dim3((d->L + BM - 1) / BM, d->clips), dim3(256), 0, (hipStream_t)stream, *d);
   return rmem_check_launch("rmem_lstt_chain_b");
 }
 
 extern "C" int RMEM_API(rmem_lstt_chain_c)(const rmem_chain_c_desc* d, void* stream) {
-  RMEM_REQUIRE(d && d->L > 0 && d->clips >= 1 && d->x, "rmem_lstt_chain_c: bad geometry");
+  RMEM_REQUIRE(d && d->L > 0 && d->clips >= 1 && (long)d->L * d->clips < (1L << 20) && d->x, "rmem_lstt_chain_c: bad geometry (rows must stay below 2^20)");
   const bool ffn2 = d->h3 != nullptr, next = d->w_qkv != nullptr;
   RMEM_REQUIRE(ffn2 || next, "rmem_lstt_chain_c: nothing to do (neither h3 nor w_qkv)");
   RMEM_REQUIRE(!ffn2 || (d->w2 && d->b2 && d->dec_g && d->dec_b && d->dec_out && d->ld_dec >= 256 && d->ld_dec % 8 == 0),
