@@ -588,6 +588,15 @@ def run_clip(engine: OracleEngine, frames: Sequence[Tensor], first_mask: Tensor,
     return labels, all_logits
 
 
+def tta_merge(logits, flips):
+    """managers/evaluator.py:427-441: each augmentation's logits [1, nc, H, W] are un-flipped (utils/image.py:109-113, dim 3),
+    soft-maxed over the classes, the probabilities averaged over the augmentations and arg-maxed.  Returns (mean probability
+    [1, nc, H, W], label [1, 1, H, W] fp32).  Pinned by tests/golden/tta.npz (the reference's own flip_tensor + mean + argmax)."""
+    ps = [torch.softmax(lg.flip(3) if fl else lg, dim=1) for lg, fl in zip(logits, flips)]
+    prob = torch.mean(torch.cat(ps, 0), dim=0, keepdim=True)
+    return prob, torch.argmax(prob, dim=1, keepdim=True).float()
+
+
 def evaluate_sequence(weights: W, frames, labels: Dict[int, Tensor], out_hw, former=1, latter=7, flip=False):
     """managers/evaluator.py:330-523 for one sequence (gap heuristic, flip / multi-scale TTA with probability averaging over
     one engine per (scale, flip) pair, new-object reference frames, memory update), on OracleInferEngine(s).  frames: one
@@ -608,12 +617,8 @@ def evaluate_sequence(weights: W, frames, labels: Dict[int, Tensor], out_hw, for
         e.add_reference_frame(frame(a, 0), lab.flip(3) if fl else lab, int(labels[0].max()), 0)
     outs, probs = [], []
     for t in range(1, n):
-        ps = []
-        for a, (e, (si, fl)) in enumerate(zip(engines, augs)):
-            lg = e.match_propogate_one_frame(frame(a, t), out_hw)
-            ps.append(torch.softmax(lg.flip(3) if fl else lg, dim=1))
-        prob = torch.mean(torch.cat(ps, 0), dim=0, keepdim=True)
-        label = torch.argmax(prob, dim=1, keepdim=True).float()
+        lgs = [e.match_propogate_one_frame(frame(a, t), out_hw) for a, e in enumerate(engines)]
+        prob, label = tta_merge(lgs, [fl for _, fl in augs])
         if t in labels:
             keep = (labels[t] == 0).float()
             label = label * keep + labels[t] * (1 - keep)

@@ -333,9 +333,37 @@ def gen_iou():
     return out
 
 
+def gen_tta():
+    """Test-time-augmentation merge of the reference (managers/evaluator.py:427-441) on seeded logits: per augmentation
+    `flip_tensor(pred_logit, 3)` where the engine ran on the flipped frame (utils/image.py:109-113, imported from the reference),
+    softmax over the classes, mean over the augmentations, argmax.  Stored: the per-augmentation logits AS THE ENGINES RETURN THEM
+    (flipped ones still flipped), the flip flags, the reference's mean probability and label."""
+    sys.path.insert(0, REF)
+    flip_tensor = importlib.import_module('utils.image').flip_tensor
+    rng = np.random.Generator(np.random.PCG64([88, 0xC0FFEE]))
+    out = {}
+    cases = [([False], 24, 40), ([False, True], 24, 40), ([False, True, False, True], 33, 47), ([True, True, False], 16, 20)]
+    out['n'] = np.array(len(cases))
+    for i, (flips, h, w) in enumerate(cases):
+        lg = torch.from_numpy((rng.standard_normal((len(flips), 11, h, w)) * 2.5).astype(np.float32))
+        all_preds = []
+        for a, fl in enumerate(flips):
+            pred_logit = lg[a:a + 1]
+            if fl:
+                pred_logit = flip_tensor(pred_logit, 3)
+            all_preds.append(torch.softmax(pred_logit, dim=1))
+        pred_prob = torch.mean(torch.cat(all_preds, dim=0), dim=0, keepdim=True)
+        pred_label = torch.argmax(pred_prob, dim=1, keepdim=True).float()
+        out[f'logits{i}'], out[f'flips{i}'] = lg.numpy(), np.array(flips)
+        out[f'prob{i}'], out[f'label{i}'] = pred_prob.numpy(), pred_label.numpy().astype(np.uint8)
+    return out
+
+
 if __name__ == '__main__':
     what = sys.argv[1] if len(sys.argv) > 1 else 'all'
     torch.set_num_threads(8)
+    if what in ('tta', 'all'):
+        np.savez_compressed(os.path.join(HERE, 'tta.npz'), **gen_tta())
     if what in ('iou', 'all'):
         np.savez_compressed(os.path.join(HERE, 'iou.npz'), **gen_iou())
     if what in ('ops', 'all'):
@@ -387,6 +415,14 @@ if __name__ == '__main__':
         # the bank overflows at every append from frame 10 on, 15 evictions of the only evictable entry
         np.savez_compressed(os.path.join(HERE, 'clip_n2_fitted.npz'),
                             **gen_clip('n2', 1, 1, 82, 481, 849, (480, 854), 5, 1, 71, fitted=True))
+    if what in ('long', 'all'):
+        # long clips (eviction traces over >= 120 frames): 160 frames at 161x193, gap 2 -> an append every second
+        # frame; bank N = 8 (1 + 7): 72 evictions, bank N = 2 (1 + 1): 78 -- the EMA scores and the UCB visit counts of the policy
+        # (layers/transformer.py:357-411) run far past the ~20 evictions of the other clips
+        np.savez_compressed(os.path.join(HERE, 'clip_long_n8.npz'),
+                            **gen_clip('long_n8', 1, 7, 160, 161, 193, (160, 192), 2, 3, 91))
+        np.savez_compressed(os.path.join(HERE, 'clip_long_n2_fitted.npz'),
+                            **gen_clip('long_n2', 1, 1, 160, 161, 193, (160, 192), 2, 2, 92, fitted=True))
     if what in ('full', 'all'):
         # cfg-2 geometry: 480x854 video at network size 481x849, bank N = 8, gap 2 so the bank fills
         # by frame 14 and evicts from frame 16

@@ -626,32 +626,22 @@ def test_group_engine_matches_per_clip_engines():
         assert (ge.long_memories_indexes(c), ge.drop_trace[c]) == ref_traces[c]
 
 
-@pytest.mark.parametrize('name', ['clip_full.npz', 'clip_full_fitted.npz'])
-def test_group_engine_bench_path_vs_reference_fixture(name):
-    """The path bench.py times -- GroupEngine + GroupSlot, 4 clips per group, hipGraphs, encoder look-ahead 2 on the side stream,
-    label-only post-processing -- at BENCH GEOMETRY (480x854 -> 481x849, bank N = 8) against the reference's own golden clip
-    (managers/evaluator.py:385-441, 509-523; engines/aot_engine.py:438-465).  All four clips of the group are the fixture's clip;
-    the reference's labels are fed back (GroupSlot.step(feed=...)), so every frame is an independent comparison: per-frame labels,
-    mask IoU, the 1/4-resolution logits resized like the reference does (at the fixture's sample points) and the bank index trace
-    must match the fixture with the per-clip tests' tolerances, for every clip of the group."""
-    if not os.path.exists(os.path.join(GOLDEN, name)):
-        pytest.skip(f'{name} not generated')
+def _group_vs_fixture(name, B, lookahead):
+    """GroupEngine + GroupSlot (hipGraphs, look-ahead encoder on the side stream, label-only post-processing) with B copies of a
+    golden clip, the reference's labels fed back (GroupSlot.step(feed=...)): per clip (labels, 1/4-resolution logits resized like
+    the reference does at the fixture's sample points [n - 1, 11, points], bank index trace per frame) + the fixture."""
     fitted = 'fitted' in name
-    if fitted and not os.path.exists(os.path.join(GOLDEN, 'trained_delta.pt')):
-        pytest.skip('fitted weights missing')
     from rmem_ocu_amd import build_vos_model, get_config
     from rmem_ocu_amd.clip_runner import GroupSlot
     from rmem_ocu_amd.networks.engines.group_engine import GroupEngine
     from rmem_ocu_amd.weights import fitted_state_dict, synth_state_dict
     g, frames, mask, (former, latter, n, h, w, oh, ow, gap, objs) = _load(name)
-    assert (h, w, oh, ow, former + latter) == (481, 849, 480, 854, 8)
     dev = torch.device('cuda', 0)
-    B = 4
     cfg = get_config('pre_vost', 'test', 'r50_aotl')
     cfg.FORMER_MEM_LEN, cfg.LATTER_MEM_LEN = former, latter
     model = build_vos_model(cfg.MODEL_VOS, cfg).cuda(0)
     model.load_state_dict(fitted_state_dict(0) if fitted else synth_state_dict(0))
-    ge = GroupEngine(model, B, 0, gap, lookahead=2)
+    ge = GroupEngine(model, B, 0, gap, lookahead=lookahead)
     assert ge.use_graphs
     gs = GroupSlot(ge, (oh, ow), dev)
     fd = frames.to(dev)
@@ -671,8 +661,25 @@ def test_group_engine_bench_path_vs_reference_fixture(name):
         samples.append(up[:, :, ys, xs].cpu().numpy())
         for c in range(B):
             traces[c].append(list(ge.long_memories_indexes(c)))
-    got = gs.labels[:, 1:n].cpu().numpy()
-    samples = np.stack(samples, 1)                      # [B, n - 1, 11, points]
+    return g, gs.labels[:, 1:n].cpu().numpy(), np.stack(samples, 1), traces, ge
+
+
+@pytest.mark.parametrize('name', ['clip_full.npz', 'clip_full_fitted.npz'])
+def test_group_engine_bench_path_vs_reference_fixture(name):
+    """The path bench.py times -- GroupEngine + GroupSlot, 4 clips per group, hipGraphs, encoder look-ahead 2 on the side stream,
+    label-only post-processing, the LSTT chain kernels -- at BENCH GEOMETRY (480x854 -> 481x849, bank N = 8) against the
+    reference's own golden clip (managers/evaluator.py:385-441, 509-523; engines/aot_engine.py:438-465).  All four clips of the
+    group are the fixture's clip; the reference's labels are fed back, so every frame is an independent comparison: per-frame
+    labels, mask IoU, logits and the bank index trace must match the fixture with the per-clip tests' tolerances, for every clip."""
+    if not os.path.exists(os.path.join(GOLDEN, name)):
+        pytest.skip(f'{name} not generated')
+    fitted = 'fitted' in name
+    if fitted and not os.path.exists(os.path.join(GOLDEN, 'trained_delta.pt')):
+        pytest.skip('fitted weights missing')
+    B = 4
+    g, got, samples, traces, ge = _group_vs_fixture(name, B, 2)
+    assert tuple(g['meta'][3:7]) == (481, 849, 480, 854) and int(g['meta'][0] + g['meta'][1]) == 8
+    assert ge.rt.chain and ge.rt.pair_attn
     ref = g['logit_samples']
     for c in range(B):
         assert (_trace_matrix(traces[c], g['indexes']) == g['indexes']).all(), c
@@ -686,6 +693,29 @@ def test_group_engine_bench_path_vs_reference_fixture(name):
             assert err < 0.065 * ref.std() and agree > 0.97
     # the four clips ran the same inputs through one launch: identical labels
     assert all(np.array_equal(got[0], got[c]) for c in range(1, B))
+
+
+@pytest.mark.parametrize('name', ['clip_long_n8.npz', 'clip_long_n2_fitted.npz'])
+def test_long_clip_eviction_traces(name):
+    """160-frame clips, gap 2: 72 (bank N = 8) / 78 (N = 2) evictions -- the eviction policy's EMA scores and UCB visit counts
+    (layers/transformer.py:357-411) far past the ~20 evictions of the short clips (SURVEY.md §8c asks for >= 120 frames).
+    Teacher-forced against the reference's clip, on the per-clip engine (hipGraphs) AND on a group of three (throughput path):
+    identical bank index trace at every frame, logits within the 16-bit tolerance."""
+    if 'fitted' in name and not os.path.exists(os.path.join(GOLDEN, 'trained_delta.pt')):
+        pytest.skip('fitted weights missing')
+    tol = 0.035 if 'fitted' in name else 0.065
+    g, labels, samples, trace = _run(name, True, use_graphs=True)
+    ref = g['logit_samples']
+    assert (_trace_matrix(trace, g['indexes']) == g['indexes']).all()
+    evictions = sum(1 for a, b in zip(trace, trace[1:]) if len(a) == len(b) and a != b)
+    err = np.abs(samples - ref).max()
+    print(f'{name} per-clip engine: {evictions} evictions, max |dlogit| {err:.4f} at logit std {ref.std():.2f}, label agreement {(labels == g["labels"]).mean():.5f}')
+    assert evictions >= 60 and err < tol * ref.std()
+    g, got, gsamples, traces, ge = _group_vs_fixture(name, 3, 2)
+    for c in range(3):
+        assert (_trace_matrix(traces[c], g['indexes']) == g['indexes']).all(), c
+        assert np.abs(gsamples[c] - ref).max() < tol * ref.std()
+        assert len(ge.drop_trace[c]) == evictions
 
 
 def _per_clip_reference(former, latter, gap, frames, mask, objs, out_hw, new_object=None):

@@ -1155,3 +1155,24 @@ def test_lstt_chain_groupnorm_statistics(dev):
         # (the last block's buffers: a 1e-7 change of a block's statistics flips single e16 roundings, which the next blocks see as
         # input differences -- single-ulp differences on many elements, never more than an ulp or two of the tensor's scale)
         assert torch.isfinite(b).all() and err < 1e-2, (k, err, frac)
+
+
+def test_tta_merge_vs_reference_fixture(dev):
+    """f3: rmem_tta_merge (un-flip, softmax, mean over augmentations, argmax on the device; managers/evaluator.py:427-441) against
+    the reference's own flip_tensor + softmax + mean + argmax on seeded logits (tests/golden/tta.npz: 1, 2, 4 and 3 augmentations,
+    mixed flips)."""
+    import os
+    from conftest import GOLDEN
+    from rmem_ocu_amd.evaluator import tta_merge
+    g = np.load(os.path.join(GOLDEN, 'tta.npz'))
+    for i in range(int(g['n'])):
+        lg = torch.from_numpy(g[f'logits{i}']).to(dev)
+        flips = [bool(f) for f in g[f'flips{i}']]
+        label, label_f, prob = tta_merge([lg[a:a + 1].contiguous() for a in range(len(flips))], flips, want_prob=True)
+        torch.cuda.synchronize()
+        assert np.abs(prob.cpu().numpy() - g[f'prob{i}']).max() < 1e-6
+        ref = g[f'label{i}'][0, 0]
+        p2 = np.sort(g[f'prob{i}'][0], axis=0)
+        tie = (p2[-1] - p2[-2]) < 1e-6
+        assert ((label.cpu().numpy() == ref) | tie).all()
+        assert torch.equal(label.float(), label_f[0, 0])

@@ -94,7 +94,7 @@ def test_encoder_idbank_decoder(golden_ops, synth_weights):
     close(O.assign_identity(oh, None, w).permute(1, 2, 0).reshape(256, 7, 9), golden_ops['id_emb'])
 
 
-def _run_clip(name, max_frames=None):
+def _run_clip(name, max_frames=None, teacher_forced=False):
     g = np.load(os.path.join(GOLDEN, name))
     former, latter, n, h, wd, oh, ow, gap, objs, seed = g['meta'].tolist()
     frames, mask = make_clip(seed, n, h, wd, objs)
@@ -119,6 +119,9 @@ def _run_clip(name, max_frames=None):
     for i in range(1, n if max_frames is None else min(n, max_frames)):
         logit = eng.match_propogate_one_frame(frames[i:i + 1], (oh, ow))
         label = torch.argmax(torch.softmax(logit, 1), 1, keepdim=True).float()
+        own = label
+        if teacher_forced:        # the reference's own mask of this frame goes into the memory: every frame is an independent comparison
+            label = torch.from_numpy(g['labels'][i - 1].astype(np.float32))[None, None]
         if i == inject_at:        # evaluator.py:484-508
             new = torch.zeros(1, 1, oh, ow)
             new[:, :, oh // 2:oh // 2 + oh // 4, ow // 8:ow // 8 + ow // 5] = objs + 1
@@ -127,7 +130,7 @@ def _run_clip(name, max_frames=None):
             eng.add_reference_frame(frames[i:i + 1], torch.nn.functional.interpolate(label, size=eng.input_size_2d, mode='nearest'), i)
         else:
             eng.update_memory(torch.nn.functional.interpolate(label, size=eng.input_size_2d, mode='nearest'))
-        labels.append(label[0, 0].to(torch.uint8).numpy())
+        labels.append((own if teacher_forced else label)[0, 0].to(torch.uint8).numpy())
         trace.append(list(eng.long_memories_indexes))
         samples.append(logit[0][:, ys, xs].numpy())
     return g, np.stack(labels), trace, np.stack(samples)
@@ -215,3 +218,32 @@ def test_n2_bank_clip_matches_reference():
     assert (got == g['indexes'][:k]).all()
     assert np.abs(samples - g['logit_samples'][:k]).max() < 2e-3
     assert (labels == g['labels'][:k]).mean() > 0.9999
+
+
+@pytest.mark.parametrize('name', ['clip_long_n8.npz', 'clip_long_n2_fitted.npz'])
+def test_long_clip_eviction_traces_match_reference(name):
+    """160-frame clips, gap 2 (eviction traces over >= 120 frames): 72 evictions with bank N = 8, 78 with N = 2 --
+    the policy's EMA scores and UCB visit counts (layers/transformer.py:357-411) run far past the ~20 evictions of the short
+    clips; the oracle is fed the reference's masks (a free run over 160 frames amplifies a single near-tied pixel through the mask feedback,
+    which says nothing about either implementation): identical bank index trace at every frame, logits, masks."""
+    g, labels, trace, samples = _run_clip(name, teacher_forced=True)
+    got = -np.ones_like(g['indexes'])
+    for i, t in enumerate(trace):
+        got[i, :len(t)] = t
+    assert (got == g['indexes']).all()
+    evictions = sum(1 for a, b in zip(trace, trace[1:]) if len(a) == len(b) and a != b)
+    assert evictions >= 60, evictions
+    assert np.abs(samples - g['logit_samples']).max() < 2e-3
+    assert (labels == g['labels']).mean() > 0.9999
+
+
+def test_tta_merge_matches_reference():
+    """f3: the test-time-augmentation merge (un-flip, softmax, mean over augmentations, argmax; managers/evaluator.py:427-441)
+    against the reference's own flip_tensor + softmax-mean-argmax on seeded logits (tests/golden/tta.npz)."""
+    g = np.load(os.path.join(GOLDEN, 'tta.npz'))
+    for i in range(int(g['n'])):
+        lg = torch.from_numpy(g[f'logits{i}'])
+        flips = [bool(f) for f in g[f'flips{i}']]
+        prob, label = O.tta_merge([lg[a:a + 1] for a in range(len(flips))], flips)
+        assert np.abs(prob.numpy() - g[f'prob{i}']).max() < 1e-6
+        assert (label.numpy().astype(np.uint8) == g[f'label{i}']).all()
