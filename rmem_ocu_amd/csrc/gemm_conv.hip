@@ -557,10 +557,13 @@ __device__ __forceinline__ void conv_gemm_dma_body(const ConvParams& p, const in
       __builtin_amdgcn_s_barrier();
     } else {
       // tile kt has landed once only the NA + NB DMA pieces per later tile (at most ST - 2 of them) are still outstanding for this wave
+      static_assert((ST - 2) * (NA + NB) <= 63, "vmcnt is a 6-bit counter");
       switch (min(ST - 2, kt1 - 1 - kt)) {
         case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
         case 1: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA + NB) : "memory"); break;
-        default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (NA + NB)) : "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (NA + NB)) : "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ST >= 5 ? 3 * (NA + NB) : 0) : "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ST >= 6 ? 4 * (NA + NB) : 0) : "memory"); break;
       }
       __builtin_amdgcn_s_barrier();                     // everyone's pieces of tile kt landed; everyone finished reading tile kt-1
       const int nxt = stage == 0 ? ST - 1 : stage - 1;  // slot of tile kt+ST-1 == slot of tile kt-1
@@ -725,6 +728,18 @@ void launch(const ConvParams& p, bool is1x1, int splits, hipStream_t s) {
 template <int BM, int BN>
 void launch_big(const ConvParams& p, bool is1x1, int st, hipStream_t s) {
   dim3 grid((p.M + BM - 1) / BM, (p.Cout + BN - 1) / BN, 1);
+  if constexpr (BM == 128 && BN == 128) {
+    if (st == 5) {        // 160 KB of LDS: one workgroup per CU with four k-steps (128 KB) in flight
+      if (is1x1) hipLaunchKernelGGL((k_conv_gemm_dma_big<true, 5, BM, BN, 1>), grid, dim3(256), 0, s, p);
+      else hipLaunchKernelGGL((k_conv_gemm_dma_big<false, 5, BM, BN, 1>), grid, dim3(256), 0, s, p);
+      return;
+    }
+    if (st == 4) {
+      if (is1x1) hipLaunchKernelGGL((k_conv_gemm_dma_big<true, 4, BM, BN, 1>), grid, dim3(256), 0, s, p);
+      else hipLaunchKernelGGL((k_conv_gemm_dma_big<false, 4, BM, BN, 1>), grid, dim3(256), 0, s, p);
+      return;
+    }
+  }
   if (st == 3) {
     if (is1x1) hipLaunchKernelGGL((k_conv_gemm_dma_big<true, 3, BM, BN, 1>), grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL((k_conv_gemm_dma_big<false, 3, BM, BN, 1>), grid, dim3(256), 0, s, p);
@@ -851,7 +866,8 @@ extern "C" int RMEM_API(rmem_conv2d_nhwc)(const rmem_conv_desc* d, const void* x
       // at most ~1 workgroup per CU and a deep k-loop: nothing else hides the DMA latency, so keep two k-steps in flight
       static const int big_deep = getenv("RMEM_GEMM_BIG_DEEP") ? atoi(getenv("RMEM_GEMM_BIG_DEEP")) : 256;
       const long t128 = (long)((p.M + 127) / 128) * ((p.Cout + 127) / 128);
-      launch_big<128, 128>(p, is1x1, (t128 <= big_deep && p.K >= 512) ? 3 : big_st, s);
+      static const int deep_st = getenv("RMEM_GEMM_BIG_DEEP_ST") ? atoi(getenv("RMEM_GEMM_BIG_DEEP_ST")) : 3;
+      launch_big<128, 128>(p, is1x1, (t128 <= big_deep && p.K >= 512) ? deep_st : big_st, s);
       return rmem_check_launch("rmem_conv2d_nhwc");
     }
     static const int big64 = getenv("RMEM_GEMM_BIG64") ? atoi(getenv("RMEM_GEMM_BIG64")) : 0;
