@@ -10,24 +10,28 @@ Launched by torch.distributed.run (WORLD_SIZE set) it is one rank.
 
 Workload (config.workload = "davis17_480p_r50_N8"): a job of 64 synthetic 480x854 clips per GPU, 80 frames each, at network
 size 481x849 (HW = 1674 tokens), ResNet-50 + 3-layer LSTT + FPN, memory bank N = 8 (1 + 7), per-clip
-gap = max(round(80/30), 5) = 5, 3 objects, bf16 operands / fp32 accumulation.
-A *step* is one propagated frame of one clip: match-propagate + argmax + memory update -- the reference's own FPS unit
-(managers/evaluator.py:399-404, 525-535).  Clips are independent; the job's clip list is handed to the ranks by
-rmem_ocu_amd.clip_runner.ClipFeeder -- a job-wide ticket queue on the process group's TCPStore (the reference's shared
-sequence queue, managers/evaluator.py:276-295) or, with --feeder static, a longest-first split -- and every rank keeps 24
-clips in flight as 6 groups of 4 clips that advance in lockstep on one GroupEngine each (one launch per layer for the 4
-clips; --clips-per-group 1 selects the per-clip engines of the drop-in API), every group on its own HIP stream with its own
-hipGraphs.  Ranks never exchange data on the hot path (weak scaling: per-GPU work is fixed); the only collectives are the
-barriers around the timed region and one final gather of (frames, seconds, checksum) to rank 0.  The timed region is a
-window of K steps per rank out of that job (the list is cyclic, a window never runs dry).  Reference frames that fall
-inside the timed region are executed but not counted as steps.  Inside a clip the ResNet-50 encoder runs 2 frames ahead of
-the LSTT (frames do not depend on each other before the memory read): one launch per encoder layer covers 2 frames x 4
-clips, every frame is still encoded exactly once (config.encoder_lookahead).  A group step propagates 4 frames, so the timed
-region executes ceil(K / 4) * 4 frames while `value` = K / elapsed (never over-reports;
-config.frames_executed_in_timed_region).  Because of the look-ahead a SHORT window can contain more or less encoder work than the
-frames it counts (the encoder of a counted frame may have run just before the window, that of a frame after it inside):
-config.frames_encoded_in_timed_region says how many frames the encoder processed inside the window (rank 0) -- with the default
-configuration it is >= the counted steps (24 for --steps 20), over a long window the two converge.  Inputs are resident in HBM when the timed region starts.
+gap = max(round(80/30), 5) = 5, 3 objects, bf16 operands / fp32 accumulation.  Other workloads (--workload): the DeAOT model, the
+cfg-3 protocol (720p, a new object arriving at frame 15), cfg 4 (1080p, 600-frame clips, restricted vs unbounded bank), cfg 5.
+
+The unit of work is one propagated frame of one clip: match-propagate + argmax + memory update -- the reference's own FPS unit
+(managers/evaluator.py:399-404, 525-535) -- and `value` is always frames / second.  A *step* (--steps K, --warmup W) is one pass
+of the engine over its batch: ONE FRAME OF EVERY CLIP IN FLIGHT on the GPU (24 clips = 6 groups of 4: config.frames_per_step
+= 24), so --steps 20 times 480 frames.  (--step-unit frame restores the rounds 1-2 reading, one frame of one clip per step:
+--steps 20 was then five group steps started from an idle GPU, i.e. a fill / drain transient 12-15 % below the rate the same
+build sustains, swinging +-5 % with what the window happened to contain; DESIGN.md section 6 quotes both.)
+Clips are independent; the job's clip list is handed to the ranks by rmem_ocu_amd.clip_runner.ClipFeeder -- a job-wide ticket
+queue on the job's TCPStore (the reference's shared sequence queue, managers/evaluator.py:276-295) or, with --feeder static, a
+longest-first split -- and every rank keeps 24 clips in flight as 6 groups of 4 clips that advance in lockstep on one
+GroupEngine each (one launch per layer for the 4 clips; --clips-per-group 1 selects the per-clip engines of the drop-in API),
+every group on its own HIP stream with its own hipGraphs.  Ranks never exchange data on the hot path (weak scaling: per-GPU
+work is fixed); the only collectives are the barriers around the timed region and one final gather of (frames, seconds,
+checksum) to rank 0.  The timed region is a window of K steps per rank out of that job (the list is cyclic, a window never
+runs dry); --drain instead runs the whole job once from a non-cyclic list (value = all ranks' frames / the slowest rank's
+seconds: tail and imbalance included).  Reference frames that fall inside the timed region are executed but not counted.
+Inside a clip the ResNet-50 encoder runs 2 frames ahead of the LSTT on a side stream (frames do not depend on each other before
+the memory read): one launch per encoder layer covers 2 frames x 4 clips, every frame is still encoded exactly once
+(config.encoder_lookahead; config.frames_encoded_in_timed_region >= config.frames_counted_in_timed_region: no encoder work is
+pre-computed outside the window).  Inputs are resident in HBM when the timed region starts.
 
 The single JSON line also carries
   roofline     -- the dominant kernel (the long-term memory read, rmem_mem_read_attn_clips): AFTER the timed region (so
@@ -149,8 +153,12 @@ def self_launch(n: int) -> int:
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=790)
-    ap.add_argument('--warmup', type=int, default=79)
+    ap.add_argument('--steps', type=int, default=40, help='timed steps; a step = ONE FRAME OF EVERY CLIP IN FLIGHT on this GPU (see --step-unit)')
+    ap.add_argument('--warmup', type=int, default=4)
+    ap.add_argument('--step-unit', default='batch', choices=['batch', 'frame'],
+                    help="what one step propagates: 'batch' (default) = one frame of each of the --clips-in-flight clips, the batch this "
+                         "engine advances together (24 frames); 'frame' = one frame of one clip (rounds 1-2: --steps 20 is then 5 group steps "
+                         'from an idle GPU, a fill / drain transient rather than a rate)')
     ap.add_argument('--clips-in-flight', type=int, default=int(os.environ.get('RMEM_CLIPS_IN_FLIGHT', 24)))
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--workload', default='davis17_480p_r50_N8', choices=sorted(WORKLOADS))
@@ -300,6 +308,8 @@ def main():
         for s in slots:
             if not s.done:
                 s.step()
+    # frames one step propagates: one frame of every clip in flight (the batch the engine advances together), or one frame
+    F = C * max(G, 1) if args.step_unit == 'batch' else 1
     if args.drain:
         # the whole job once, from empty slots: a fresh NON-cyclic list (its own ticket counter), every slot takes units until
         # the list is empty and then idles; the priming pass above was the warm-up
@@ -311,7 +321,8 @@ def main():
         t0 = time.perf_counter()
         pump(slots, start, DRAIN, G)
         # propagated frames this rank ran (frame 0 of a clip is its reference frame): from the units it actually took
-        args.steps = sum(len(feeder.units[u]) * (lengths[feeder.units[u][0]] - 1) for u in feeder.history)
+        frames_timed = sum(len(feeder.units[u]) * (lengths[feeder.units[u][0]] - 1) for u in feeder.history)
+        args.steps = max(1, frames_timed // F)
         host_enqueue = time.perf_counter() - t0
         torch.cuda.synchronize()
         if dist is not None:
@@ -331,7 +342,7 @@ def main():
             """n propagated frames in total (a group step propagates G frames); a finished slot takes the job's next unit."""
             pump(slots, start, n, G)
 
-        run_steps(args.warmup)
+        run_steps(args.warmup * F)
         torch.cuda.synchronize()
 
         if dist is not None:
@@ -339,7 +350,8 @@ def main():
         torch.cuda.synchronize()
         enc0 = sum(s.frames_encoded for s in slots)
         t0 = time.perf_counter()
-        run_steps(args.steps)
+        frames_timed = args.steps * F
+        run_steps(frames_timed)
         host_enqueue = time.perf_counter() - t0
         torch.cuda.synchronize()
         if dist is not None:
@@ -350,7 +362,7 @@ def main():
     checksum = float(sum(int(s.labels.sum().item()) for s in slots))
     from rmem_ocu_amd.clip_runner import gather_stats
     gdev = dev if (dist is None or dist.get_backend() == 'nccl') else torch.device('cpu')
-    agg = gather_stats(float(args.steps), elapsed, checksum, dist, rank, world, gdev)   # the one data exchange: 24 bytes per rank
+    agg = gather_stats(float(frames_timed), elapsed, checksum, dist, rank, world, gdev)   # the one data exchange: 24 bytes per rank
 
     # ---- roofline leg, after (and outside) the timed region: isolated launches of the dominant kernel under HIP events ----
     L = _lib.lib()
@@ -397,23 +409,24 @@ def main():
                     'avg_launch_us': round(1e3 * ms.value / nl.value, 2), 't_mix': {str(T): nl.value}}
 
     if rank == 0:
-        total_steps, elapsed, _ = agg
+        total_frames, elapsed, _ = agg
         traffic, traffic_src = pmc_traffic(G) if args.workload.startswith('davis17_480p_r50_N8') else (None, None)
         L16 = (net_hw[0] // 16 if wl['net'] else (net_hw[0] - 1) // 16 + 1) * (net_hw[1] // 16 if wl['net'] else (net_hw[1] - 1) // 16 + 1)
         out = {
             'metric': 'frames/sec (whole node) 480p VOS, N=8 memory bank' if args.workload == 'davis17_480p_r50_N8'
-            else f'frames/sec (whole node) {args.workload}', 'value': round(total_steps / elapsed, 2), 'unit': 'frames/s',
+            else f'frames/sec (whole node) {args.workload}', 'value': round(total_frames / elapsed, 2), 'unit': 'frames/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * elapsed / max(args.steps, 1), 4),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': cfg.MODEL_DTYPE, 'data': 'synthetic',
             'config': {'workload': args.workload, 'clip_frames': list(wl['lengths']) if len(wl['lengths']) > 1 else wl['lengths'][0],
                        'job_clips': len(lengths), 'clip_feeder': feeder.mode, 'video_hw': list(VIDEO_HW), 'network_hw': list(net_hw),
                        'tokens': L16, 'objects': NUM_OBJS,
                        'memory_bank': f"{wl['former']}+{wl['latter']}", 'gap': [max(int(round(n / 30)), 5) for n in wl['lengths']][0],
-                       'clips_in_flight_per_gpu': C * G, 'clips_per_group': G, 'frames_executed_in_timed_region': -(-args.steps // G) * G,
+                       'clips_in_flight_per_gpu': C * G, 'clips_per_group': G, 'step_unit': args.step_unit, 'frames_per_step': F,
+                       'frames_counted_in_timed_region': frames_timed, 'frames_executed_in_timed_region': -(-frames_timed // G) * G,
                        'frames_encoded_in_timed_region': enc_in_window,
                        'parallelism': f'clip-parallel x{world}', 'weights': 'synthetic (no checkpoint offline)',
                        'hipgraphs': not args.no_graphs, 'frames_from': 'pinned host uint8 (PCIe-inclusive)' if args.host_frames else 'HBM',
-                       'encoder_lookahead': lookahead, 'host_enqueue_ms_per_step': round(1e3 * host_enqueue / max(args.steps, 1), 4),
+                       'encoder_lookahead': lookahead, 'host_enqueue_ms_per_frame': round(1e3 * host_enqueue / max(frames_timed, 1), 4),
                        'timed_region': 'whole job, drained (non-cyclic list)' if args.drain else 'window of --steps frames of a cyclic job',
                        **({'new_object_at_frame': inject_at} if inject_at is not None else {})},
             'roofline': {'bound': 'mfma', 'kernel': 'k_gp_pv<1, true>' if deaot else 'k_attn_partial<true, true>',

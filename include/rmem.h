@@ -170,14 +170,16 @@ int rmem_layernorm256_pair(const void* a0, const void* b0, void* y0, const void*
  * (rows are [clip][token], everything contiguous unless a leading dimension is given), a workgroup owning 32 consecutive
  * tokens of one clip with the rows resident in LDS; results are bit-identical to the same sequence of rmem_conv2d_nhwc /
  * rmem_layernorm256 / rmem_layernorm256_pair launches (same accumulation order, same points of rounding).
- * Weights are 16-bit [N][K] matrices (nn.Linear layout) re-packed once in FRAGMENT ORDER: [N / 256][4][K / 32][4][64][8] =
- * [column block][wave][k chunk][column tile j][lane][8 consecutive k], element (n, k) with n = 256 nb + 64 wave + 16 j + (lane & 15),
- * k = 32 kc + 8 (lane >> 4) + e (rmem_ocu_amd/pack.py::pack_frag), so that a wave reads one MFMA B fragment as 1 KiB of
- * contiguous memory.  Biases and LayerNorm parameters are fp32; every pointer must be 16-byte aligned.
+ * Weights are 16-bit [N][K] matrices (nn.Linear layout) re-packed once in FRAGMENT ORDER for NW = rmem_lstt_chain_waves()
+ * waves per workgroup: [N / 256][NW][K / 32][16 / NW][64][8] = [column block][wave][k chunk][column tile j][lane][8 consecutive k],
+ * element (n, k) with n = 256 nb + (256 / NW) wave + 16 j + (lane & 15), k = 32 kc + 8 (lane >> 4) + e
+ * (rmem_ocu_amd/pack.py::pack_frag), so that a wave reads one MFMA B fragment as 1 KiB of contiguous memory.  Biases and
+ * LayerNorm parameters are fp32; every pointer must be 16-byte aligned.
  *
  * chain A, after the self attention (transformer.py:571-576, 659-660):
  *   x += att . w_proj^T + b_proj;  curr_v = LN2(x);  curr_q = curr_v . w_q^T + b_q;
  *   k4 = LN4(short_k + curr_q);  v4 = LN4(short_v + curr_v) */
+int rmem_lstt_chain_waves(void);      /* waves per workgroup the chain kernels were built for (4 or 8): the weight packing depends on it */
 typedef struct rmem_chain_a_desc {
   int L, clips; float eps; int reserved;
   const void* att; float* x;

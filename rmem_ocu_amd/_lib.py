@@ -64,6 +64,7 @@ SIGNATURES = {
     'rmem_add16': (_i, [_vp, _vp, _vp, _ll, _vp]),
     'rmem_add16_grouped': (_i, [_i, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), _ll, _vp]),
     'rmem_layernorm256_pair': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i, _vp]),
+    'rmem_lstt_chain_waves': (_i, []),
     'rmem_lstt_chain_a': (_i, [C.POINTER(ChainA), _vp]),
     'rmem_lstt_chain_b': (_i, [C.POINTER(ChainB), _vp]),
     'rmem_lstt_chain_c': (_i, [C.POINTER(ChainC), _vp]),

@@ -53,7 +53,24 @@ struct ConvParams {
   int H2, W2, Cin2, stride2;
   long x2_elems;
   int fast_ok;           // 1: Cin % 64 == 0, <= 32 taps, x and w below 2 GB: scalar k-walk + hardware zero fill; 2: row-run form
+  int xcd_ny;            // > 0: 1-D grid in XCD-aware order, xcd_ny = column tiles per row tile (see tile_of_block)
 };
+
+// Which output tile a workgroup owns.  Plain 2-D grid (xcd_ny == 0): (blockIdx.x, blockIdx.y) -- all row tiles of column tile 0 are
+// dispatched before any of column tile 1, so by the time a row tile's A operand is wanted again it has left every L2 and is
+// fetched from the Infinity Cache / HBM once per COLUMN tile.  XCD-aware 1-D grid (xcd_ny = Ny > 0): hardware deals consecutive
+// block ids round-robin over the 8 XCDs (a private 4 MiB L2 each), so ids that are congruent mod 8 walk the (row tile, column
+// tile) pairs with the column tile fastest: the Ny workgroups that read the same A rows run back to back on ONE XCD and all
+// but the first find them in its L2.  Row tile = (j / Ny) * 8 + xcd for the j-th block of an XCD; the grid is rounded up to a
+// whole number of row tiles per XCD, the surplus workgroups exit at once.  Placement is a speed matter only.
+__device__ __forceinline__ bool tile_of_block(const ConvParams& p, int BM, int& bx, int& by) {
+  if (p.xcd_ny <= 0) { bx = blockIdx.x; by = blockIdx.y; return true; }
+  const int b = blockIdx.x, xcd = b & 7, j = b >> 3;
+  const int xl = j / p.xcd_ny;
+  bx = xl * 8 + xcd;
+  by = j - xl * p.xcd_ny;
+  return bx * BM < p.M;
+}
 
 // LDS tile rows are 128 B (BK = 64 e16 = 8 chunks of 16 B).  Physical chunk = chunk ^ ((row >> 1) & 7): the 16 lanes of
 // every ds_read_b128 lane group (rows r..r+3, r+12..r+15 at chunk c and rows r+4..r+11 at chunk c+1) then land on 16
@@ -366,7 +383,9 @@ __device__ __forceinline__ void conv_gemm_dma_body(const ConvParams& p, const in
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: LDS-DMA destinations stay in SGPRs
   const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  int tbx, tby;
+  if (!tile_of_block(p, BM, tbx, tby)) return;          // (workgroup-uniform: surplus block of the XCD-aware grid)
+  const int m0 = tbx * BM, n0 = tby * BN;
   const int rr_len = p.KW * p.Cin;                        // ROWRUN: elements per filter row, k-steps per filter row
   const int rr_spr = (rr_len + BK - 1) / BK;
   const int nk_total = ROWRUN ? p.KH * rr_spr : (p.K + BK - 1) / BK;
@@ -683,6 +702,13 @@ void launch(const ConvParams& p, bool is1x1, int splits, hipStream_t s) {
       const long total = (long)p.M * (p.Cout / 8);
       hipLaunchKernelGGL(k_splitk_epilogue, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p, splits);
     } else {
+      ConvParams q = p;
+      static const bool xcd_on = !(getenv("RMEM_GEMM_XCD") && atoi(getenv("RMEM_GEMM_XCD")) == 0);   // kernel experiments only
+      if (xcd_on && grid.y > 1 && grid.x >= 16) {        // XCD-aware order: the column tiles of a row tile share one L2
+        q.xcd_ny = (int)grid.y;
+        grid = dim3(8 * ((grid.x + 7) / 8) * grid.y, 1, 1);
+      }
+      const ConvParams& p = q;
       // ring depth: measured with 4 clips per launch, 1 / 2 / 3 / 4 stages give 2146 / 2044 / 1978 / 1735 frames/s -- a
       // 16 KB single buffer lets 8 workgroups share a CU, and their DMA in flight beats any prefetch depth inside one
       static const int st = getenv("RMEM_GEMM_ST") ? atoi(getenv("RMEM_GEMM_ST")) : 1;     // kernel experiments only
@@ -696,7 +722,7 @@ void launch(const ConvParams& p, bool is1x1, int splits, hipStream_t s) {
         // few-workgroup problems (token GEMMs of the LSTT, id bank): too few resident workgroups to hide the DMA latency behind
         // each other, so a 3-deep ring keeps two k-steps in flight inside the workgroup
         static const int deep_wgs = getenv("RMEM_GEMM_DEEP_WGS") ? atoi(getenv("RMEM_GEMM_DEEP_WGS")) : 1024;
-        const bool deep = (long)grid.x * grid.y <= deep_wgs && p.steps_per_split >= 3;
+        const bool deep = (long)((p.M + 63) / 64) * ((p.Cout + 63) / 64) <= deep_wgs && p.steps_per_split >= 3;
         if (p.fast_ok == 2) {
           if (deep) hipLaunchKernelGGL((k_conv_gemm_dma<false, false, 3, 2>), grid, dim3(256), 0, s, p);
           else hipLaunchKernelGGL((k_conv_gemm_dma<false, false, 1, 2>), grid, dim3(256), 0, s, p);
@@ -726,8 +752,14 @@ void launch(const ConvParams& p, bool is1x1, int splits, hipStream_t s) {
 }
 
 template <int BM, int BN>
-void launch_big(const ConvParams& p, bool is1x1, int st, hipStream_t s) {
-  dim3 grid((p.M + BM - 1) / BM, (p.Cout + BN - 1) / BN, 1);
+void launch_big(const ConvParams& pin, bool is1x1, int st, hipStream_t s) {
+  dim3 grid((pin.M + BM - 1) / BM, (pin.Cout + BN - 1) / BN, 1);
+  ConvParams p = pin;
+  static const bool xcd_on = !(getenv("RMEM_GEMM_XCD") && atoi(getenv("RMEM_GEMM_XCD")) == 0);   // kernel experiments only
+  if (xcd_on && grid.y > 1 && grid.x >= 16) {
+    p.xcd_ny = (int)grid.y;
+    grid = dim3(8 * ((grid.x + 7) / 8) * grid.y, 1, 1);
+  }
   if constexpr (BM == 128 && BN == 128) {
     if (st == 5) {        // 160 KB of LDS: one workgroup per CU with four k-steps (128 KB) in flight
       if (is1x1) hipLaunchKernelGGL((k_conv_gemm_dma_big<true, 5, BM, BN, 1>), grid, dim3(256), 0, s, p);
@@ -798,6 +830,7 @@ static int conv_setup(const rmem_conv_desc* d, const void* x, const void* w, con
   RMEM_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)w % 16) == 0, "rmem_conv2d_nhwc: x/w must be 16-byte aligned");
   p.x = (const e16*)x; p.w = (const e16*)w; p.bias = bias; p.res = residual; p.y = y; p.y2 = (e16*)y2;
   p.slabs = nullptr;
+  p.xcd_ny = 0;
   p.x2 = nullptr; p.H2 = p.W2 = p.Cin2 = p.stride2 = 0; p.x2_elems = 0;
   p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Ho = Ho; p.Wo = Wo; p.Cout = d->Cout;
   p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad;
@@ -901,11 +934,14 @@ extern "C" int RMEM_API(rmem_conv1x1_dual_nhwc)(const rmem_conv_desc* d, const v
   RMEM_REQUIRE(p.x_elems * 2 < lim && p.x2_elems * 2 < lim && (long)p.Cout * p.K * 2 < lim, "rmem_conv1x1_dual_nhwc: operands must stay below 2 GB");
   hipStream_t s = (hipStream_t)stream;
   static const int big_thr = getenv("RMEM_GEMM_BIG") ? atoi(getenv("RMEM_GEMM_BIG")) : 128;
+  static const bool xcd_on = !(getenv("RMEM_GEMM_XCD") && atoi(getenv("RMEM_GEMM_XCD")) == 0);   // kernel experiments only
   if (big_thr > 0 && p.Cout >= 128 && p.K >= 256 && (long)((p.M + 127) / 128) * ((p.Cout + 127) / 128) >= big_thr) {
     dim3 grid((p.M + 127) / 128, (p.Cout + 127) / 128, 1);
+    if (xcd_on && grid.y > 1 && grid.x >= 16) { p.xcd_ny = (int)grid.y; grid = dim3(8 * ((grid.x + 7) / 8) * grid.y, 1, 1); }
     hipLaunchKernelGGL((k_conv_gemm_dma_big<true, 1, 128, 128, 3>), grid, dim3(256), 0, s, p);
   } else {
     dim3 grid((p.M + 63) / 64, (p.Cout + 63) / 64, 1);
+    if (xcd_on && grid.y > 1 && grid.x >= 16) { p.xcd_ny = (int)grid.y; grid = dim3(8 * ((grid.x + 7) / 8) * grid.y, 1, 1); }
     hipLaunchKernelGGL((k_conv_gemm_dma<true, false, 1, 3>), grid, dim3(256), 0, s, p);
   }
   return rmem_check_launch("rmem_conv1x1_dual_nhwc");

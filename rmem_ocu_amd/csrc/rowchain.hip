@@ -23,7 +23,7 @@
 // GEMM form.  M = 32 rows per workgroup is far too few to amortise a weight tile through LDS per workgroup; instead the A
 // operand (the 32 rows, <= 1024 deep) lives in LDS for the whole chain and the WEIGHTS stream straight from L2 into registers,
 // each wave taking its own 64 output columns: they are packed once at model load in fragment order (pack.py::pack_frag:
-// [N / 256][wave][K / 32][4 column tiles][64 lanes][8]), so a wave-instruction reads 1 KiB of contiguous memory that is exactly
+// [N / 256][wave][K / 32][column tiles][64 lanes][8]), so a wave-instruction reads 1 KiB of contiguous memory that is exactly
 // one B fragment, no LDS, no barrier, no address arithmetic; a ring of 4 k-chunks (16 KiB per workgroup) stays in flight.
 // All workgroups read the same weights (128 KiB - 512 KiB per matrix): they are L2 hits after the first workgroup of an XCD.
 #include "common.h"
@@ -31,10 +31,18 @@
 
 namespace {
 
+#ifndef RMEM_CHAIN_WAVES
+#define RMEM_CHAIN_WAVES 8
+#endif
+constexpr int NW = RMEM_CHAIN_WAVES;   // waves per workgroup (4 or 8): each takes 256 / NW of the 256 output columns of a block
+constexpr int NT = 64 * NW;       // threads
+constexpr int JT = 16 / NW;       // 16-column MFMA tiles per wave and column block (4 or 2)
+constexpr int WC = 256 / NW;      // columns per wave and column block
+constexpr int RW = 32 / NW;       // rows per wave in the row phases (8 or 4)
 constexpr int BM = 32;            // rows per workgroup
 constexpr int XS = 260;           // fp32 staging row stride (floats): 4 rows apart = 16 banks apart, conflict-free ds_write_b32
 constexpr int PANEL = BM * 64;    // elements of one [32 rows][64 k] A panel (128-byte rows, XOR-swizzled 16-byte chunks)
-constexpr int PF = 4;             // k-chunks (of 32) of B fragments in flight per wave
+constexpr int PF = 16 / JT;       // k-chunks (of 32) of B fragments in flight per wave (64 registers; PF <= 8 = the k-chunks of the shortest K)
 constexpr int OOB = (int)0x80000000;   // byte offset beyond every buffer: the hardware range check drops the store
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 1) & 7)) << 3); }
@@ -65,14 +73,18 @@ __device__ inline void st16(rsrc_t, int, f32x4) {}
 // [nrows <= 32][64 * NP] e16 rows of stride ld at src -> A panels p0 .. p0 + NP - 1
 template <int NP>
 __device__ __forceinline__ void stage_tile(e16* A16, int p0, const e16* src, long ld, int nrows) {
-  const int row = threadIdx.x >> 3, ch = threadIdx.x & 7;
+  // 256 threads cover one [32][64] panel (row = t >> 3, 16-byte chunk = t & 7); with 512 threads the two halves take alternate panels
+  constexpr int PT = NT / 256;                      // panels per pass
+  static_assert(NP % PT == 0, "panels must divide among the thread halves");
+  const int t = threadIdx.x & 255, half = threadIdx.x >> 8;
+  const int row = t >> 3, ch = t & 7;
   // rows beyond the block's last one re-read that last row (their results are never stored): an unconditional load
   const e16* sr = src + min(row, nrows - 1) * ld + ch * 8;
-  e16x8 v[NP];
+  e16x8 v[NP / PT];
 #pragma unroll
-  for (int p = 0; p < NP; ++p) v[p] = *reinterpret_cast<const e16x8*>(sr + p * 64);
+  for (int p = 0; p < NP / PT; ++p) v[p] = *reinterpret_cast<const e16x8*>(sr + (p * PT + half) * 64);
 #pragma unroll
-  for (int p = 0; p < NP; ++p) *reinterpret_cast<e16x8*>(&A16[(p0 + p) * PANEL + swz(row, ch)]) = v[p];
+  for (int p = 0; p < NP / PT; ++p) *reinterpret_cast<e16x8*>(&A16[(p0 + p * PT + half) * PANEL + swz(row, ch)]) = v[p];
 }
 
 // 4 consecutive channels c0 .. c0 + 3 of row `row` as e16 into the A panels p0 .. (the LayerNorm output that feeds the next GEMM)
@@ -80,10 +92,10 @@ __device__ __forceinline__ void put_a(e16* A16, int p0, int row, int lane, e16x4
   *reinterpret_cast<e16x4*>(&A16[(p0 + (lane >> 4)) * PANEL + swz(row, (lane & 15) >> 1) + (lane & 1) * 4]) = v;
 }
 
-struct BRing { e16x8 b[PF][4]; };
+struct BRing { e16x8 b[PF][JT]; };
 
-// this wave's weight stream of column block nb: [K / 32][4][64 lanes][8]
-__device__ __forceinline__ const e16* wstream(const e16* w, int nb, int wave, int KC) { return w + (long)(nb * 4 + wave) * KC * 2048; }
+// this wave's weight stream of column block nb: [K / 32][JT][64 lanes][8]
+__device__ __forceinline__ const e16* wstream(const e16* w, int nb, int wave, int KC) { return w + (long)(nb * NW + wave) * KC * (JT * 512); }
 
 // (sched_barrier: the machine scheduler otherwise SINKS these loads down to their first use to save registers, which turns the
 // ring into load -> wait -> MFMA, one L2 round trip per k-chunk)
@@ -91,14 +103,14 @@ __device__ __forceinline__ void b_preload(BRing& r, const e16* wp, int lane) {
 #pragma unroll
   for (int u = 0; u < PF; ++u)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) r.b[u][j] = *reinterpret_cast<const e16x8*>(wp + ((u * 4 + j) * 64 + lane) * 8);
+    for (int j = 0; j < JT; ++j) r.b[u][j] = *reinterpret_cast<const e16x8*>(wp + ((u * JT + j) * 64 + lane) * 8);
   __builtin_amdgcn_sched_barrier(0);
 }
 
 // acc[2][4] (32 rows x this wave's 64 columns) += A[32][64 * NP] (panels p0 ..) . W^T, k ascending in chunks of 32: the
 // accumulation order of the 64x64-tile GEMM kernel (two MFMAs per 64-deep k-step).  The ring holds chunks 0 .. PF - 1 on entry.
 template <int NP>
-__device__ __forceinline__ void gemm32(const e16* A16, int p0, const e16* wp, BRing& r, f32x4 (&acc)[2][4], int lane) {
+__device__ __forceinline__ void gemm32(const e16* A16, int p0, const e16* wp, BRing& r, f32x4 (&acc)[2][JT], int lane) {
   constexpr int KC = NP * 2;
   const int fr = lane & 15, fc = lane >> 4;
 #pragma unroll
@@ -107,34 +119,34 @@ __device__ __forceinline__ void gemm32(const e16* A16, int p0, const e16* wp, BR
     const e16x8 a0 = *reinterpret_cast<const e16x8*>(&Ap[swz(fr, 4 * (kc & 1) + fc)]);
     const e16x8 a1 = *reinterpret_cast<const e16x8*>(&Ap[swz(16 + fr, 4 * (kc & 1) + fc)]);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < JT; ++j) {
       acc[0][j] = RMEM_MFMA_16x16x32(a0, r.b[kc % PF][j], acc[0][j], 0, 0, 0);
       acc[1][j] = RMEM_MFMA_16x16x32(a1, r.b[kc % PF][j], acc[1][j], 0, 0, 0);
     }
     if (kc + PF < KC) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) r.b[kc % PF][j] = *reinterpret_cast<const e16x8*>(wp + (((kc + PF) * 4 + j) * 64 + lane) * 8);
+      for (int j = 0; j < JT; ++j) r.b[kc % PF][j] = *reinterpret_cast<const e16x8*>(wp + (((kc + PF) * JT + j) * 64 + lane) * 8);
       __builtin_amdgcn_sched_barrier(0);
     }
   }
 }
 
-__device__ __forceinline__ void zero_acc(f32x4 (&acc)[2][4]) {
+__device__ __forceinline__ void zero_acc(f32x4 (&acc)[2][JT]) {
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < JT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 }
 
 // raw accumulators -> fp32 staging tile [32][XS] (C/D map of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg)
-__device__ __forceinline__ void dump_acc(float* X, const f32x4 (&acc)[2][4], int wave, int lane) {
+__device__ __forceinline__ void dump_acc(float* X, const f32x4 (&acc)[2][JT], int wave, int lane) {
   const int fr = lane & 15, fc = lane >> 4;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < JT; ++j)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) X[(i * 16 + fc * 4 + q) * XS + wave * 64 + j * 16 + fr] = acc[i][j][q];
+      for (int q = 0; q < 4; ++q) X[(i * 16 + fc * 4 + q) * XS + wave * WC + j * 16 + fr] = acc[i][j][q];
 }
 
 struct Blk { int nrows; long g0; };      // rows this workgroup owns: g0 .. g0 + nrows - 1 of the [clips * L] row space
@@ -146,18 +158,18 @@ __device__ __forceinline__ Blk my_rows(int L) {
   return b;
 }
 
-// Row phases.  A wave owns rows wave * 8 .. wave * 8 + 7 of the block, a lane 4 consecutive channels of each.  Everything a phase
+// Row phases.  A wave owns RW = 32 / NW consecutive rows of the block (wave * RW ..), a lane 4 consecutive channels of each.  Everything a phase
 // reads from global memory is loaded into registers at the START of the kernel (x rows, short-term memory rows, biases, norm
 // parameters) or before the GEMM whose epilogue needs it: a load issued inside the phase costs one full memory latency PER ROW
 // (the phase is a dependent chain of cross-lane reductions; the first version of this file spent 12 us per phase that way).
 template <typename T>
-struct Rows8 { T r[8]; };
+struct Rows8 { T r[RW]; };      // this wave's rows
 
 __device__ __forceinline__ Rows8<f32x4> load_rows_f32(const float* base, int ld, const Blk& blk, int wave, int c0) {
   Rows8<f32x4> o;
 #pragma unroll
-  for (int rr = 0; rr < 8; ++rr) {
-    const int row = min(wave * 8 + rr, blk.nrows - 1);      // (rows beyond the block: the last row again, unconditionally; never stored)
+  for (int rr = 0; rr < RW; ++rr) {
+    const int row = min(wave * RW + rr, blk.nrows - 1);      // (rows beyond the block: the last row again, unconditionally; never stored)
     o.r[rr] = ld4(base + (blk.g0 + row) * ld + c0);
   }
   return o;
@@ -165,20 +177,20 @@ __device__ __forceinline__ Rows8<f32x4> load_rows_f32(const float* base, int ld,
 __device__ __forceinline__ Rows8<e16x4> load_rows_e16(const e16* base, int ld, const Blk& blk, int wave, int c0) {
   Rows8<e16x4> o;
 #pragma unroll
-  for (int rr = 0; rr < 8; ++rr) {
-    const int row = min(wave * 8 + rr, blk.nrows - 1);
+  for (int rr = 0; rr < RW; ++rr) {
+    const int row = min(wave * RW + rr, blk.nrows - 1);
     o.r[rr] = *reinterpret_cast<const e16x4*>(base + (blk.g0 + row) * ld + c0);
   }
   return o;
 }
 // byte offset of (row rr of this wave, channel c0) in a [rows][ld] array of `esz`-byte elements, or OOB beyond the block
 __device__ __forceinline__ int row_off(const Blk& blk, int wave, int rr, int ld, int c0, int esz) {
-  const int row = wave * 8 + rr;
+  const int row = wave * RW + rr;
   return row < blk.nrows ? (int)(((blk.g0 + row) * ld + c0) * esz) : OOB;
 }
 
 // ------------------------------------------------------------------------------------------------------------ chain A
-__global__ __launch_bounds__(256) void k_chain_a(rmem_chain_a_desc d) {
+__global__ __launch_bounds__(NT) void k_chain_a(rmem_chain_a_desc d) {
   __shared__ __attribute__((aligned(16))) char smem[4 * PANEL * 2 + BM * XS * 4];
   e16* A16 = reinterpret_cast<e16*>(smem);
   float* X = reinterpret_cast<float*>(smem + 4 * PANEL * 2);
@@ -194,7 +206,7 @@ __global__ __launch_bounds__(256) void k_chain_a(rmem_chain_a_desc d) {
   const Rows8<e16x4> sk = load_rows_e16((const e16*)d.short_k, 256, blk, wave, c0);
   const Rows8<e16x4> sv = load_rows_e16((const e16*)d.short_v, 256, blk, wave, c0);
   BRing ring;
-  f32x4 acc[2][4];
+  f32x4 acc[2][JT];
   const e16* wp = wstream((const e16*)d.w_proj, 0, wave, 8);
   stage_tile<4>(A16, 0, (const e16*)d.att + blk.g0 * 256, 256, blk.nrows);
   b_preload(ring, wp, lane);                                     // weights do not depend on anything: in flight before the rows arrive
@@ -206,22 +218,22 @@ __global__ __launch_bounds__(256) void k_chain_a(rmem_chain_a_desc d) {
   b_preload(ring, wq, lane);
   __syncthreads();
   // x += self_proj(att) ; curr_V = LN2(x)
-  e16x4 cv[8];
+  e16x4 cv[RW];
   {
-    f32x4 v[8];
+    f32x4 v[RW];
 #pragma unroll
-    for (int rr = 0; rr < 8; ++rr) {
-      v[rr] = ld4(&X[(wave * 8 + rr) * XS + c0]);
+    for (int rr = 0; rr < RW; ++rr) {
+      v[rr] = ld4(&X[(wave * RW + rr) * XS + c0]);
       v[rr] += bp;
       v[rr] += xo.r[rr];
       st16(rx, row_off(blk, wave, rr, 256, c0, 4), v[rr]);
     }
-    rmem_ln256_rows<8>(v, g2, b2, d.eps);
+    rmem_ln256_rows<RW>(v, g2, b2, d.eps);
 #pragma unroll
-    for (int rr = 0; rr < 8; ++rr) {
+    for (int rr = 0; rr < RW; ++rr) {
       cv[rr] = cvt4(v[rr]);
       st8(rcv, row_off(blk, wave, rr, 256, c0, 2), cv[rr]);
-      put_a(A16, 0, wave * 8 + rr, lane, cv[rr]);
+      put_a(A16, 0, wave * RW + rr, lane, cv[rr]);
     }
   }
   __syncthreads();
@@ -231,10 +243,10 @@ __global__ __launch_bounds__(256) void k_chain_a(rmem_chain_a_desc d) {
   __syncthreads();
   // curr_Q ; k4 = LN4(short_K + curr_Q) ; v4 = LN4(short_V + curr_V)
   {
-    f32x4 kk[8], vv[8];
+    f32x4 kk[RW], vv[RW];
 #pragma unroll
-    for (int rr = 0; rr < 8; ++rr) {
-      f32x4 q = ld4(&X[(wave * 8 + rr) * XS + c0]);
+    for (int rr = 0; rr < RW; ++rr) {
+      f32x4 q = ld4(&X[(wave * RW + rr) * XS + c0]);
       q += bq;
       const e16x4 cq = cvt4(q);
       st8(rcq, row_off(blk, wave, rr, 256, c0, 2), cq);
@@ -243,10 +255,10 @@ __global__ __launch_bounds__(256) void k_chain_a(rmem_chain_a_desc d) {
       vv[rr] = up4(sv.r[rr]);
       vv[rr] += up4(cv[rr]);
     }
-    rmem_ln256_rows<8>(kk, g4, b4, d.eps);
-    rmem_ln256_rows<8>(vv, g4, b4, d.eps);
+    rmem_ln256_rows<RW>(kk, g4, b4, d.eps);
+    rmem_ln256_rows<RW>(vv, g4, b4, d.eps);
 #pragma unroll
-    for (int rr = 0; rr < 8; ++rr) {
+    for (int rr = 0; rr < RW; ++rr) {
       const int off = row_off(blk, wave, rr, 256, c0, 2);
       st8(rk4, off, cvt4(kk[rr]));
       st8(rv4, off, cvt4(vv[rr]));
@@ -257,8 +269,8 @@ __global__ __launch_bounds__(256) void k_chain_a(rmem_chain_a_desc d) {
 // ------------------------------------------------------------------------------------------------------------ chain B
 // STATS: also write the GroupNorm partial sums of h1 (d.gn_partial)
 template <bool STATS>
-__global__ __launch_bounds__(256) void k_chain_b(rmem_chain_b_desc d) {
-  __shared__ __attribute__((aligned(16))) char smem[8 * PANEL * 2 + 2 * BM * XS * 4 + 4 * 4 * 8 * 2 * 4];
+__global__ __launch_bounds__(NT) void k_chain_b(rmem_chain_b_desc d) {
+  __shared__ __attribute__((aligned(16))) char smem[8 * PANEL * 2 + 2 * BM * XS * 4 + 4 * NW * 8 * 2 * 4];
   e16* A16 = reinterpret_cast<e16*>(smem);
   float* Xa = reinterpret_cast<float*>(smem + 8 * PANEL * 2);
   float* Xb = Xa + BM * XS;
@@ -274,7 +286,7 @@ __global__ __launch_bounds__(256) void k_chain_b(rmem_chain_b_desc d) {
   for (int nb = 0; nb < 4; ++nb) b1[nb] = ld4(d.b1 + nb * 256 + c0);
   const Rows8<f32x4> xo = load_rows_f32(d.x, 256, blk, wave, c0);
   BRing ring;
-  f32x4 acc[2][4];
+  f32x4 acc[2][JT];
   const e16* wl = wstream((const e16*)d.w_long, 0, wave, 8);
   stage_tile<4>(A16, 0, (const e16*)d.att_long + blk.g0 * 256, 256, blk.nrows);
   stage_tile<4>(A16, 4, (const e16*)d.att_short + blk.g0 * 256, 256, blk.nrows);
@@ -293,21 +305,21 @@ __global__ __launch_bounds__(256) void k_chain_b(rmem_chain_b_desc d) {
   __syncthreads();
   // x += long_proj(attL) ; tgt3 = short_proj(attS) ; x += tgt3 ; LN3(x) -> A panels 0..3
   {
-    f32x4 t[8];
+    f32x4 t[RW];
 #pragma unroll
-    for (int rr = 0; rr < 8; ++rr) {
-      f32x4 v1 = ld4(&Xa[(wave * 8 + rr) * XS + c0]);
+    for (int rr = 0; rr < RW; ++rr) {
+      f32x4 v1 = ld4(&Xa[(wave * RW + rr) * XS + c0]);
       v1 += bl;
-      t[rr] = ld4(&Xb[(wave * 8 + rr) * XS + c0]);
+      t[rr] = ld4(&Xb[(wave * RW + rr) * XS + c0]);
       t[rr] += bs;
       v1 += xo.r[rr];                                   // x after the long-term projection (what the unfused route stores)
       st8(rt3, row_off(blk, wave, rr, 256, c0, 2), cvt4(t[rr]));
       t[rr] += v1;
       st16(rx, row_off(blk, wave, rr, 256, c0, 4), t[rr]);
     }
-    rmem_ln256_rows<8>(t, g3, b3, d.eps);
+    rmem_ln256_rows<RW>(t, g3, b3, d.eps);
 #pragma unroll
-    for (int rr = 0; rr < 8; ++rr) put_a(A16, 0, wave * 8 + rr, lane, cvt4(t[rr]));
+    for (int rr = 0; rr < RW; ++rr) put_a(A16, 0, wave * RW + rr, lane, cvt4(t[rr]));
   }
   __syncthreads();
   // h1 = linear1(LN3(x)): four column blocks of 256, staged alternately through Xa / Xb (one barrier per block)
@@ -321,14 +333,14 @@ __global__ __launch_bounds__(256) void k_chain_b(rmem_chain_b_desc d) {
     __syncthreads();
     float gs = 0.f, gss = 0.f;          // this lane's channels belong to ONE GroupNorm group (32 channels = 8 lanes) per block
 #pragma unroll
-    for (int rr = 0; rr < 8; ++rr) {
-      f32x4 v = ld4(&X[(wave * 8 + rr) * XS + c0]);
+    for (int rr = 0; rr < RW; ++rr) {
+      f32x4 v = ld4(&X[(wave * RW + rr) * XS + c0]);
       v += b1[nb];
       const e16x4 h = cvt4(v);
       st8(rh1, row_off(blk, wave, rr, 1024, nb * 256 + c0, 2), h);
       if (STATS) {
         const f32x4 hf = up4(h);
-        const float okf = wave * 8 + rr < blk.nrows ? 1.f : 0.f;      // (a select, not a branch)
+        const float okf = wave * RW + rr < blk.nrows ? 1.f : 0.f;      // (a select, not a branch)
         gs += okf * rmem_sum4(hf);
         gss += okf * rmem_sumsq4(hf);
       }
@@ -338,7 +350,7 @@ __global__ __launch_bounds__(256) void k_chain_b(rmem_chain_b_desc d) {
       gs += __shfl_xor(gs, 1); gss += __shfl_xor(gss, 1);
       gs += __shfl_xor(gs, 2); gss += __shfl_xor(gss, 2);
       gs += __shfl_xor(gs, 4); gss += __shfl_xor(gss, 4);
-      if ((lane & 7) == 0) { gsum[((nb * 4 + wave) * 8 + (lane >> 3)) * 2] = gs; gsum[((nb * 4 + wave) * 8 + (lane >> 3)) * 2 + 1] = gss; }
+      if ((lane & 7) == 0) { gsum[((nb * NW + wave) * 8 + (lane >> 3)) * 2] = gs; gsum[((nb * NW + wave) * 8 + (lane >> 3)) * 2 + 1] = gss; }
     }
   }
   if (STATS) {
@@ -348,7 +360,7 @@ __global__ __launch_bounds__(256) void k_chain_b(rmem_chain_b_desc d) {
       const int nb = threadIdx.x >> 3, g = threadIdx.x & 7;
       float a = 0.f, b = 0.f;
 #pragma unroll
-      for (int w = 0; w < 4; ++w) { a += gsum[((nb * 4 + w) * 8 + g) * 2]; b += gsum[((nb * 4 + w) * 8 + g) * 2 + 1]; }
+      for (int w = 0; w < NW; ++w) { a += gsum[((nb * NW + w) * 8 + g) * 2]; b += gsum[((nb * NW + w) * 8 + g) * 2 + 1]; }
       float* o = d.gn_partial + (((long)blockIdx.y * 32 + threadIdx.x) * d.gn_splits + blockIdx.x) * 2;
       o[0] = a; o[1] = b;
     }
@@ -359,7 +371,7 @@ __global__ __launch_bounds__(256) void k_chain_b(rmem_chain_b_desc d) {
 // FFN2: x += linear2(h3) first (else the rows are read from x as they are: the first block of the stack);
 // NEXT: LN1' + fused QKV projection of the next block
 template <bool FFN2, bool NEXT>
-__global__ __launch_bounds__(256) void k_chain_c(rmem_chain_c_desc d) {
+__global__ __launch_bounds__(NT) void k_chain_c(rmem_chain_c_desc d) {
   constexpr int NPA = FFN2 ? 16 : 4;
   __shared__ __attribute__((aligned(16))) char smem[NPA * PANEL * 2 + 2 * BM * XS * 4];
   e16* A16 = reinterpret_cast<e16*>(smem);
@@ -381,7 +393,7 @@ __global__ __launch_bounds__(256) void k_chain_c(rmem_chain_c_desc d) {
   }
   const Rows8<f32x4> xo = load_rows_f32(d.x, 256, blk, wave, c0);
   BRing ring;
-  f32x4 acc[2][4];
+  f32x4 acc[2][JT];
   const e16* wq = NEXT ? wstream((const e16*)d.w_qkv, 0, wave, 8) : nullptr;
   if (FFN2) {
     const e16* w2 = wstream((const e16*)d.w2, 0, wave, 32);
@@ -397,28 +409,28 @@ __global__ __launch_bounds__(256) void k_chain_c(rmem_chain_c_desc d) {
     b_preload(ring, wq, lane);
   }
   {
-    f32x4 v[8];
+    f32x4 v[RW];
     if (FFN2) {
-      f32x4 vd[8];
+      f32x4 vd[RW];
 #pragma unroll
-      for (int rr = 0; rr < 8; ++rr) {
-        v[rr] = ld4(&Xa[(wave * 8 + rr) * XS + c0]);
+      for (int rr = 0; rr < RW; ++rr) {
+        v[rr] = ld4(&Xa[(wave * RW + rr) * XS + c0]);
         v[rr] += b2;
         v[rr] += xo.r[rr];
         st16(rx, row_off(blk, wave, rr, 256, c0, 4), v[rr]);
         vd[rr] = v[rr];
       }
-      rmem_ln256_rows<8>(vd, gd, bd, d.eps);
+      rmem_ln256_rows<RW>(vd, gd, bd, d.eps);
 #pragma unroll
-      for (int rr = 0; rr < 8; ++rr) st8(rdec, row_off(blk, wave, rr, d.ld_dec, c0, 2), cvt4(vd[rr]));
+      for (int rr = 0; rr < RW; ++rr) st8(rdec, row_off(blk, wave, rr, d.ld_dec, c0, 2), cvt4(vd[rr]));
     } else {
 #pragma unroll
-      for (int rr = 0; rr < 8; ++rr) v[rr] = xo.r[rr];
+      for (int rr = 0; rr < RW; ++rr) v[rr] = xo.r[rr];
     }
     if (NEXT) {
-      rmem_ln256_rows<8>(v, g1, b1, d.eps);
+      rmem_ln256_rows<RW>(v, g1, b1, d.eps);
 #pragma unroll
-      for (int rr = 0; rr < 8; ++rr) put_a(A16, 0, wave * 8 + rr, lane, cvt4(v[rr]));
+      for (int rr = 0; rr < RW; ++rr) put_a(A16, 0, wave * RW + rr, lane, cvt4(v[rr]));
     }
   }
   if (!NEXT) return;
@@ -433,8 +445,8 @@ __global__ __launch_bounds__(256) void k_chain_c(rmem_chain_c_desc d) {
     if (nb < 2) { wq = wstream((const e16*)d.w_qkv, nb + 1, wave, 8); b_preload(ring, wq, lane); }
     __syncthreads();
 #pragma unroll
-    for (int rr = 0; rr < 8; ++rr) {
-      f32x4 v = ld4(&X[(wave * 8 + rr) * XS + c0]);
+    for (int rr = 0; rr < RW; ++rr) {
+      f32x4 v = ld4(&X[(wave * RW + rr) * XS + c0]);
       v += bq[nb];
       v += pos.r[rr];
       st8(rqkv, row_off(blk, wave, rr, 768, nb * 256 + c0, 2), cvt4(v));
@@ -442,6 +454,11 @@ __global__ __launch_bounds__(256) void k_chain_c(rmem_chain_c_desc d) {
   }
 }
 
+#ifndef RMEM_F16
+}  // namespace
+extern "C" int rmem_lstt_chain_waves(void) { return NW; }
+namespace {
+#endif
 bool al16(const void* p) { return p == nullptr || ((uintptr_t)p % 16) == 0; }
 
 }  // namespace
@@ -453,7 +470,7 @@ extern "C" int RMEM_API(rmem_lstt_chain_a)(const rmem_chain_a_desc* d, void* str
   RMEM_REQUIRE(al16(d->att) && al16(d->x) && al16(d->w_proj) && al16(d->w_q) && al16(d->curr_v) && al16(d->curr_q) && al16(d->short_k) &&
                al16(d->short_v) && al16(d->k4) && al16(d->v4) && al16(d->b_proj) && al16(d->b_q) && al16(d->ln2_g) && al16(d->ln2_b) &&
                al16(d->ln4_g) && al16(d->ln4_b), "rmem_lstt_chain_a: operands must be 16-byte aligned");
-  hipLaunchKernelGGL(k_chain_a, dim3((d->L + BM - 1) / BM, d->clips), dim3(256), 0, (hipStream_t)stream, *d);
+  hipLaunchKernelGGL(k_chain_a, dim3((d->L + BM - 1) / BM, d->clips), dim3(NT), 0, (hipStream_t)stream, *d);
   return rmem_check_launch("rmem_lstt_chain_a");
 }
 
@@ -465,8 +482,8 @@ extern "C" int RMEM_API(rmem_lstt_chain_b)(const rmem_chain_b_desc* d, void* str
                al16(d->h1) && al16(d->b_long) && al16(d->b_short) && al16(d->b1) && al16(d->ln3_g) && al16(d->ln3_b),
                "rmem_lstt_chain_b: operands must be 16-byte aligned");
   RMEM_REQUIRE(!d->gn_partial || d->gn_splits >= (d->L + BM - 1) / BM, "rmem_lstt_chain_b: gn_splits must cover the row blocks of a clip");
-  if (d->gn_partial) hipLaunchKernelGGL(k_chain_b<true>, dim3((d->L + BM - 1) / BM, d->clips), dim3(256), 0, (hipStream_t)stream, *d);
-  else hipLaunchKernelGGL(k_chain_b<false>, dim3((d->L + BM - 1) / BM, d->clips), dim3(256), 0, (hipStream_t)stream, *d);
+  if (d->gn_partial) hipLaunchKernelGGL(k_chain_b<true>, dim3((d->L + BM - 1) / BM, d->clips), dim3(NT), 0, (hipStream_t)stream, *d);
+  else hipLaunchKernelGGL(k_chain_b<false>, dim3((d->L + BM - 1) / BM, d->clips), dim3(NT), 0, (hipStream_t)stream, *d);
   return rmem_check_launch("rmem_lstt_chain_b");
 }
 
@@ -481,8 +498,8 @@ extern "C" int RMEM_API(rmem_lstt_chain_c)(const rmem_chain_c_desc* d, void* str
                al16(d->ln1_b) && al16(d->w_qkv) && al16(d->b_qkv) && al16(d->pos_qk) && al16(d->qkv), "rmem_lstt_chain_c: operands must be 16-byte aligned");
   const dim3 grid((d->L + BM - 1) / BM, d->clips);
   hipStream_t s = (hipStream_t)stream;
-  if (ffn2 && next) hipLaunchKernelGGL((k_chain_c<true, true>), grid, dim3(256), 0, s, *d);
-  else if (ffn2) hipLaunchKernelGGL((k_chain_c<true, false>), grid, dim3(256), 0, s, *d);
-  else hipLaunchKernelGGL((k_chain_c<false, true>), grid, dim3(256), 0, s, *d);
+  if (ffn2 && next) hipLaunchKernelGGL((k_chain_c<true, true>), grid, dim3(NT), 0, s, *d);
+  else if (ffn2) hipLaunchKernelGGL((k_chain_c<true, false>), grid, dim3(NT), 0, s, *d);
+  else hipLaunchKernelGGL((k_chain_c<false, true>), grid, dim3(NT), 0, s, *d);
   return rmem_check_launch("rmem_lstt_chain_c");
 }

@@ -29,14 +29,18 @@ def _conv_w(w: torch.Tensor, cin_pad: int = 0) -> torch.Tensor:
     return w.contiguous().to(_DT)
 
 
-def pack_frag(w: torch.Tensor) -> torch.Tensor:
+def pack_frag(w: torch.Tensor, waves: int = 0) -> torch.Tensor:
     """[N, K] 16-bit weight (nn.Linear layout, N % 256 == 0, K % 32 == 0) -> the fragment order the LSTT chain kernels stream
-    (include/rmem.h, rmem_lstt_chain_*): [N / 256][4 waves][K / 32][4 column tiles][64 lanes][8], element (n, k) with
-    n = 256 nb + 64 wave + 16 j + (lane & 15), k = 32 kc + 8 (lane >> 4) + e -- one MFMA B fragment per KiB."""
+    (include/rmem.h, rmem_lstt_chain_*): [N / 256][NW waves][K / 32][16 / NW column tiles][64 lanes][8], element (n, k) with
+    n = 256 nb + (256 / NW) wave + 16 j + (lane & 15), k = 32 kc + 8 (lane >> 4) + e -- one MFMA B fragment per KiB.
+    waves = 0: what the loaded library was built for (rmem_lstt_chain_waves)."""
+    if not waves:
+        from . import _lib
+        waves = _lib.lib().rmem_lstt_chain_waves()
     N, K = w.shape
-    assert N % 256 == 0 and K % 32 == 0, (N, K)
-    v = w.reshape(N // 256, 4, 4, 16, K // 32, 4, 8)          # nb, wave, j, fr, kc, fc, e
-    return v.permute(0, 1, 4, 2, 5, 3, 6).contiguous().reshape(-1)   # nb, wave, kc, j, fc, fr, e  (lane = 16 fc + fr)
+    assert N % 256 == 0 and K % 32 == 0 and waves in (4, 8), (N, K, waves)
+    v = w.reshape(N // 256, waves, 16 // waves, 16, K // 32, 4, 8)          # nb, wave, j, fr, kc, fc, e
+    return v.permute(0, 1, 4, 2, 5, 3, 6).contiguous().reshape(-1)            # nb, wave, kc, j, fc, fr, e  (lane = 16 fc + fr)
 
 
 def _fold_bn(sd, conv_key: str, bn_prefix: str, cin_pad: int = 0):

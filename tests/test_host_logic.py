@@ -142,8 +142,9 @@ def test_pack_frag_layout():
     from rmem_ocu_amd.pack import pack_frag
     N, K = 512, 64
     w = (torch.arange(N)[:, None] * 1000 + torch.arange(K)[None, :]).float()
-    f = pack_frag(w).reshape(N // 256, 4, K // 32, 4, 64, 8)
-    for nb, wave, kc, j, lane, e in [(0, 0, 0, 0, 0, 0), (1, 3, 1, 2, 37, 5), (0, 2, 1, 3, 63, 7), (1, 0, 0, 1, 16, 0)]:
-        n = 256 * nb + 64 * wave + 16 * j + (lane & 15)
-        k = 32 * kc + 8 * (lane >> 4) + e
-        assert f[nb, wave, kc, j, lane, e].item() == n * 1000 + k
+    for nw in (4, 8):
+        f = pack_frag(w, nw).reshape(N // 256, nw, K // 32, 16 // nw, 64, 8)
+        for nb, wave, kc, j, lane, e in [(0, 0, 0, 0, 0, 0), (1, 3, 1, 1, 37, 5), (0, 2, 1, 16 // nw - 1, 63, 7), (1, nw - 1, 0, 1, 16, 0)]:
+            n = 256 * nb + (256 // nw) * wave + 16 * j + (lane & 15)
+            k = 32 * kc + 8 * (lane >> 4) + e
+            assert f[nb, wave, kc, j, lane, e].item() == n * 1000 + k
