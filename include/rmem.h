@@ -311,6 +311,21 @@ int rmem_gated_attn(const void* q, int ldq,                                     
 int rmem_local_gated_attn(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const float* rel, int ldrel,
                           int H, int W, int DV, const void* u_a, int ldua, const void* u_b, int ldub, int usplit,
                           void* out, int ldo, const float* dw_w_t, void* workspace, void* stream);
+
+/* Both gated attentions for nclips independent clips of identical shape in ONE launch per kernel (clips of a group advance in
+ * lockstep): q, the gates, out and (one-frame calls) k / v / rel are [clip][rows][ld] arrays, i.e. clip c sits rows * ld elements
+ * further; the bank is addressed through GLOBAL slot indexes in the table, clip c's table rows are chunks[c * nchunks ...], its
+ * mass attn_mass + c * Lq * frames; the workspace is nclips times rmem_gated_attn_workspace_bytes.  Results per clip are those
+ * of the single-clip entry points (the split of the key stream into partial-sum slabs depends on the clip count: fp32 summation
+ * order only). */
+int rmem_gated_attn_clips(const void* q, int ldq, const void* k_bank, long long k_slot_stride, int ldk, const void* v_bank,
+                          long long v_slot_stride, int ldv, const rmem_attn_chunk* chunks, int nchunks, int frames, int keys_per_frame,
+                          const float* pe_cur, const float* pe_mem, int Lq, int DV, const void* u_a, int ldua, const void* u_b, int ldub,
+                          int usplit, void* out, int ldo, float* attn_mass, const float* dw_w_t, int H, int W, int nclips,
+                          void* workspace, void* stream);
+int rmem_local_gated_attn_clips(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const float* rel, int ldrel,
+                                int H, int W, int DV, const void* u_a, int ldua, const void* u_b, int ldub, int usplit, void* out, int ldo,
+                                const float* dw_w_t, int nclips, void* workspace, void* stream);
 /* HIP-event timing of the k_gp_pv launches of rmem_gated_attn calls that carry a chunk table (bench.py's roofline leg) */
 int rmem_gated_profile_start(void);
 int rmem_gated_profile_stop(double* total_ms, double* total_flops, int* launches);
@@ -446,6 +461,8 @@ int rmem_label_to_onehot16_f16(const void* label, int label_is_f32, int Hs, int 
 int rmem_label_to_onehot16_images_f16(const void* label, int label_is_f32, int images, int Hs, int Ws, int Hd, int Wd, int num_classes, void* out, void* stream);
 int rmem_gated_attn_f16(const void* q, int ldq, const void* k_bank, long long k_slot_stride, int ldk, const void* v_bank, long long v_slot_stride, int ldv, const rmem_attn_chunk* chunks, int nchunks, int frames, int keys_per_frame, const float* pe_cur, const float* pe_mem, int Lq, int DV, const void* u_a, int ldua, const void* u_b, int ldub, int usplit, void* out, int ldo, float* attn_mass, const float* dw_w_t, int H, int W, void* workspace, void* stream);
 int rmem_local_gated_attn_f16(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const float* rel, int ldrel, int H, int W, int DV, const void* u_a, int ldua, const void* u_b, int ldub, int usplit, void* out, int ldo, const float* dw_w_t, void* workspace, void* stream);
+int rmem_gated_attn_clips_f16(const void* q, int ldq, const void* k_bank, long long k_slot_stride, int ldk, const void* v_bank, long long v_slot_stride, int ldv, const rmem_attn_chunk* chunks, int nchunks, int frames, int keys_per_frame, const float* pe_cur, const float* pe_mem, int Lq, int DV, const void* u_a, int ldua, const void* u_b, int ldub, int usplit, void* out, int ldo, float* attn_mass, const float* dw_w_t, int H, int W, int nclips, void* workspace, void* stream);
+int rmem_local_gated_attn_clips_f16(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const float* rel, int ldrel, int H, int W, int DV, const void* u_a, int ldua, const void* u_b, int ldub, int usplit, void* out, int ldo, const float* dw_w_t, int nclips, void* workspace, void* stream);
 
 #ifdef __cplusplus
 }

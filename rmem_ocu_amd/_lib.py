@@ -105,6 +105,9 @@ SIGNATURES = {
     'rmem_gated_attn': (_i, [_vp, _i, _vp, _ll, _i, _vp, _ll, _i, _vp, _i, _i, _i, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _i, _vp, _i,
                              _vp, _vp, _i, _i, _vp, _vp]),
     'rmem_local_gated_attn': (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _vp]),
+    'rmem_gated_attn_clips': (_i, [_vp, _i, _vp, _ll, _i, _vp, _ll, _i, _vp, _i, _i, _i, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _i, _vp, _i,
+                                   _vp, _vp, _i, _i, _i, _vp, _vp]),
+    'rmem_local_gated_attn_clips': (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _i, _vp, _i, _vp, _i, _vp, _vp]),
     'rmem_gated_profile_start': (_i, []),
     'rmem_gated_profile_stop': (_i, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i)]),
     'rmem_graph_begin': (_i, [_vp]),
@@ -119,7 +122,7 @@ F16_TWINS = ('rmem_conv2d_nhwc', 'rmem_mem_read_attn', 'rmem_mem_read_attn_clips
              'rmem_groupnorm_nhwc', 'rmem_groupnorm_f32_nhwc', 'rmem_groupnorm_nhwc_images', 'rmem_groupnorm_head_nhwc_images',
              'rmem_gn_act_dwconv5x5_nhwc_images', 'rmem_gn_act_dwconv5x5_prestats_nhwc_images', 'rmem_gn_act_dwconv5x5_nhwc', 'rmem_dwconv5x5_nhwc', 'rmem_image_to_nhwc8',
              'rmem_image_to_nhwc8_images', 'rmem_ingest_rgb8', 'rmem_maxpool3x3s2_nhwc', 'rmem_maxpool3x3s2_nhwc_images', 'rmem_bilinear_nhwc',
-             'rmem_bilinear_nhwc_images', 'rmem_label_to_onehot16', 'rmem_label_to_onehot16_images', 'rmem_gated_attn', 'rmem_local_gated_attn')
+             'rmem_bilinear_nhwc_images', 'rmem_label_to_onehot16', 'rmem_label_to_onehot16_images', 'rmem_gated_attn', 'rmem_local_gated_attn', 'rmem_gated_attn_clips', 'rmem_local_gated_attn_clips')
 SIGNATURES.update({n + '_f16': SIGNATURES[n] for n in F16_TWINS})
 
 _lib = None

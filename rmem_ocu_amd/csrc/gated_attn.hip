@@ -56,7 +56,19 @@ struct GpParams {
   int DV, nq, ncs, groups, rows_per_group;
   float* slabs;
   int debug;               // kernel experiments only (RMEM_GP_DEBUG): 1 = no MFMA, 2 = no refills after the first stages
+  // several clips of identical shape in one launch: clip c's queries / one-frame keys and values / relative logits sit c * {q, k, v,
+  // rel}_cs elements further (the bank is addressed through global slot indexes in the table: k_cs = v_cs = 0 there), its table
+  // rows at rows + c * rows_cs, its share of the workspace c * ws_cs BYTES further
+  int nclips; long q_cs, k_cs, v_cs, rel_cs, ws_cs; int rows_cs;
 };
+
+__device__ __forceinline__ void gp_select_clip(GpParams& p, int clip) {
+  p.q += clip * p.q_cs; p.k += clip * p.k_cs; p.v += clip * p.v_cs;
+  if (p.rows) p.rows += clip * p.rows_cs;
+  if (p.rel) p.rel += clip * p.rel_cs;
+  const long wf = clip * (p.ws_cs >> 2);
+  p.mpart += wf; p.lpart += wf; p.slabs += wf; p.P += clip * (p.ws_cs >> 1);
+}
 
 // MODE 0: one key frame split into nrows ranges of `per` keys; 1: chunk table over the memory bank; 2: as 0 with the 15x15
 // window mask and the relative embedding
@@ -97,6 +109,7 @@ __global__ __launch_bounds__(256) void k_gp_scores(GpParams p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int qh = wave >> 1, kh = wave & 1, lq = lane & 31, kg = lane >> 5;
+  gp_select_clip(p, blockIdx.z);
   const int q0 = blockIdx.x * QT;
   const GpRow row = get_row<MODE>(p, blockIdx.y);
   const e16* Kp = p.k + (long)row.slot * p.k_slot_stride + (long)row.kb * p.ldk;
@@ -395,14 +408,16 @@ __global__ __launch_bounds__(256) void k_gp_pv(GpParams p) {
   // value slice) with the value slice fastest, so one XCD's L2 sees few distinct P and V tiles at a time
   int g, qt, cs;
   {
-    const int total = p.nq * p.ncs * p.groups;
+    const int total = p.nq * p.ncs * p.groups * p.nclips;
     const int b = blockIdx.x, xcd = b & 7, j = b >> 3;
     const int qd = total >> 3, rm = total & 7;
     const int idx = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + j;
     cs = idx % p.ncs;
-    const int rest = idx / p.ncs;
+    int rest = idx / p.ncs;
     qt = rest % p.nq;
-    g = rest / p.nq;
+    rest /= p.nq;
+    g = rest % p.groups;
+    gp_select_clip(p, rest / p.groups);
   }
   const int q0 = qt * QT, c0 = cs * CW;
   // table rows in LDS (scalar-like reads that do not touch vmcnt: the DMA pipeline below counts on vmcnt); the key tiles of
@@ -542,10 +557,22 @@ struct GpCombine {
   e16* out; int ldo;
   const rmem_attn_chunk* rows; float* mass; int T;
   const float* dw; int H, W;        // optional: depth-wise 5x5 (weights [25][DV]) applied to the gated output in the same launch
+  long ua_cs, ub_cs, out_cs, mass_cs, ws_cs; int rows_cs;      // per-clip strides (elements; ws_cs bytes), clip = blockIdx.z
 };
+
+__device__ __forceinline__ void gp_select_clip(GpCombine& p, int clip) {
+  const long wf = clip * (p.ws_cs >> 2);
+  p.slabs += wf; p.lpart += wf;
+  p.ua += clip * p.ua_cs;
+  if (p.ub) p.ub += clip * p.ub_cs;
+  p.out += clip * p.out_cs;
+  if (p.rows) p.rows += clip * p.rows_cs;
+  if (p.mass) p.mass += clip * p.mass_cs;
+}
 
 // out[q, c] = (sum_g slab[g][q][c]) / l[q] * U[q][c]; thread = 8 columns of one query
 __global__ __launch_bounds__(256) void k_gp_combine(GpCombine p) {
+  gp_select_clip(p, blockIdx.z);
   const int vpr = p.DV / 8;
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= (long)p.Lq * vpr) return;
@@ -585,6 +612,7 @@ __global__ __launch_bounds__(256) void k_gp_combine_dwconv(GpCombine p) {
   __shared__ __attribute__((aligned(16))) float wl[25 * CT_C];
   __shared__ float inv_l[CT_HW];
   const int tid = threadIdx.x;
+  gp_select_clip(p, blockIdx.z);
   const int tiles_x = (p.W + CT_W - 1) / CT_W;
   const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
   const int c0 = blockIdx.y * CT_C;
@@ -660,6 +688,7 @@ __global__ __launch_bounds__(256) void k_gp_combine_dwconv(GpCombine p) {
 
 // mass[q][t] = sum of the row sums of frame t / total (transformer.py:1185-1192 with one head); grid = (query blocks, T)
 __global__ __launch_bounds__(256) void k_gp_mass(GpCombine p) {
+  gp_select_clip(p, blockIdx.z);
   const int q = blockIdx.x * 256 + threadIdx.x, t = blockIdx.y;
   if (q >= p.Lq) return;
   float l = 0.f, lt = 0.f;
@@ -673,13 +702,13 @@ __global__ __launch_bounds__(256) void k_gp_mass(GpCombine p) {
 
 struct GpPlan { int Lqp, Lp, ldp, nrows, groups, rpg; size_t off_l, off_p, off_s, total; };
 
-GpPlan plan(int Lq, int DV, int frames, int keys_per_frame, int nrows) {
+GpPlan plan(int Lq, int DV, int frames, int keys_per_frame, int nrows, int nclips = 1) {
   GpPlan g;
   g.Lqp = (Lq + QT - 1) / QT * QT;
   g.Lp = (keys_per_frame + KT - 1) / KT * KT;
   g.ldp = frames * g.Lp;
   g.nrows = nrows;
-  const int tiles = (g.Lqp / QT) * (DV / CW);
+  const int tiles = (g.Lqp / QT) * (DV / CW) * (nclips > 0 ? nclips : 1);
   int groups = tiles >= 256 ? 1 : 256 / tiles;      // about one workgroup per CU; the key-tile stream is cut evenly
   const int max_tiles = frames * (g.Lp / KT);
   if (groups > 8) groups = 8;
@@ -712,10 +741,10 @@ int check_common(const void* q, int ldq, const void* k, int ldk, const void* v, 
 
 template <int MODE>
 void launch_all(GpParams& p, const GpPlan& g, GpCombine& c, bool timed, double flops, hipStream_t s) {
-  const dim3 sg(p.nq, p.nrows);
+  const dim3 sg(p.nq, p.nrows, p.nclips);
   hipLaunchKernelGGL((k_gp_scores<MODE, 0>), sg, dim3(256), 0, s, p);
   hipLaunchKernelGGL((k_gp_scores<MODE, 1>), sg, dim3(256), 0, s, p);
-  const dim3 pg(p.nq * p.ncs * p.groups);
+  const dim3 pg(p.nq * p.ncs * p.groups * p.nclips);
   constexpr int PM = MODE == 1 ? 1 : 0;
   const int slot = timed ? rmem_prof_begin(RMEM_PROF_GATED_PV, s, flops) : -1;      // rmem_gated_profile_start: bench.py's DeAOT roofline leg
   if (slot >= 0) {
@@ -724,9 +753,9 @@ void launch_all(GpParams& p, const GpPlan& g, GpCombine& c, bool timed, double f
   } else {
     hipLaunchKernelGGL((k_gp_pv<PM, false>), pg, dim3(256), 0, s, p);
   }
-  if (c.dw) hipLaunchKernelGGL(k_gp_combine_dwconv, dim3(((c.W + CT_W - 1) / CT_W) * ((c.H + CT_H - 1) / CT_H), c.DV / CT_C), dim3(256), 0, s, c);
-  else hipLaunchKernelGGL(k_gp_combine, dim3((unsigned)(((long)c.Lq * (c.DV / 8) + 255) / 256)), dim3(256), 0, s, c);
-  if (c.mass) hipLaunchKernelGGL(k_gp_mass, dim3((c.Lq + 255) / 256, c.T), dim3(256), 0, s, c);
+  if (c.dw) hipLaunchKernelGGL(k_gp_combine_dwconv, dim3(((c.W + CT_W - 1) / CT_W) * ((c.H + CT_H - 1) / CT_H), c.DV / CT_C, p.nclips), dim3(256), 0, s, c);
+  else hipLaunchKernelGGL(k_gp_combine, dim3((unsigned)(((long)c.Lq * (c.DV / 8) + 255) / 256), 1, p.nclips), dim3(256), 0, s, c);
+  if (c.mass) hipLaunchKernelGGL(k_gp_mass, dim3((c.Lq + 255) / 256, c.T, p.nclips), dim3(256), 0, s, c);
   (void)g;
 }
 
@@ -735,15 +764,30 @@ void launch_all(GpParams& p, const GpPlan& g, GpCombine& c, bool timed, double f
 #ifndef RMEM_F16
 extern "C" size_t rmem_gated_attn_workspace_bytes(int Lq, int DV, int frames, int keys_per_frame, int nrows) {
   if (Lq <= 0 || DV < CW || DV % CW || frames < 1 || keys_per_frame < 1 || nrows < 1 || nrows > MAX_ROWS) return 0;
-  return plan(Lq, DV, frames, keys_per_frame, nrows).total;
+  return plan(Lq, DV, frames, keys_per_frame, nrows).total;       // worst case over the clip count (1 clip: most key groups)
 }
 #endif
 
+extern "C" int RMEM_API(rmem_gated_attn_clips)(const void* q, int ldq, const void* k_bank, long long k_slot_stride, int ldk, const void* v_bank,
+                               long long v_slot_stride, int ldv, const rmem_attn_chunk* chunks, int nchunks, int frames,
+                               int keys_per_frame, const float* pe_cur, const float* pe_mem, int Lq, int DV, const void* u_a,
+                               int ldua, const void* u_b, int ldub, int usplit, void* out, int ldo, float* attn_mass,
+                               const float* dw_w_t, int H, int W, int nclips, void* workspace, void* stream);
 extern "C" int RMEM_API(rmem_gated_attn)(const void* q, int ldq, const void* k_bank, long long k_slot_stride, int ldk, const void* v_bank,
                                long long v_slot_stride, int ldv, const rmem_attn_chunk* chunks, int nchunks, int frames,
                                int keys_per_frame, const float* pe_cur, const float* pe_mem, int Lq, int DV, const void* u_a,
                                int ldua, const void* u_b, int ldub, int usplit, void* out, int ldo, float* attn_mass,
                                const float* dw_w_t, int H, int W, void* workspace, void* stream) {
+  return RMEM_API(rmem_gated_attn_clips)(q, ldq, k_bank, k_slot_stride, ldk, v_bank, v_slot_stride, ldv, chunks, nchunks, frames, keys_per_frame,
+                                         pe_cur, pe_mem, Lq, DV, u_a, ldua, u_b, ldub, usplit, out, ldo, attn_mass, dw_w_t, H, W, 1, workspace, stream);
+}
+
+extern "C" int RMEM_API(rmem_gated_attn_clips)(const void* q, int ldq, const void* k_bank, long long k_slot_stride, int ldk, const void* v_bank,
+                               long long v_slot_stride, int ldv, const rmem_attn_chunk* chunks, int nchunks, int frames,
+                               int keys_per_frame, const float* pe_cur, const float* pe_mem, int Lq, int DV, const void* u_a,
+                               int ldua, const void* u_b, int ldub, int usplit, void* out, int ldo, float* attn_mass,
+                               const float* dw_w_t, int H, int W, int nclips, void* workspace, void* stream) {
+  RMEM_REQUIRE(nclips >= 1 && nclips <= 64, "rmem_gated_attn: 1..64 clips");
   if (check_common(q, ldq, k_bank, ldk, v_bank, ldv, Lq, DV, u_a, ldua, u_b, ldub, usplit, out, ldo, workspace, "rmem_gated_attn")) return -1;
   RMEM_REQUIRE(frames >= 1 && keys_per_frame >= 1, "rmem_gated_attn: frames and keys_per_frame must be >= 1");
   RMEM_REQUIRE(nchunks >= 1 && nchunks <= MAX_ROWS, "rmem_gated_attn: 1 <= nchunks <= 64");
@@ -762,7 +806,10 @@ extern "C" int RMEM_API(rmem_gated_attn)(const void* q, int ldq, const void* k_b
     nrows = (keys_per_frame + p.per - 1) / p.per;
   }
   p.nrows = nrows;
-  const GpPlan g = plan(Lq, DV, frames, keys_per_frame, nrows);
+  const GpPlan g = plan(Lq, DV, frames, keys_per_frame, nrows, nclips);
+  // clips: [clip][Lq rows] layouts of q / gates / out; one-frame keys and values [clip][keys]; the bank through global slots
+  p.nclips = nclips; p.q_cs = (long)Lq * ldq; p.k_cs = chunks ? 0 : (long)keys_per_frame * ldk; p.v_cs = chunks ? 0 : (long)keys_per_frame * ldv;
+  p.rel_cs = 0; p.ws_cs = (long)g.total; p.rows_cs = nchunks;
   p.pe_cur = pe_cur; p.pe_mem = pe_mem; p.Lq = Lq; p.Lqp = g.Lqp; p.Lp = g.Lp; p.ldp = g.ldp;
   RMEM_REQUIRE((long)g.Lqp * g.ldp < (1L << 31), "rmem_gated_attn: probability matrix exceeds 2^31 elements");
   char* ws = (char*)workspace;
@@ -775,16 +822,29 @@ extern "C" int RMEM_API(rmem_gated_attn)(const void* q, int ldq, const void* k_b
   c.ua = (const e16*)u_a; c.ldua = ldua; c.ub = (const e16*)u_b; c.ldub = ldub; c.usplit = usplit;
   c.out = (e16*)out; c.ldo = ldo; c.rows = chunks; c.mass = attn_mass; c.T = frames;
   c.dw = dw_w_t; c.H = H; c.W = W;
+  c.ua_cs = (long)Lq * ldua; c.ub_cs = (long)Lq * ldub; c.out_cs = (long)Lq * ldo; c.mass_cs = (long)Lq * frames; c.ws_cs = (long)g.total;
+  c.rows_cs = nchunks;
   hipStream_t s = (hipStream_t)stream;
-  const double flops = 2.0 * (double)Lq * (double)frames * (double)keys_per_frame * (double)DV;
+  const double flops = 2.0 * (double)Lq * (double)frames * (double)keys_per_frame * (double)DV * nclips;
   if (chunks) launch_all<1>(p, g, c, true, flops, s);
   else launch_all<0>(p, g, c, false, flops, s);
   return rmem_check_launch("rmem_gated_attn");
 }
 
+extern "C" int RMEM_API(rmem_local_gated_attn_clips)(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const float* rel,
+                                     int ldrel, int H, int W, int DV, const void* u_a, int ldua, const void* u_b, int ldub,
+                                     int usplit, void* out, int ldo, const float* dw_w_t, int nclips, void* workspace, void* stream);
 extern "C" int RMEM_API(rmem_local_gated_attn)(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const float* rel,
                                      int ldrel, int H, int W, int DV, const void* u_a, int ldua, const void* u_b, int ldub,
                                      int usplit, void* out, int ldo, const float* dw_w_t, void* workspace, void* stream) {
+  return RMEM_API(rmem_local_gated_attn_clips)(q, ldq, k, ldk, v, ldv, rel, ldrel, H, W, DV, u_a, ldua, u_b, ldub, usplit, out, ldo, dw_w_t, 1,
+                                               workspace, stream);
+}
+
+extern "C" int RMEM_API(rmem_local_gated_attn_clips)(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const float* rel,
+                                     int ldrel, int H, int W, int DV, const void* u_a, int ldua, const void* u_b, int ldub,
+                                     int usplit, void* out, int ldo, const float* dw_w_t, int nclips, void* workspace, void* stream) {
+  RMEM_REQUIRE(nclips >= 1 && nclips <= 64, "rmem_local_gated_attn: 1..64 clips");
   const int L = H * W;
   if (check_common(q, ldq, k, ldk, v, ldv, L, DV, u_a, ldua, u_b, ldub, usplit, out, ldo, workspace, "rmem_local_gated_attn")) return -1;
   RMEM_REQUIRE(rel && H > 0 && W > 0 && W < 32768 && ldrel >= WIN * WIN, "rmem_local_gated_attn: bad rel / H / W");
@@ -794,7 +854,9 @@ extern "C" int RMEM_API(rmem_local_gated_attn)(const void* q, int ldq, const voi
   const int want = 8;
   p.per = ((L + want - 1) / want + KT - 1) / KT * KT;
   p.nrows = (L + p.per - 1) / p.per;
-  const GpPlan g = plan(L, DV, 1, L, p.nrows);
+  const GpPlan g = plan(L, DV, 1, L, p.nrows, nclips);
+  p.nclips = nclips; p.q_cs = (long)L * ldq; p.k_cs = (long)L * ldk; p.v_cs = (long)L * ldv; p.rel_cs = (long)L * ldrel; p.ws_cs = (long)g.total;
+  p.rows_cs = 0;
   p.Lq = L; p.Lqp = g.Lqp; p.Lp = g.Lp; p.ldp = g.ldp;
   char* ws = (char*)workspace;
   p.mpart = (float*)ws; p.lpart = (float*)(ws + g.off_l); p.P = (e16*)(ws + g.off_p); p.slabs = (float*)(ws + g.off_s);
@@ -808,6 +870,7 @@ extern "C" int RMEM_API(rmem_local_gated_attn)(const void* q, int ldq, const voi
   c.out = (e16*)out; c.ldo = ldo;
   RMEM_REQUIRE(!dw_w_t || usplit % 64 == 0, "rmem_local_gated_attn: the fused depth-wise conv needs usplit % 64 == 0");
   c.dw = dw_w_t; c.H = H; c.W = W;
+  c.ua_cs = (long)L * ldua; c.ub_cs = (long)L * ldub; c.out_cs = (long)L * ldo; c.mass_cs = 0; c.ws_cs = (long)g.total; c.rows_cs = 0;
   launch_all<2>(p, g, c, false, 0.0, (hipStream_t)stream);
   return rmem_check_launch("rmem_local_gated_attn");
 }

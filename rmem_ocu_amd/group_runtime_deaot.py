@@ -56,7 +56,7 @@ class GroupRuntimeDeAOT(GroupRuntime):
 
     def _gp(self) -> torch.Tensor:
         if self.gp_ws is None:
-            self.gp_ws = ops.gated_workspace(self.L, E2, self.S, self.L, GP_ROWS, self.dev)
+            self.gp_ws = ops.gated_workspace(self.L, E2, self.S, self.L, GP_ROWS, self.dev, nclips=self.B)
         return self.gp_ws
 
     def prepare_pos(self, stream: int):
@@ -83,14 +83,15 @@ class GroupRuntimeDeAOT(GroupRuntime):
         """Clip c's rows of a [B * L, ld] buffer, starting at column col (flat view: the ops take a pointer and a row stride)."""
         return t.view(-1)[c * self.L * ld + col:]
 
-    def _long_attn(self, i: int, c: int, chunks: torch.Tensor, nchunks: int, frames: int, mass: Optional[torch.Tensor]):
+    def _long_attn(self, i: int, chunks: torch.Tensor, nchunks: int, frames: int, mass: Optional[torch.Tensor]):
+        """The long-term gated attention of layer i for ALL clips of the group: one launch per kernel (clip dimension)."""
         P, L = self.P, self.L
-        ub = self._clip(self.idu, c, E1) if i > 0 else None
-        return ops.gated_attn(self._clip(self.qvu[i], c, QVU), self.bank_K[i], self.bank_V[i], self._clip(self.qvu[i], c, QVU, D_ATT + E1),
-                              self._clip(self.g2, c, E2), self._gp(), Lq=L, DV=E2, ldq=QVU, ldk=D_ATT, ldv=E2, ldua=QVU, ldo=E2,
+        ub = self.idu if i > 0 else None
+        return ops.gated_attn(self.qvu[i], self.bank_K[i], self.bank_V[i], self.qvu[i].view(-1)[D_ATT + E1:],
+                              self.g2, self._gp(), Lq=L, DV=E2, ldq=QVU, ldk=D_ATT, ldv=E2, ldua=QVU, ldo=E2,
                               k_slot_stride=L * D_ATT, v_slot_stride=L * E2, chunks=chunks, nchunks=nchunks, frames=frames,
                               keys_per_frame=L, pe_cur=P['pe_cur'], pe_mem=P['pe_mem'], u_b=ub, ldub=E1, usplit=E1, mass=mass,
-                              dw=P[f'g{i}.long_dw.w'], H=self.H16, W=self.W16)
+                              dw=P[f'g{i}.long_dw.w'], H=self.H16, W=self.W16, nclips=self.B)
 
     def _tail(self, name: str, residual) -> list:
         """depth-wise 5x5 ran inside the attention's combine launch (per clip, into g2); the projection into both residual streams
@@ -98,15 +99,15 @@ class GroupRuntimeDeAOT(GroupRuntime):
         return [self._lin(self.g2, name + '_proj', self.xc, E2, 2 * D_MODEL, residual=residual)]
 
     def mem_read_probe(self, T: int, layer: int = 0):
-        """Clip 0's long-term gated attention of ``layer`` at bank size T as a stand-alone Op (bench.py's roofline leg): same launch
-        as prog_lstt's, own key table (bank slots 0 .. T-1), no mass.  Returns (op, algorithmic FLOPs of that one call)."""
+        """The group's long-term gated attention of ``layer`` at bank size T as a stand-alone Op (bench.py's roofline leg): same launch
+        as prog_lstt's (all clips), own key table (bank slots 0 .. T-1), no mass.  Returns (op, algorithmic FLOPs of that one call)."""
         if not 1 <= T <= self.S:
             raise ops.RmemError(f'mem_read_probe: T = {T} outside 1..{self.S}')
         rows, n = GroupRuntime._chunk_rows(self, [list(range(T)) for _ in range(self.B)])
-        table = torch.zeros(n, 8, dtype=torch.int32)
-        table[:, :5] = torch.tensor(rows[:n], dtype=torch.int32)
+        table = torch.zeros(self.B * n, 8, dtype=torch.int32)
+        table[:, :5] = torch.tensor(rows, dtype=torch.int32)
         self._probe_chunks = table.to(self.dev)
-        return self._long_attn(layer, 0, self._probe_chunks, n, T, None), 2.0 * self.L * (T * self.L) * (D_ATT + E2)
+        return self._long_attn(layer, self._probe_chunks, n, T, None), 2.0 * self.L * (T * self.L) * (D_ATT + E2) * self.B
 
     # ------------------------------------------------------------------ programs
     def prog_project(self, e: Optional[int]) -> list:
@@ -138,29 +139,21 @@ class GroupRuntimeDeAOT(GroupRuntime):
                 o.append(self._lin(self.idcat[i], d + '.idu', self.idu, C, E1, relu=3, ldx=2 * C))
             if ref_mode:
                 o += self._write_memory(i) + self._scatter_memory(i)
-            for c in range(B):
-                mass = self.mass[c * L * T:] if (i == 0 and not ref_mode and want_mass) else None
-                o.append(self._long_attn(i, c, self.chunks.view(-1)[c * nchunks * 8:], nchunks, frames, mass))
+            o.append(self._long_attn(i, self.chunks, nchunks, frames, self.mass if (i == 0 and not ref_mode and want_mass) else None))
             o += self._tail(d + '.long', xin)
             o.append(self._lin(self.qvu[i], d + '.rel', self.rel, D_ATT, 225, ldo=REL_LD, ldx=QVU))
-            for c in range(B):
-                ub = self._clip(self.idu, c, E1) if i > 0 else None
-                o.append(ops.local_gated_attn(self._clip(self.qvu[i], c, QVU), self._clip(self.short_K[i], c, D_ATT),
-                                              self._clip(self.short_V[i], c, E2), self._clip(self.rel, c, REL_LD),
-                                              self._clip(self.qvu[i], c, QVU, D_ATT + E1), self._clip(self.g2, c, E2), self._gp(),
-                                              H=self.H16, W=self.W16, DV=E2, ldq=QVU, ldk=D_ATT, ldv=E2, ldrel=REL_LD, ldua=QVU, ldo=E2,
-                                              u_b=ub, ldub=E1, usplit=E1, dw=P[d + '.short_dw.w']))
+            o.append(ops.local_gated_attn(self.qvu[i], self.short_K[i], self.short_V[i], self.rel, self.qvu[i].view(-1)[D_ATT + E1:], self.g2,
+                                          self._gp(), H=self.H16, W=self.W16, DV=E2, ldq=QVU, ldk=D_ATT, ldv=E2, ldrel=REL_LD, ldua=QVU,
+                                          ldo=E2, u_b=self.idu if i > 0 else None, ldub=E1, usplit=E1, dw=P[d + '.short_dw.w'], nclips=B))
             o += self._tail(d + '.short', self.xc)
             # --- gated self-attention over [LN(tgt) | LN(tgt_id)] (1222-1232)
             o.append(ops.layernorm256(self.xc, P[d + '.ln2.g'], P[d + '.ln2.b'], M=R, lda=2 * C, y=self.xn, ldy=2 * C))
             o.append(ops.layernorm256(self.xc.view(-1)[C:], P[d + '.idn2.g'], P[d + '.idn2.b'], M=R, lda=2 * C,
                                       y=self.xn.view(-1)[C:], ldy=2 * C))
             o.append(self._lin(self.xn, d + '.self', self.sqvu, 2 * C, SQVU, relu=3, act_begin=D_ATT))
-            for c in range(B):
-                o.append(ops.gated_attn(self._clip(self.sqvu, c, SQVU), self._clip(self.sqvu, c, SQVU), self._clip(self.sqvu, c, SQVU, D_ATT),
-                                        self._clip(self.sqvu, c, SQVU, D_ATT + E2), self._clip(self.g2, c, E2), self._gp(), Lq=L, DV=E2,
-                                        ldq=SQVU, ldk=SQVU, ldv=SQVU, ldua=SQVU, ldo=E2, nchunks=8, frames=1, keys_per_frame=L,
-                                        dw=P[d + '.self_dw.w'], H=self.H16, W=self.W16))
+            o.append(ops.gated_attn(self.sqvu, self.sqvu, self.sqvu.view(-1)[D_ATT:], self.sqvu.view(-1)[D_ATT + E2:], self.g2, self._gp(),
+                                    Lq=L, DV=E2, ldq=SQVU, ldk=SQVU, ldv=SQVU, ldua=SQVU, ldo=E2, nchunks=8, frames=1, keys_per_frame=L,
+                                    dw=P[d + '.self_dw.w'], H=self.H16, W=self.W16, nclips=B))
             o += self._tail(d + '.self', self.xc)
         for c in range(B):      # GroupNorm1D(512, 2) over fp32 rows, statistics per clip (760-808)
             o.append(ops.groupnorm(self._clip(self.xc, c, 2 * C), P['dec_gn.g'], P['dec_gn.b'], self._clip(self.dec_in, c, 2 * C),

@@ -477,44 +477,45 @@ def copy2d_async(dst, dst_pitch: int, src, src_pitch: int, row_bytes: int, rows:
     return Op(_lib.lib().rmem_copy2d_async, (_ptr(dst), dst_pitch, _ptr(src), src_pitch, row_bytes, rows), 'rmem_copy2d_async', (dst, src))
 
 
-def gated_workspace(Lq: int, DV: int, frames: int, keys_per_frame: int, nchunks: int, device) -> torch.Tensor:
+def gated_workspace(Lq: int, DV: int, frames: int, keys_per_frame: int, nchunks: int, device, nclips: int = 1) -> torch.Tensor:
     n = _lib.lib().rmem_gated_attn_workspace_bytes(Lq, DV, frames, keys_per_frame, nchunks)
     if n == 0:
         raise RmemError('rmem_gated_attn_workspace_bytes: bad geometry')
-    return torch.empty(n // 4 + 64, dtype=F32, device=device)
+    return torch.empty(nclips * n // 4 + 64, dtype=F32, device=device)
 
 
 def gated_attn(q, k_bank, v_bank, u_a, out, workspace, *, Lq, DV, ldq, ldk, ldv, ldua, ldo, k_slot_stride=0, v_slot_stride=0,
                chunks=None, nchunks=1, frames=1, keys_per_frame, pe_cur=None, pe_mem=None, u_b=None, ldub=0, usplit=None,
-               mass=None, dw=None, H=0, W=0) -> Op:
-    """DeAOT gated propagation attention (single head, d_att 128); see include/rmem.h."""
+               mass=None, dw=None, H=0, W=0, nclips=1) -> Op:
+    """DeAOT gated propagation attention (single head, d_att 128); see include/rmem.h.  nclips > 1: [clip][rows][ld] operands."""
     _dev(q, k_bank, v_bank, u_a, u_b, out, workspace, chunks, pe_cur, pe_mem, mass, dw)
     dt = q.dtype
     assert dw is None or (dw.dtype == F32 and dw.numel() == 25 * DV and H * W == Lq)
     assert all(t.dtype == dt for t in (q, k_bank, v_bank, u_a, out)) and (u_b is None or u_b.dtype == dt)
-    assert workspace.numel() * 4 >= _lib.lib().rmem_gated_attn_workspace_bytes(Lq, DV, frames, keys_per_frame, nchunks)
-    assert chunks is None or (chunks.dtype == torch.int32 and chunks.numel() >= nchunks * 8)
-    assert mass is None or (mass.dtype == F32 and mass.numel() >= Lq * frames)
+    assert workspace.numel() * 4 >= nclips * _lib.lib().rmem_gated_attn_workspace_bytes(Lq, DV, frames, keys_per_frame, nchunks)
+    assert chunks is None or (chunks.dtype == torch.int32 and chunks.numel() >= nclips * nchunks * 8)
+    assert mass is None or (mass.dtype == F32 and mass.numel() >= nclips * Lq * frames)
+    assert out.numel() >= ((nclips - 1) * Lq + Lq - 1) * ldo + DV
     usplit = DV if usplit is None else usplit
     args = (_ptr(q), ldq, _ptr(k_bank), k_slot_stride, ldk, _ptr(v_bank), v_slot_stride, ldv, _ptr(chunks), nchunks, frames,
             keys_per_frame, _ptr(pe_cur), _ptr(pe_mem), Lq, DV, _ptr(u_a), ldua, _ptr(u_b), ldub, usplit, _ptr(out), ldo,
-            _ptr(mass), _ptr(dw), H, W, _ptr(workspace))
-    return Op(_fn('rmem_gated_attn', dt), args, 'rmem_gated_attn',
+            _ptr(mass), _ptr(dw), H, W, nclips, _ptr(workspace))
+    return Op(_fn('rmem_gated_attn_clips', dt), args, 'rmem_gated_attn',
               (q, k_bank, v_bank, u_a, u_b, out, workspace, chunks, pe_cur, pe_mem, mass, dw))
 
 
 def local_gated_attn(q, k, v, rel, u_a, out, workspace, *, H, W, DV, ldq, ldk, ldv, ldrel, ldua, ldo, u_b=None, ldub=0,
-                     usplit=None, dw=None) -> Op:
-    """DeAOT 15x15 local gated propagation attention; rel = relative_emb_k(q) fp32 [H*W][ldrel]."""
+                     usplit=None, dw=None, nclips=1) -> Op:
+    """DeAOT 15x15 local gated propagation attention; rel = relative_emb_k(q) fp32 [H*W][ldrel].  nclips > 1: [clip][rows][ld] operands."""
     _dev(q, k, v, rel, u_a, u_b, out, workspace, dw)
     dt = q.dtype
     assert dw is None or (dw.dtype == F32 and dw.numel() == 25 * DV)
     assert all(t.dtype == dt for t in (q, k, v, u_a, out)) and rel.dtype == F32
-    assert workspace.numel() * 4 >= _lib.lib().rmem_gated_attn_workspace_bytes(H * W, DV, 1, H * W, 8)
+    assert workspace.numel() * 4 >= nclips * _lib.lib().rmem_gated_attn_workspace_bytes(H * W, DV, 1, H * W, 8)
     usplit = DV if usplit is None else usplit
     args = (_ptr(q), ldq, _ptr(k), ldk, _ptr(v), ldv, _ptr(rel), ldrel, H, W, DV, _ptr(u_a), ldua, _ptr(u_b), ldub, usplit,
-            _ptr(out), ldo, _ptr(dw), _ptr(workspace))
-    return Op(_fn('rmem_local_gated_attn', dt), args, 'rmem_local_gated_attn', (q, k, v, rel, u_a, u_b, out, workspace, dw))
+            _ptr(out), ldo, _ptr(dw), nclips, _ptr(workspace))
+    return Op(_fn('rmem_local_gated_attn_clips', dt), args, 'rmem_local_gated_attn', (q, k, v, rel, u_a, u_b, out, workspace, dw))
 
 
 class Graph:
