@@ -73,11 +73,6 @@ class GroupRuntimeDeAOT(GroupRuntime):
     def _keys_per_chunk(self, splits: int) -> int:
         return ((self.L + splits - 1) // splits + 63) // 64 * 64
 
-    def _chunk_rows(self, slots):
-        if len({len(s) for s in slots}) != 1:
-            raise ops.RmemError('DeAOT clip groups need banks of equal length')
-        return super()._chunk_rows(slots)
-
     # ------------------------------------------------------------------ helpers
     def _clip(self, t: torch.Tensor, c: int, ld: int, col: int = 0) -> torch.Tensor:
         """Clip c's rows of a [B * L, ld] buffer, starting at column col (flat view: the ops take a pointer and a row stride)."""

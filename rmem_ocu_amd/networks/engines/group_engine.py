@@ -15,8 +15,8 @@ Covered protocols (the reference's evaluator, managers/evaluator.py:385-523):
     so from then on the clips of a group hold banks of DIFFERENT lengths and append at different frames.  The launches are laid
     out for the longest bank; shorter ones are padded with empty key-table rows (include/rmem.h: key_count 0), and bank appends
     go through the per-clip destination table (negative = no append for this clip).
-R50-DeAOTL models run through group_runtime_deaot.GroupRuntimeDeAOT (same protocol; the eviction policy's scores and visit
-counts then move on EVERY long-term update, deaot_engine.py / transformer.py:880-892; no mid-clip reference frames there).
+R50-DeAOTL models run through group_runtime_deaot.GroupRuntimeDeAOT (same protocols; the eviction policy's scores and visit
+counts then move on EVERY long-term update, deaot_engine.py / transformer.py:880-892).
 SwinB-AOTL models (cfg 5) run through the same GroupRuntime with encoder_batch.SwinBatchEncoder as the look-ahead encoder.
 Clips with > 10 objects and multi-scale / flip testing run on the per-clip engines, which are the drop-in API.
 """
@@ -147,12 +147,14 @@ class GroupEngine:
         memory, the clip's long-term schedule restarts here, ``long_memories_indexes`` keeps growing (the reference's quirk, 323),
         the eviction policy's state is reset (init_memory, transformer.py:438-443)."""
         rt, c = self.rt, clip
-        if self.deaot:
-            raise NotImplementedError('mid-clip reference frames of DeAOT clips run on the per-clip engine (DeAOTInferEngine)')
         self._resolve_pending()
         if self._side is None:
-            self._side = ClipRuntime(self.AOT.packed(), (rt.H, rt.W), 1, self.device, self.cfg.MODEL_LSTT_NUM, self.align_corners,
-                                     self.max_obj_num + 1)
+            if self.deaot:
+                from ...runtime_deaot import DeAOTRuntime as Side
+            else:
+                Side = ClipRuntime
+            self._side = Side(self.AOT.packed(), (rt.H, rt.W), 1, self.device, self.cfg.MODEL_LSTT_NUM, self.align_corners,
+                              self.max_obj_num + 1)
             self._side_img = torch.empty(3, rt.H, rt.W, dtype=F32, device=self.device)
         side = self._side
         hs, ws = int(label_u8.shape[-2]), int(label_u8.shape[-1])
@@ -170,11 +172,11 @@ class GroupEngine:
             new = rt.free[c].pop(0)
             rt.slots[c] = [new]
             for i in range(rt.NL):
-                nb = L * 256 * 2
-                ops.copy_async(rt.bank_K[i][c * rt.S + new], side.bank_K[i][side.slots[0]], nb)(s)
-                ops.copy_async(rt.bank_V[i][c * rt.S + new], side.bank_V[i][side.slots[0]], nb)(s)
-                ops.copy_async(rt.short_K[i][c * L:(c + 1) * L], side.short_K[i], nb)(s)
-                ops.copy_async(rt.short_V[i][c * L:(c + 1) * L], side.short_V[i], nb)(s)
+                nk, nv = L * rt.bank_kw * 2, L * rt.bank_vw * 2          # bytes of one bank entry's keys / values
+                ops.copy_async(rt.bank_K[i][c * rt.S + new], side.bank_K[i][side.slots[0]], nk)(s)
+                ops.copy_async(rt.bank_V[i][c * rt.S + new], side.bank_V[i][side.slots[0]], nv)(s)
+                ops.copy_async(rt.short_K[i][c * L:(c + 1) * L], side.short_K[i], nk)(s)
+                ops.copy_async(rt.short_V[i][c * L:(c + 1) * L], side.short_V[i], nv)(s)
             rt.upload_chunks(s)
         self.last_mem_step[c] = self.frame_step
         self.policies[c] = MemoryPolicy()

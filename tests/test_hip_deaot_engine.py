@@ -122,5 +122,47 @@ def test_deaot_group_engine_matches_per_clip_engines():
         print(f'deaot clip {c}: label agreement {agree:.5f}, indexes {ge.long_memories_indexes(c)}, drops {ge.drop_trace[c]}')
         assert agree > 0.995
         assert (ge.long_memories_indexes(c), ge.drop_trace[c]) == ref_traces[c]
-    with pytest.raises(NotImplementedError):
-        ge.add_reference_frame_for(0, clips[0][0][3].to(dev), gs.cur_label[0])
+
+
+def test_deaot_new_object_raises_like_the_reference():
+    """R50-DeAOTL + a new object mid-clip (managers/evaluator.py:484-508): the REFERENCE raises at the first long-term update after
+    the re-added reference frame -- DualBranchGPM.restrict_long_memories has no early return while the bank is not full
+    (layers/transformer.py:880-892), so the policy meets a bank of 2 entries and a long_memories_indexes list that kept growing
+    (aot_engine.py:322-323) -- observed by running the reference itself (RuntimeError: size of tensor a (2) must match ... (5)).
+    The per-clip engine and the clip group (gated attention with a clip dimension, banks of different lengths) reproduce that
+    failure at the same update instead of inventing a behaviour; up to there the group delivers the per-clip engine's masks."""
+    from rmem_ocu_amd import build_vos_model, get_config
+    from rmem_ocu_amd.clip_runner import GroupSlot
+    from rmem_ocu_amd.networks.engines.group_engine import GroupEngine
+    from rmem_ocu_amd.synth import make_clip
+    from rmem_ocu_amd.weights import synth_state_dict
+    from test_hip_engine import _per_clip_reference
+    dev = torch.device('cuda', 0)
+    B, n, oh, ow, objs = 3, 12, 160, 192, 2
+    clips = [make_clip(80 + c, n, 161, 193, objs) for c in range(B)]
+    new = torch.zeros(oh, ow, dtype=torch.uint8)
+    new[oh // 2:oh // 2 + oh // 4, ow // 8:ow // 8 + ow // 5] = objs + 1
+    with pytest.raises(RuntimeError):
+        _per_clip_reference(1, 8, 2, clips[1][0], clips[1][1], objs, (oh, ow), new_object=(5, new), model_name='r50_deaotl')
+    ref0 = _per_clip_reference(1, 8, 2, clips[0][0][:7], clips[0][1], objs, (oh, ow), model_name='r50_deaotl')
+    cfg = get_config('pre_vost', 'test', 'r50_deaotl')
+    cfg.FORMER_MEM_LEN, cfg.LATTER_MEM_LEN = 1, 8
+    model = build_vos_model(cfg.MODEL_VOS, cfg).cuda(0)
+    model.load_state_dict(synth_state_dict(0, model='deaot'))
+    ge = GroupEngine(model, B, 0, 2, lookahead=2)
+    gs = GroupSlot(ge, (oh, ow), dev)
+    gs.start([f.to(dev) for f, _ in clips], [m.to(dev) for _, m in clips], objs, new_objects={1: (5, new.to(dev))})
+    ge.long_term_mem_gap = 2
+    steps = 0
+    with pytest.raises(RuntimeError):
+        while not gs.done:
+            gs.step()
+            steps += 1
+            ge.long_memories_indexes(1)          # resolves the pending policy update of the frame just issued
+    ge.synchronize()
+    # frame 5 re-adds the reference frame; the long-term update at frame 7 meets a ONE-entry bank (its size-1 score vector broadcasts
+    # silently, in the reference too); the one at frame 9 meets two entries against five remembered indexes and fails -- the
+    # reference's own message is "The size of tensor a (2) must match the size of tensor b (5)"
+    assert 8 <= steps <= 10, steps
+    got = gs.labels[0, 1:6].cpu().numpy()
+    assert (got == ref0[0][:5]).mean() > 0.995

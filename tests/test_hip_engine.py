@@ -718,11 +718,11 @@ def test_long_clip_eviction_traces(name):
         assert len(ge.drop_trace[c]) == evictions
 
 
-def _per_clip_reference(former, latter, gap, frames, mask, objs, out_hw, new_object=None):
+def _per_clip_reference(former, latter, gap, frames, mask, objs, out_hw, new_object=None, model_name='r50_aotl'):
     """One clip through the drop-in per-clip engine with the evaluator's protocol (propagate -> argmax -> update, or re-add the
     frame as a reference frame when a new object's mask arrives, managers/evaluator.py:484-508): labels and the bank trace."""
     dev = torch.device('cuda', 0)
-    eng = _engine(former, latter, gap)
+    eng = _engine(former, latter, gap, model_name=model_name)
     fd = frames.to(dev)
     eng.add_reference_frame(fd[0:1], mask.to(dev), obj_nums=[objs], frame_step=0)
     labels, trace = [], []

@@ -113,3 +113,26 @@ def test_small_clip_matches_reference():
 def test_full_clip_matches_reference():
     """cfg-2 geometry (481x849 -> 31x54 tokens, larger than the 15x15 window), bank 1 + 8, gap 2."""
     _check_clip('deaot_clip_full.npz')
+
+
+def test_new_object_raises_like_the_reference():
+    """R50-DeAOTL with a mid-clip reference frame (a new object's mask, managers/evaluator.py:484-508): the reference raises at the
+    first long-term update afterwards -- DualBranchGPM.restrict_long_memories has no early return while the bank is not full
+    (layers/transformer.py:880-892) and long_memories_indexes kept growing across the bank reset (aot_engine.py:322-323); observed
+    by running the reference (tests/golden/make_golden.py gen_clip(..., inject_at=5, model_name='r50_deaotl') -> RuntimeError).  The
+    restatement reproduces the failure instead of inventing a behaviour."""
+    import pytest
+    from rmem_ocu_amd.synth import make_clip
+    from rmem_ocu_amd.weights import synth_state_dict
+    frames, mask = make_clip(31, 10, 97, 129, 2)
+    eng = D.OracleDeAOTEngine(synth_state_dict(0, model='deaot'), 1, 8, 2)
+    eng.add_reference_frame(frames[0:1], mask, 0)
+    with pytest.raises(RuntimeError):
+        for i in range(1, 10):
+            logit = eng.match_propogate_one_frame(frames[i:i + 1], (96, 128))
+            label = torch.argmax(logit, 1, keepdim=True).float()
+            m = torch.nn.functional.interpolate(label, size=eng.input_size_2d, mode='nearest')
+            if i == 4:
+                eng.add_reference_frame(frames[i:i + 1], m, i)
+            else:
+                eng.update_memory(m)
