@@ -272,8 +272,21 @@ def main():
         from rmem_ocu_amd.clip_runner import GroupSlot
         from rmem_ocu_amd.networks.engines.group_engine import GroupEngine
         C = max(1, C // G)                    # C groups of G clips each
+        # stream creation order = hardware-queue assignment (round-robin over the runtime's 4 queues): 'pairs' (default) creates
+        # main, encoder, main, encoder ...; 'mains_first' all main streams, then all encoder streams
+        order = os.environ.get('RMEM_STREAM_ORDER', 'pairs')
+        if order == 'mains_first':
+            mains = [torch.cuda.Stream(dev) for _ in range(C)]
+            encs = [torch.cuda.Stream(dev) for _ in range(C)]
+            pools = list(zip(mains, encs))
+        elif order == 'encs_first':
+            encs = [torch.cuda.Stream(dev) for _ in range(C)]
+            mains = [torch.cuda.Stream(dev) for _ in range(C)]
+            pools = list(zip(mains, encs))
+        else:
+            pools = [None] * C
         for j in range(C):
-            eng = GroupEngine(model, G, local_rank, 5, lookahead=lookahead)
+            eng = GroupEngine(model, G, local_rank, 5, lookahead=lookahead, streams=pools[j])
             eng.use_graphs = not args.no_graphs
             slots.append(GroupSlot(eng, VIDEO_HW, dev))
         inner_of = lambda s: s.engine                                            # noqa: E731

@@ -36,7 +36,7 @@ F32 = torch.float32
 
 
 class GroupEngine:
-    def __init__(self, aot_model, clips: int, gpu_id: int = 0, long_term_mem_gap: int = 9999, lookahead: int = 4):
+    def __init__(self, aot_model, clips: int, gpu_id: int = 0, long_term_mem_gap: int = 9999, lookahead: int = 4, streams=None):
         self.cfg = aot_model.cfg
         self.AOT = aot_model
         self.B = clips
@@ -48,10 +48,12 @@ class GroupEngine:
         self.max_obj_num = aot_model.max_obj_num
         self.long_term_mem_gap = long_term_mem_gap
         self.lookahead = lookahead
-        self.stream = torch.cuda.Stream(self.device)
+        # streams = (main, encoder) made by the caller: the runtime deals streams onto its (4) hardware queues in CREATION order, so a
+        # caller with several engines decides which streams share a queue by the order it creates them in (bench.py)
+        self.stream = streams[0] if streams else torch.cuda.Stream(self.device)
         # the look-ahead encoder of the NEXT batch of frames runs here, beside the propagation of the current batch (events order
         # the two: a batch is propagated after its encoder finished, a buffer is re-encoded after its last frame was decoded)
-        self.enc_stream = torch.cuda.Stream(self.device)
+        self.enc_stream = streams[1] if streams else torch.cuda.Stream(self.device)
         self._enc_done = [torch.cuda.Event(), torch.cuda.Event()]
         self._enc_free = [None, None]
         self.use_graphs = True
