@@ -15,21 +15,21 @@ cfg-3 protocol (720p, a new object arriving at frame 15), cfg 4 (1080p, 600-fram
 
 The unit of work is one propagated frame of one clip: match-propagate + argmax + memory update -- the reference's own FPS unit
 (managers/evaluator.py:399-404, 525-535) -- and `value` is always frames / second.  A *step* (--steps K, --warmup W) is one pass
-of the engine over its batch: ONE FRAME OF EVERY CLIP IN FLIGHT on the GPU (24 clips = 6 groups of 4: config.frames_per_step
+of the engine over its batch: ONE FRAME OF EVERY CLIP IN FLIGHT on the GPU (24 clips = 3 groups of 8: config.frames_per_step
 = 24), so --steps 20 times 480 frames.  (--step-unit frame restores the rounds 1-2 reading, one frame of one clip per step:
---steps 20 was then five group steps started from an idle GPU, i.e. a fill / drain transient 12-15 % below the rate the same
+--steps 20 was then five 4-clip group steps started from an idle GPU, i.e. a fill / drain transient 12-15 % below the rate the same
 build sustains, swinging +-5 % with what the window happened to contain; DESIGN.md section 6 quotes both.)
 Clips are independent; the job's clip list is handed to the ranks by rmem_ocu_amd.clip_runner.ClipFeeder -- a job-wide ticket
 queue on the job's TCPStore (the reference's shared sequence queue, managers/evaluator.py:276-295) or, with --feeder static, a
-longest-first split -- and every rank keeps 24 clips in flight as 6 groups of 4 clips that advance in lockstep on one
-GroupEngine each (one launch per layer for the 4 clips; --clips-per-group 1 selects the per-clip engines of the drop-in API),
+longest-first split -- and every rank keeps 24 clips in flight as 3 groups of 8 clips that advance in lockstep on one
+GroupEngine each (one launch per layer for the 8 clips; --clips-per-group 1 selects the per-clip engines of the drop-in API),
 every group on its own HIP stream with its own hipGraphs.  Ranks never exchange data on the hot path (weak scaling: per-GPU
 work is fixed); the only collectives are the barriers around the timed region and one final gather of (frames, seconds,
 checksum) to rank 0.  The timed region is a window of K steps per rank out of that job (the list is cyclic, a window never
 runs dry); --drain instead runs the whole job once from a non-cyclic list (value = all ranks' frames / the slowest rank's
 seconds: tail and imbalance included).  Reference frames that fall inside the timed region are executed but not counted.
 Inside a clip the ResNet-50 encoder runs 2 frames ahead of the LSTT on a side stream (frames do not depend on each other before
-the memory read): one launch per encoder layer covers 2 frames x 4 clips, every frame is still encoded exactly once
+the memory read): one launch per encoder layer covers 2 frames x 8 clips, every frame is still encoded exactly once
 (config.encoder_lookahead; config.frames_encoded_in_timed_region >= config.frames_counted_in_timed_region: no encoder work is
 pre-computed outside the window).  Inputs are resident in HBM when the timed region starts.
 
@@ -120,7 +120,7 @@ def pmc_traffic(clips_per_launch=1):
     """HBM bytes per T = 8 launch of the memory-read kernel from the newest committed PMC summary (rocprofv3 --pmc FETCH_SIZE /
     WRITE_SIZE in separate passes, gfx950 FETCH correction applied; bench.py cannot collect counters itself).  A summary is
     only valid for the kernel source it was measured on: it names attention.hip's sha256, and anything else gives None."""
-    name = {1: 'attn_pmc.json', 4: 'attn_pmc_group4.json'}.get(clips_per_launch)
+    name = {1: 'attn_pmc.json', 4: 'attn_pmc_group4.json', 8: 'attn_pmc_group8.json'}.get(clips_per_launch)
     if name is None:
         return None, None
     sha = attention_source_sha256()
@@ -163,7 +163,7 @@ def parse_args(argv=None):
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--workload', default='davis17_480p_r50_N8', choices=sorted(WORKLOADS))
     ap.add_argument('--no-graphs', action='store_true')
-    ap.add_argument('--clips-per-group', type=int, default=int(os.environ.get('RMEM_CLIPS_PER_GROUP', 4)),
+    ap.add_argument('--clips-per-group', type=int, default=int(os.environ.get('RMEM_CLIPS_PER_GROUP', 8)),
                     help='> 1: that many clips advance in lockstep on one GroupEngine (one launch per layer for the group)')
     ap.add_argument('--host-frames', action='store_true',
                     help='PCIe-inclusive variant (not the contract line): frames start as decoded uint8 RGB in pinned host memory')

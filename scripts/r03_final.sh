@@ -21,4 +21,4 @@ timeout -k 10 300 python bench.py --no-cpu-baseline --step-unit frame --steps 20
 cat $O/bench_frame_unit_20.json
 bash scripts/r03_pmc_attn.sh > $O/attn_pmc_counters.txt 2>&1
 cat $O/attn_pmc_counters.txt
-cp gpurun_out/pmc/attn_pmc_group4.json $O/ 2>/dev/null
+cp gpurun_out/pmc/attn_pmc_group8.json $O/ 2>/dev/null

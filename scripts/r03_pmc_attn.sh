@@ -1,12 +1,12 @@
 #!/bin/bash
-# PMC passes over the memory-read kernel at the bench's group shape (T = 8, 4 clips): rocprofv3 --pmc, one counter set per run
+# PMC passes over the memory-read kernel at the bench's group shape (T = 8, 8 clips per launch): rocprofv3 --pmc, one counter set per run
 # (FETCH_SIZE and WRITE_SIZE cannot share a pass: MI355X_MICROARCH.md, rocprofv3 PMC slots); prints medians, writes the JSON
 # bench.py's `roofline.traffic` reads (it names the sha256 of the attention.hip it was measured on)
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/pmc
 export TMPDIR=/tmp
 run() {  # name, counters
-  timeout -k 10 200 rocprofv3 --kernel-trace --pmc $2 --output-format csv -d gpurun_out/pmc/$1 -o p -- python3 scripts/attn_bench.py --T 8 --iters 10 > gpurun_out/pmc/$1.log 2>&1 || { echo "pass $1 failed"; tail -5 gpurun_out/pmc/$1.log; return 1; }
+  timeout -k 10 200 rocprofv3 --kernel-trace --pmc $2 --output-format csv -d gpurun_out/pmc/$1 -o p -- python3 scripts/attn_bench.py --T 8 --clips 8 --iters 10 > gpurun_out/pmc/$1.log 2>&1 || { echo "pass $1 failed"; tail -5 gpurun_out/pmc/$1.log; return 1; }
   f=$(find gpurun_out/pmc/$1 -name "*counter_collection.csv" | head -1)
   python3 - "$f" "$1" <<'PY'
 import csv, sys, collections, json, os
@@ -34,13 +34,13 @@ import json, hashlib
 f = json.load(open('gpurun_out/pmc/fetch.json'))['FETCH_SIZE']
 w = json.load(open('gpurun_out/pmc/write.json'))['WRITE_SIZE']
 sha = hashlib.sha256(open('rmem_ocu_amd/csrc/attention.hip', 'rb').read()).hexdigest()
-alg = 4 * (2 * 8 * 1674 * 256 * 2 + 2 * 1674 * 256 * 2)
+alg = 8 * (2 * 8 * 1674 * 256 * 2 + 2 * 1674 * 256 * 2)
 hbm = int((2 * f + w) * 1024)
-out = {'kernel': 'k_attn_partial<true, *> (memory read, HW=1674, T=8, 8 heads, 4 clips per launch: rmem_mem_read_attn_clips; 1792 workgroups walking 2 bank frames each)',
-       'command': 'bash scripts/r03_pmc_attn.sh  (rocprofv3 --kernel-trace --pmc FETCH_SIZE -- python3 scripts/attn_bench.py --T 8 --iters 10, and a second pass with --pmc WRITE_SIZE); medians over the launches',
+out = {'kernel': 'k_attn_partial<true, *> (memory read, HW=1674, T=8, 8 heads, 8 clips per launch: rmem_mem_read_attn_clips; 1792 workgroups walking 4 bank frames each)',
+       'command': 'bash scripts/r03_pmc_attn.sh  (rocprofv3 --kernel-trace --pmc FETCH_SIZE -- python3 scripts/attn_bench.py --T 8 --clips 8 --iters 10, and a second pass with --pmc WRITE_SIZE); medians over the launches',
        'FETCH_SIZE_KB_median': f, 'WRITE_SIZE_KB_median': w,
        'correction': 'gfx950 FETCH_SIZE counts 64 B per 128-B request on wide coalesced reads: doubled (MI355X_MICROARCH.md, HBM section); WRITE_SIZE exact',
        'hbm_bytes_per_launch': hbm, 'algorithmic_bytes_per_launch': alg, 'ratio': round(hbm / alg, 3), 'attention_hip_sha256': sha}
-json.dump(out, open('gpurun_out/pmc/attn_pmc_group4.json', 'w'), indent=1)
+json.dump(out, open('gpurun_out/pmc/attn_pmc_group8.json', 'w'), indent=1)
 print(json.dumps(out, indent=1))
 PY

@@ -666,9 +666,9 @@ def _group_vs_fixture(name, B, lookahead):
 
 @pytest.mark.parametrize('name', ['clip_full.npz', 'clip_full_fitted.npz'])
 def test_group_engine_bench_path_vs_reference_fixture(name):
-    """The path bench.py times -- GroupEngine + GroupSlot, 4 clips per group, hipGraphs, encoder look-ahead 2 on the side stream,
+    """The path bench.py times -- GroupEngine + GroupSlot, 8 clips per group, hipGraphs, encoder look-ahead 2 on the side stream,
     label-only post-processing, the LSTT chain kernels -- at BENCH GEOMETRY (480x854 -> 481x849, bank N = 8) against the
-    reference's own golden clip (managers/evaluator.py:385-441, 509-523; engines/aot_engine.py:438-465).  All four clips of the
+    reference's own golden clip (managers/evaluator.py:385-441, 509-523; engines/aot_engine.py:438-465).  All eight clips of the
     group are the fixture's clip; the reference's labels are fed back, so every frame is an independent comparison: per-frame
     labels, mask IoU, logits and the bank index trace must match the fixture with the per-clip tests' tolerances, for every clip."""
     if not os.path.exists(os.path.join(GOLDEN, name)):
@@ -676,7 +676,7 @@ def test_group_engine_bench_path_vs_reference_fixture(name):
     fitted = 'fitted' in name
     if fitted and not os.path.exists(os.path.join(GOLDEN, 'trained_delta.pt')):
         pytest.skip('fitted weights missing')
-    B = 4
+    B = 8
     g, got, samples, traces, ge = _group_vs_fixture(name, B, 2)
     assert tuple(g['meta'][3:7]) == (481, 849, 480, 854) and int(g['meta'][0] + g['meta'][1]) == 8
     assert ge.rt.chain and ge.rt.pair_attn
@@ -691,7 +691,7 @@ def test_group_engine_bench_path_vs_reference_fixture(name):
             assert err < 0.035 * ref.std() and np.mean(ious) >= 0.99 and agree >= 0.999
         else:
             assert err < 0.065 * ref.std() and agree > 0.97
-    # the four clips ran the same inputs through one launch: identical labels
+    # the eight clips ran the same inputs through one launch: identical labels
     assert all(np.array_equal(got[0], got[c]) for c in range(1, B))
 
 
