@@ -349,6 +349,9 @@ int rmem_image_to_nhwc8(const float* img_chw, void* out, int H, int W, void* str
 /* the `_images` forms of this section take `images` equally sized problems stored back to back (clip groups, encoder
  * look-ahead) as ONE launch; each image's result equals the single-image call. */
 int rmem_image_to_nhwc8_images(const float* img_chw, void* out, int images, int H, int W, void* stream);
+/* The same with the images named by a DEVICE table of `images` pointers (fp32 [3][H][W] each): the frames of several clips go into
+ * one encoder batch from wherever the caller keeps them, without a staging copy (models/aot.py:116-134: the encoder's input). */
+int rmem_image_ptrs_to_nhwc8(const float* const* img_ptrs, void* out, int images, int H, int W, void* stream);
 /* Frame ingest: decoded uint8 RGB [Hs][Ws][3] -> bicubic resize to the network size (OpenCV INTER_CUBIC semantics) ->
  * ImageNet normalise -> fp32 [3][Hd][Wd] (the engine API's input) and/or bf16 [Hd][Wd][8] (the encoder's input).
  * Replaces dataloaders/video_transforms.py:648-652 (cv2.resize) + 676-680 (normalise) on the host. */
@@ -450,6 +453,7 @@ int rmem_gn_act_dwconv5x5_nhwc_images_f16(const void* x, int images, int H, int 
 int rmem_gn_act_dwconv5x5_prestats_nhwc_images_f16(const void* x, int images, int H, int W, int C, int groups, const float* gamma, const float* beta, float eps, int act, const float* w_t, void* y, const float* stats, void* stream);
 int rmem_gn_act_dwconv5x5_nhwc_f16(const void* x, int H, int W, int C, int groups, const float* gamma, const float* beta, float eps, int act, const float* w_t, void* y, float* workspace, void* stream);
 int rmem_dwconv5x5_nhwc_f16(const void* x, const float* w_t, void* y, int H, int W, int C, void* stream);
+int rmem_image_ptrs_to_nhwc8_f16(const float* const* img_ptrs, void* out, int images, int H, int W, void* stream);
 int rmem_image_to_nhwc8_f16(const float* img_chw, void* out, int H, int W, void* stream);
 int rmem_image_to_nhwc8_images_f16(const float* img_chw, void* out, int images, int H, int W, void* stream);
 int rmem_ingest_rgb8_f16(const unsigned char* rgb_hwc, int Hs, int Ws, int Hd, int Wd, float* out_chw, void* out_nhwc8, void* stream);

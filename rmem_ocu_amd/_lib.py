@@ -85,6 +85,7 @@ SIGNATURES = {
     'rmem_dwconv5x5_nhwc': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     'rmem_image_to_nhwc8': (_i, [_vp, _vp, _i, _i, _vp]),
     'rmem_image_to_nhwc8_images': (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    'rmem_image_ptrs_to_nhwc8': (_i, [_vp, _vp, _i, _i, _i, _vp]),
     'rmem_ingest_rgb8': (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     'rmem_maxpool3x3s2_nhwc': (_i, [_vp, _vp, _i, _i, _i, _vp]),
     'rmem_maxpool3x3s2_nhwc_images': (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
@@ -121,7 +122,7 @@ F16_TWINS = ('rmem_conv2d_nhwc', 'rmem_mem_read_attn', 'rmem_mem_read_attn_clips
              'rmem_window_attn', 'rmem_window_attn_images', 'rmem_patch_merge_ln_images', 'rmem_add16', 'rmem_add16_grouped', 'rmem_layernorm256_pair', 'rmem_lstt_chain_a', 'rmem_lstt_chain_b', 'rmem_lstt_chain_c', 'rmem_conv1x1_dual_nhwc', 'rmem_linear_grouped',
              'rmem_groupnorm_nhwc', 'rmem_groupnorm_f32_nhwc', 'rmem_groupnorm_nhwc_images', 'rmem_groupnorm_head_nhwc_images',
              'rmem_gn_act_dwconv5x5_nhwc_images', 'rmem_gn_act_dwconv5x5_prestats_nhwc_images', 'rmem_gn_act_dwconv5x5_nhwc', 'rmem_dwconv5x5_nhwc', 'rmem_image_to_nhwc8',
-             'rmem_image_to_nhwc8_images', 'rmem_ingest_rgb8', 'rmem_maxpool3x3s2_nhwc', 'rmem_maxpool3x3s2_nhwc_images', 'rmem_bilinear_nhwc',
+             'rmem_image_to_nhwc8_images', 'rmem_image_ptrs_to_nhwc8', 'rmem_ingest_rgb8', 'rmem_maxpool3x3s2_nhwc', 'rmem_maxpool3x3s2_nhwc_images', 'rmem_bilinear_nhwc',
              'rmem_bilinear_nhwc_images', 'rmem_label_to_onehot16', 'rmem_label_to_onehot16_images', 'rmem_gated_attn', 'rmem_local_gated_attn', 'rmem_gated_attn_clips', 'rmem_local_gated_attn_clips')
 SIGNATURES.update({n + '_f16': SIGNATURES[n] for n in F16_TWINS})
 

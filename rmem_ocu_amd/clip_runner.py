@@ -270,6 +270,8 @@ class GroupSlot:
         propagated, the new label is laid over the prediction and the frame is re-added as a reference frame for that clip."""
         assert len(frames) == self.B and len({int(f.shape[0]) for f in frames}) == 1
         n = int(frames[0].shape[0])
+        if getattr(self, '_frames_by_pointer', False):
+            self.engine.enc_stream.synchronize()  # queued encoder launches read the previous clips' frames in place: let go of them after
         self.frames = list(frames)
         self.host_u8 = frames[0].dtype == torch.uint8
         self.new_objects = dict(new_objects or {})
@@ -278,6 +280,7 @@ class GroupSlot:
         if self.labels is None or self.labels.shape[1] < n:
             self.labels = torch.zeros(self.B, n, self.out_hw[0], self.out_hw[1], dtype=torch.uint8, device=self.device)
         eng = self.engine
+        self._frames_by_pointer = not self.host_u8 and eng.lookahead > 1
         eng.restart_engine()
         eng.long_term_mem_gap = max(int(round(n / 30)), 5)      # evaluator.py:330-335
         H, W = int(first_masks[0].shape[-2]), int(first_masks[0].shape[-1])
@@ -316,7 +319,15 @@ class GroupSlot:
                 hs, ws = int(self.frames[0].shape[1]), int(self.frames[0].shape[2])
                 self._stage_la = torch.empty(eng.lookahead * self.B, hs, ws, 3, dtype=torch.uint8, device=self.device)
             stage = self._stage_la
-        self._fill_encoder_inputs(eng.encode_inputs(buf), i, m, stream=eng.enc_stream, stage=stage)
+        enc = eng.rt.enc_bufs[buf]
+        if self.host_u8:
+            enc.point_at_img_in(eng.enc_stream.cuda_stream)
+            self._fill_encoder_inputs(eng.encode_inputs(buf), i, m, stream=eng.enc_stream, stage=stage)
+        else:
+            # the encoder reads the frames where the clips are (device table of pointers, row k * B + c = frame i + k of clip c): no
+            # staging copy; rows beyond the clip's end name its last frame again (encoded, never used)
+            last = self.frames[0].shape[0] - 1
+            enc.set_frames([self.frames[c][min(i + k, last)] for k in range(eng.lookahead) for c in range(self.B)], eng.enc_stream.cuda_stream)
         eng.encode_ahead(buf)
 
     def _fill_encoder_inputs(self, dst: torch.Tensor, i: int, m: int, stream=None, stage=None):

@@ -27,6 +27,20 @@ __global__ __launch_bounds__(256) void k_image_to_nhwc8(const float* img, e16* o
   reinterpret_cast<e16x8*>(out)[i] = o;
 }
 
+// the same with one source pointer per image (a device table): frames stay where the caller keeps its clips
+__global__ __launch_bounds__(256) void k_image_ptrs_to_nhwc8(const float* const* imgs, e16* out, int H, int W) {
+  const long n = (long)H * W;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float* img = imgs[blockIdx.y];        // blockIdx.y = image of a batch
+  out += (long)blockIdx.y * 8 * n;
+  e16x8 o = {0, 0, 0, 0, 0, 0, 0, 0};
+  o[0] = (e16)img[i];
+  o[1] = (e16)img[n + i];
+  o[2] = (e16)img[2 * n + i];
+  reinterpret_cast<e16x8*>(out)[i] = o;
+}
+
 __global__ __launch_bounds__(256) void k_maxpool3s2(const e16* x, e16* y, int H, int W, int C, int Ho, int Wo) {
   const int vpr = C / 8;
   const long total = (long)Ho * Wo * vpr;
@@ -534,6 +548,12 @@ extern "C" int RMEM_API(rmem_image_to_nhwc8_images)(const float* img_chw, void* 
   RMEM_REQUIRE(img_chw && out && images >= 1 && H > 0 && W > 0, "rmem_image_to_nhwc8: bad argument");
   hipLaunchKernelGGL(k_image_to_nhwc8, dim3(nblk((long)H * W), images), dim3(256), 0, (hipStream_t)stream, img_chw, (e16*)out, H, W);
   return rmem_check_launch("rmem_image_to_nhwc8");
+}
+
+extern "C" int RMEM_API(rmem_image_ptrs_to_nhwc8)(const float* const* img_ptrs, void* out, int images, int H, int W, void* stream) {
+  RMEM_REQUIRE(img_ptrs && out && images >= 1 && H > 0 && W > 0, "rmem_image_ptrs_to_nhwc8: bad argument");
+  hipLaunchKernelGGL(k_image_ptrs_to_nhwc8, dim3(nblk((long)H * W), images), dim3(256), 0, (hipStream_t)stream, img_ptrs, (e16*)out, H, W);
+  return rmem_check_launch("rmem_image_ptrs_to_nhwc8");
 }
 
 extern "C" int RMEM_API(rmem_image_to_nhwc8)(const float* img_chw, void* out, int H, int W, void* stream) {

@@ -18,7 +18,37 @@ from .pack import R50_BLOCKS, R50_STRIDES
 from .runtime import BF16, F32, _out
 
 
-class BatchEncoder:
+class _PtrInput:
+    """Input side of the batch encoders: the frames are named by a device table of pointers (one fp32 [3, H, W] frame each,
+    wherever the caller keeps its clips) that set_frames() re-sends before a launch; img_in remains as a staging buffer for
+    callers that copy their frames in (point_at_img_in: the default state)."""
+
+    def _init_ptrs(self, B: int, device):
+        self.img_ptrs = torch.tensor([self.img_in[i].data_ptr() for i in range(B)], dtype=torch.int64).to(device)
+        self._ptr_ring = ops.PinnedRing(4, (B,), torch.int64, device)
+        self._ptrs_set = False              # True: the table names caller-owned frames (set_frames), not img_in
+
+    def _input_op(self):
+        return ops.image_ptrs_to_nhwc8(self.img_ptrs, self.img8, H=self.H, W=self.W, images=self.B)
+
+    def set_frames(self, frames, stream: int):
+        """frames: B fp32 [3, H, W] contiguous device tensors (kept alive by the caller until the encoder launch has run)."""
+        assert len(frames) == self.B
+        host = self._ptr_ring.next()
+        for i, f in enumerate(frames):
+            assert f.dtype == F32 and f.is_contiguous() and f.numel() == 3 * self.H * self.W
+            host[i] = f.data_ptr()
+        self._ptr_ring.upload(self.img_ptrs, self.B * 8, stream)
+        self._ptrs_set = True
+
+    def point_at_img_in(self, stream: int):
+        """the table names the rows of img_in again (callers that fill img_in themselves)"""
+        if self._ptrs_set:
+            self.set_frames([self.img_in[i] for i in range(self.B)], stream)
+            self._ptrs_set = False
+
+
+class BatchEncoder(_PtrInput):
     def __init__(self, P: Dict[str, torch.Tensor], in_hw: Tuple[int, int], batch: int, device):
         if 'pe.w' in P:
             raise ops.RmemError('BatchEncoder covers the ResNet-50 encoder')
@@ -34,6 +64,7 @@ class BatchEncoder:
         dt16 = P['stem.w'].dtype
         e = lambda *shape, dt=None: torch.empty(*shape, dtype=dt or dt16, device=device)  # noqa: E731
         self.img_in = e(B, 3, H, W, dt=F32)
+        self._init_ptrs(B, device)
         self.img8 = e(B, H * W, 8)
         self.stem = e(B, self.H2 * self.W2, 64)
         self.pool = e(B, M4, 64)
@@ -54,7 +85,7 @@ class BatchEncoder:
         if self._prog is not None:
             return self._prog
         P, B, o = self.P, self.B, []
-        o.append(ops.image_to_nhwc8(self.img_in, self.img8, H=self.H, W=self.W, images=B))
+        o.append(self._input_op())
         o.append(self._conv(self.img8, P['stem.w'], P['stem.b'], self.stem, H=self.H, W=self.W, Cin=8, Cout=64, KH=7, KW=7, stride=2,
                             pad=3, relu=True))
         o.append(ops.maxpool3x3s2(self.stem, self.pool, H=self.H2, W=self.W2, C=64, images=B))
@@ -83,7 +114,7 @@ class BatchEncoder:
         return o
 
 
-class SwinBatchEncoder:
+class SwinBatchEncoder(_PtrInput):
     """Swin-B (cfg 5; encoders/swin/swin_transformer.py:500-716) over B frames: the look-ahead counterpart of
     ClipRuntime._prog_encode_swin.  One 720x1280 frame leaves only 3600 tokens for the 18 blocks of stage 3, so its linears are
     GEMMs of 3600 rows and its LayerNorms launches of 3.7 MB; with B frames stacked as rows [frame][token] every linear and
@@ -107,6 +138,7 @@ class SwinBatchEncoder:
         dt16 = P['proj.w'].dtype
         e = lambda *shape, dt=None: torch.empty(*shape, dtype=dt or dt16, device=device)  # noqa: E731
         self.img_in = e(B, 3, H, W, dt=F32)
+        self._init_ptrs(B, device)
         self.img8 = e(B, H * W, 8)
         self.sx = e(B * M4, 128, dt=F32)            # fp32 residual stream of the current stage
         self.sln = e(B * M4, 128)
@@ -126,7 +158,7 @@ class SwinBatchEncoder:
             return self._prog
         from .pack import SWIN_DEPTHS, SWIN_HEADS
         P, B, o = self.P, self.B, []
-        o.append(ops.image_to_nhwc8(self.img_in, self.img8, H=self.H, W=self.W, images=B))
+        o.append(self._input_op())
         h, w, C = self.H4, self.W4, 128
         x = self.sx.view(-1)
         o.append(ops.conv2d(self.img8, P['pe.w'], P['pe.b'], x[: B * h * w * C], H=self.H, W=self.W, Cin=8, Cout=C, KH=4, KW=4, stride=4,

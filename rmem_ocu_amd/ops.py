@@ -372,6 +372,14 @@ def image_to_nhwc8(img, out, *, H, W, images=1) -> Op:
     return Op(_fn('rmem_image_to_nhwc8_images', dt), (_ptr(img), _ptr(out), images, H, W), 'rmem_image_to_nhwc8', (img, out))
 
 
+def image_ptrs_to_nhwc8(ptr_table, out, *, H, W, images) -> Op:
+    """device int64 table of `images` pointers to fp32 [3, H, W] frames -> 16-bit [images, H*W, 8]"""
+    _dev(ptr_table, out)
+    dt = out.dtype
+    assert ptr_table.dtype == torch.int64 and ptr_table.numel() >= images and out.is_contiguous() and out.numel() >= images * H * W * 8
+    return Op(_fn('rmem_image_ptrs_to_nhwc8', dt), (_ptr(ptr_table), _ptr(out), images, H, W), 'rmem_image_ptrs_to_nhwc8', (ptr_table, out))
+
+
 def ingest_rgb8(rgb, *, Hs, Ws, Hd, Wd, out_chw=None, out_nhwc8=None) -> Op:
     """uint8 RGB [Hs, Ws, 3] device tensor -> resized, normalised fp32 [3, Hd, Wd] and/or bf16 [Hd*Wd, 8]."""
     _dev(rgb, out_chw, out_nhwc8)
