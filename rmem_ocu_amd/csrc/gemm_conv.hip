@@ -54,6 +54,8 @@ struct ConvParams {
   long x2_elems;
   int fast_ok;           // 1: Cin % 64 == 0, <= 32 taps, x and w below 2 GB: scalar k-walk + hardware zero fill; 2: row-run form
   int xcd_ny;            // > 0: 1-D grid in XCD-aware order, xcd_ny = column tiles per row tile (see tile_of_block)
+  int debug;             // timing experiments only (RMEM_GEMM_DEBUG; results are then wrong by construction): 1 = no MFMA, 2 = no DMA
+                         // after the first k-step, 4 = no epilogue (nothing is stored), 8 = no global stores / residual reads in it
 };
 
 // Which output tile a workgroup owns.  Plain 2-D grid (xcd_ny == 0): (blockIdx.x, blockIdx.y) -- all row tiles of column tile 0 are
@@ -571,7 +573,7 @@ __device__ __forceinline__ void conv_gemm_dma_body(const ConvParams& p, const in
   for (int kt = kt0; kt < kt1; ++kt) {
     if (ST == 1) {                                    // single buffer: other resident workgroups hide the load
       if (kt > kt0) __builtin_amdgcn_s_barrier();     // everyone finished reading tile kt-1
-      issue(kt, 0);
+      if (!(p.debug & 2) || kt == kt0) issue(kt, 0);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     } else {
@@ -586,7 +588,7 @@ __device__ __forceinline__ void conv_gemm_dma_body(const ConvParams& p, const in
       }
       __builtin_amdgcn_s_barrier();                     // everyone's pieces of tile kt landed; everyone finished reading tile kt-1
       const int nxt = stage == 0 ? ST - 1 : stage - 1;  // slot of tile kt+ST-1 == slot of tile kt-1
-      if (kt + ST - 1 < kt1) issue(kt + ST - 1, nxt);
+      if (kt + ST - 1 < kt1 && !(p.debug & 2)) issue(kt + ST - 1, nxt);
     }
     const e16* As = reinterpret_cast<const e16*>(smem + stage * STAGE_BYTES);
     const e16* Bs = As + BM * BK;
@@ -597,15 +599,29 @@ __device__ __forceinline__ void conv_gemm_dma_body(const ConvParams& p, const in
       for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const e16x8*>(&As[swz(wm * (BM / 2) + i * 16 + fr, 4 * ks + fc)]);
 #pragma unroll
       for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const e16x8*>(&Bs[swz(wn * (BN / 2) + j * 16 + fr, 4 * ks + fc)]);
+      if (p.debug & 1) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) asm volatile("" :: "v"(af[i]));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) asm volatile("" :: "v"(bfr[j]));
+      } else {
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
           acc[i][j] = RMEM_MFMA_16x16x32(af[i], bfr[j], acc[i][j], 0, 0, 0);
+      }
     }
     stage = stage == ST - 1 ? 0 : stage + 1;
   }
   __syncthreads();                                     // all DMA drained (vmcnt(0) above) and all fragment reads done
+  if (p.debug & 4) {                                   // timing experiment: keep the accumulators alive, store nothing
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) asm volatile("" :: "v"(acc[i][j]));
+    return;
+  }
 
   // epilogue through LDS, 32 output rows per pass: pass -> wave row wm = pass / (TM/2), its tiles i = 2*(pass % (TM/2)), +1
   float* Cs = reinterpret_cast<float*>(smem);
@@ -631,7 +647,9 @@ __device__ __forceinline__ void conv_gemm_dma_body(const ConvParams& p, const in
       const float* c = Cs + row * CP + cv * 8;
       const f32x4 c0 = *reinterpret_cast<const f32x4*>(c), c1 = *reinterpret_cast<const f32x4*>(c + 4);
       float v[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
-      if (SPLITK) {
+      if (p.debug & 8) {
+        asm volatile("" :: "v"(v[0]), "v"(v[7]));
+      } else if (SPLITK) {
         float* s = p.slabs + ((long)zslice * p.M + m) * p.Cout + n;
         *reinterpret_cast<f32x4*>(s) = c0;
         *reinterpret_cast<f32x4*>(s + 4) = c1;
@@ -831,6 +849,7 @@ static int conv_setup(const rmem_conv_desc* d, const void* x, const void* w, con
   p.x = (const e16*)x; p.w = (const e16*)w; p.bias = bias; p.res = residual; p.y = y; p.y2 = (e16*)y2;
   p.slabs = nullptr;
   p.xcd_ny = 0;
+  { static const int dbg = getenv("RMEM_GEMM_DEBUG") ? atoi(getenv("RMEM_GEMM_DEBUG")) : 0; p.debug = dbg; }
   p.x2 = nullptr; p.H2 = p.W2 = p.Cin2 = p.stride2 = 0; p.x2_elems = 0;
   p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Ho = Ho; p.Wo = Wo; p.Cout = d->Cout;
   p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad;
