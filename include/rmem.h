@@ -398,6 +398,12 @@ int rmem_split_label(const float* label, int start_id, int end_id, float* out, l
 int rmem_soft_logit_aggregate(const float* const* logits_nchw, int n_engines, int num_classes, int objs_per_engine, int H, int W,
                               float* out_nchw, void* stream);
 
+/* fp32 planes [planes][Hs][Ws] -> optionally mirrored along W (utils/image.py:109-113 flip_tensor(dim 3)) -> nearest-neighbour resize
+ * (F.interpolate(mode='nearest') index rule: src = floor(dst * in / out)) to [planes][Hd][Wd]: the frames and label maps the
+ * evaluator hands to its flipped-augmentation engines, in the reference's order flip, then resize (managers/evaluator.py:342-355,
+ * 490-522). */
+int rmem_resize_nearest_flip_f32(const float* src, int planes, int Hs, int Ws, float* dst, int Hd, int Wd, int flip_w, void* stream);
+
 /* Test-time-augmentation merge: softmax of each augmentation's NCHW logits (read horizontally flipped where flips[a] != 0),
  * mean over the <= 8 augmentations (scales x flips), argmax; writes any of uint8 labels, fp32 labels, NCHW mean probabilities.
  * logits_nchw / flips are HOST arrays of n_aug entries.  Replaces managers/evaluator.py:427-441 (flip / multi-scale TTA). */

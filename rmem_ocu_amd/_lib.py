@@ -95,6 +95,7 @@ SIGNATURES = {
     'rmem_label_to_onehot16': (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     'rmem_label_to_onehot16_images': (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     'rmem_evict_scores': (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp]),
+    'rmem_resize_nearest_flip_f32': (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _vp]),
     'rmem_tta_merge': (_i, [C.POINTER(_vp), C.POINTER(_i), _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     'rmem_mask_iou_counts': (_i, [_vp, _vp, _ll, _i, _i, _vp, _vp]),
     'rmem_split_label': (_i, [_vp, _i, _i, _vp, _ll, _vp]),

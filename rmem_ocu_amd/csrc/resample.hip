@@ -298,6 +298,22 @@ __global__ __launch_bounds__(256) void k_logits_post(const float* lg, int ldl, i
   if (label_f32) label_f32[i] = (float)arg;
 }
 
+// planes [C][Hs][Ws] fp32 -> (optionally mirrored along W first: utils/image.py:109-113 flip_tensor(dim 3)) -> nearest resize
+// (F.interpolate(mode='nearest') index rule) to [C][Hd][Wd]: the order of managers/evaluator.py:490-522 (flip_tensor(pred_label, 3),
+// then F.interpolate to the engine's input size) -- the flipped-augmentation engines of the evaluator get their frames and label
+// maps through this instead of ATen flip / interpolate
+__global__ __launch_bounds__(256) void k_resize_nearest_flip(const float* src, int Hs, int Ws, float* dst, int Hd, int Wd, int flip) {
+  const long total = (long)Hd * Wd;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  src += (long)blockIdx.y * Hs * Ws;          // blockIdx.y = plane
+  dst += (long)blockIdx.y * total;
+  const int y = (int)(i / Wd), x = (int)(i - (long)y * Wd);
+  const int sy = min((int)floorf((float)y * ((float)Hs / (float)Hd)), Hs - 1);
+  const int sx = min((int)floorf((float)x * ((float)Ws / (float)Wd)), Ws - 1);
+  dst[i] = src[(long)sy * Ws + (flip ? Ws - 1 - sx : sx)];      // resize(flip(src)): column sx of the mirrored source
+}
+
 // label [Hs][Ws] (uint8 or fp32) -> nearest resize to [Hd][Wd] -> one-hot NHWC16 e16
 // channels 0..ncls-1 one-hot (channel 0 cleared where label == 255), channel ncls = ignore (label == 255)
 __global__ __launch_bounds__(256) void k_label_onehot(const void* lab, int lab_f32, int Hs, int Ws, int Hd, int Wd, int ncls, e16* out) {
@@ -623,6 +639,14 @@ extern "C" int RMEM_API(rmem_label_to_onehot16_images)(const void* label, int la
 extern "C" int RMEM_API(rmem_label_to_onehot16)(const void* label, int label_is_f32, int Hs, int Ws, int Hd, int Wd, int num_classes, void* out, void* stream) {
   return RMEM_API(rmem_label_to_onehot16_images)(label, label_is_f32, 1, Hs, Ws, Hd, Wd, num_classes, out, stream);
 }
+
+#ifndef RMEM_F16
+extern "C" int rmem_resize_nearest_flip_f32(const float* src, int planes, int Hs, int Ws, float* dst, int Hd, int Wd, int flip_w, void* stream) {
+  RMEM_REQUIRE(src && dst && planes >= 1 && Hs > 0 && Ws > 0 && Hd > 0 && Wd > 0, "rmem_resize_nearest_flip_f32: bad argument");
+  hipLaunchKernelGGL(k_resize_nearest_flip, dim3(nblk((long)Hd * Wd), planes), dim3(256), 0, (hipStream_t)stream, src, Hs, Ws, dst, Hd, Wd, flip_w);
+  return rmem_check_launch("rmem_resize_nearest_flip_f32");
+}
+#endif
 
 #ifndef RMEM_F16
 extern "C" int rmem_evict_scores(const float* logits_nhwc, int ldl, int num_classes, int keep_max_id, int Hi, int Wi, int He, int We,

@@ -17,7 +17,6 @@ from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
-import torch.nn.functional as F
 
 from . import _lib, ops
 from .networks.engines import build_engine
@@ -111,17 +110,23 @@ class SequenceEvaluator:
         aflips = [fl for _, fl in augs]
         outs: List[torch.Tensor] = []
 
+        def resized(src, size, fl):
+            """(mirror along W for a flipped augmentation, then) nearest resize to `size` on the device: rmem_resize_nearest_flip_f32"""
+            dst = torch.empty(*src.shape[:-2], int(size[0]), int(size[1]), dtype=torch.float32, device=src.device)
+            ops.run(ops.resize_nearest_flip(src.contiguous(), dst, flip=fl))
+            return dst
+
         def frame(a, t):
             si, fl = augs[a]
             img = per_scale[si][t:t + 1]
-            return img.flip(3) if fl else img
+            return resized(img, img.shape[-2:], True) if fl else img
 
         for a, (si, fl) in enumerate(augs):
             e = self._engine(a)
             e.restart_engine()
             e.long_term_mem_gap = gap
-            lab = F.interpolate(labels[0], size=tuple(per_scale[si].shape[2:]), mode='nearest')
-            e.add_reference_frame(frame(a, 0), lab.flip(3) if fl else lab, obj_nums=[int(labels[0].max().item())], frame_step=0)
+            lab = resized(labels[0], per_scale[si].shape[2:], fl)
+            e.add_reference_frame(frame(a, 0), lab, obj_nums=[int(labels[0].max().item())], frame_step=0)
         for t in range(1, n):
             logits = [self.engines[a].match_propogate_one_frame(frame(a, t), output_size=out_hw) for a in range(len(augs))]
             label_u8, label_f, _ = tta_merge(logits, aflips)
@@ -132,7 +137,7 @@ class SequenceEvaluator:
                 label_u8 = label_f[0, 0].to(torch.uint8)
                 nobj = [int(label_f.max().item())]
                 for a, (si, fl) in enumerate(augs):
-                    lab = F.interpolate(label_f.flip(3) if fl else label_f, size=self.engines[a].input_size_2d, mode='nearest')
+                    lab = resized(label_f, self.engines[a].input_size_2d, fl)
                     self.engines[a].add_reference_frame(frame(a, t), lab, obj_nums=nobj, frame_step=t)
             else:
                 for a, (si, fl) in enumerate(augs):
@@ -145,7 +150,6 @@ class SequenceEvaluator:
                         ops.copy_async(self._lab_u8, label_u8, label_u8.numel())(torch.cuda.current_stream(label_u8.device).cuda_stream)
                         e.update_memory_from_label_u8(self._lab_u8)
                     else:
-                        lab = F.interpolate(label_f.flip(3) if fl else label_f, size=e.input_size_2d, mode='nearest')
-                        e.update_memory(lab)
+                        e.update_memory(resized(label_f, e.input_size_2d, fl))
             outs.append(label_u8)
         return outs

@@ -426,6 +426,17 @@ def label_to_onehot16(label, out, *, Hs, Ws, Hd, Wd, ncls=11, images=1) -> Op:
     return Op(_fn('rmem_label_to_onehot16_images', dt), args, 'rmem_label_to_onehot16', (label, out))
 
 
+def resize_nearest_flip(src, dst, *, flip: bool) -> Op:
+    """fp32 [..., Hs, Ws] -> nearest resize to dst's [..., Hd, Wd] (same leading planes), optionally flipped along W."""
+    _dev(src, dst)
+    assert src.dtype == F32 and dst.dtype == F32 and src.is_contiguous() and dst.is_contiguous()
+    Hs, Ws, Hd, Wd = int(src.shape[-2]), int(src.shape[-1]), int(dst.shape[-2]), int(dst.shape[-1])
+    planes = src.numel() // (Hs * Ws)
+    assert dst.numel() == planes * Hd * Wd
+    return Op(_lib.lib().rmem_resize_nearest_flip_f32, (_ptr(src), planes, Hs, Ws, _ptr(dst), Hd, Wd, int(flip)), 'rmem_resize_nearest_flip_f32',
+              (src, dst))
+
+
 def evict_scores(logits, mass, scores, *, ldl, nc, keep, Hi, Wi, He, We, T) -> Op:
     _dev(logits, mass, scores)
     assert scores.dtype == F32 and scores.numel() >= 32 + 64 * 32

@@ -1176,3 +1176,17 @@ def test_tta_merge_vs_reference_fixture(dev):
         tie = (p2[-1] - p2[-2]) < 1e-6
         assert ((label.cpu().numpy() == ref) | tie).all()
         assert torch.equal(label.float(), label_f[0, 0])
+
+
+def test_resize_nearest_flip(dev):
+    """rmem_resize_nearest_flip_f32 = F.interpolate(flip_tensor(x, 3), size, mode='nearest') (managers/evaluator.py:490-522: flip first,
+    then resize), bit for bit (it only moves values), for label maps (down / up, ragged ratios) and 3-plane frames (same size)."""
+    from rmem_ocu_amd import ops
+    for (c, hs, ws, hd, wd) in [(1, 480, 854, 481, 849), (1, 160, 192, 161, 193), (1, 481, 849, 480, 854), (3, 161, 193, 161, 193), (1, 37, 53, 90, 17)]:
+        x = (seeded(200 + hs, (1, c, hs, ws)) * 5).round()
+        for fl in (False, True):
+            dst = torch.full((1, c, hd, wd), -7.0, dtype=F32, device=dev)
+            ops.run(ops.resize_nearest_flip(x.to(dev), dst, flip=fl))
+            torch.cuda.synchronize()
+            ref = F.interpolate(x.flip(3) if fl else x, size=(hd, wd), mode='nearest')
+            assert torch.equal(dst.cpu(), ref), (c, hs, ws, hd, wd, fl)
