@@ -125,7 +125,11 @@ class SequenceEvaluator:
             e = self._engine(a)
             e.restart_engine()
             e.long_term_mem_gap = gap
-            lab = resized(labels[0], per_scale[si].shape[2:], fl)
+            # the first frame's label is resized THEN mirrored (the data pipeline flips the resized sample,
+            # dataloaders/video_transforms.py MultiRestrictSize), later labels are mirrored then resized (evaluator.py:490-522)
+            lab = resized(labels[0], per_scale[si].shape[2:], False)
+            if fl:
+                lab = resized(lab, lab.shape[-2:], True)
             e.add_reference_frame(frame(a, 0), lab, obj_nums=[int(labels[0].max().item())], frame_step=0)
         for t in range(1, n):
             logits = [self.engines[a].match_propogate_one_frame(frame(a, t), output_size=out_hw) for a in range(len(augs))]
