@@ -30,8 +30,9 @@ runs dry); --drain instead runs the whole job once from a non-cyclic list (value
 seconds: tail and imbalance included).  Reference frames that fall inside the timed region are executed but not counted.
 Inside a clip the ResNet-50 encoder runs 2 frames ahead of the LSTT on a side stream (frames do not depend on each other before
 the memory read): one launch per encoder layer covers 2 frames x 8 clips, every frame is still encoded exactly once
-(config.encoder_lookahead; config.frames_encoded_in_timed_region >= config.frames_counted_in_timed_region: no encoder work is
-pre-computed outside the window).  Inputs are resident in HBM when the timed region starts.
+(config.encoder_lookahead; config.frames_encoded_in_timed_region counts the frames whose encoder was enqueued inside the window:
+it equals config.frames_counted_in_timed_region up to one look-ahead batch per group -- the encoder pipeline is equally far
+ahead at both ends of the window, so no encoder work is moved out of it).  Inputs are resident in HBM when the timed region starts.
 
 The single JSON line also carries
   roofline     -- the dominant kernel (the long-term memory read, rmem_mem_read_attn_clips): AFTER the timed region (so

@@ -769,7 +769,7 @@ void launch(const ConvParams& p, bool is1x1, int splits, hipStream_t s) {
   }
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int MODE = 1>
 void launch_big(const ConvParams& pin, bool is1x1, int st, hipStream_t s) {
   dim3 grid((pin.M + BM - 1) / BM, (pin.Cout + BN - 1) / BN, 1);
   ConvParams p = pin;
@@ -780,25 +780,25 @@ void launch_big(const ConvParams& pin, bool is1x1, int st, hipStream_t s) {
   }
   if constexpr (BM == 128 && BN == 128) {
     if (st == 5) {        // 160 KB of LDS: one workgroup per CU with four k-steps (128 KB) in flight
-      if (is1x1) hipLaunchKernelGGL((k_conv_gemm_dma_big<true, 5, BM, BN, 1>), grid, dim3(256), 0, s, p);
-      else hipLaunchKernelGGL((k_conv_gemm_dma_big<false, 5, BM, BN, 1>), grid, dim3(256), 0, s, p);
+      if (is1x1) hipLaunchKernelGGL((k_conv_gemm_dma_big<true, 5, BM, BN, MODE>), grid, dim3(256), 0, s, p);
+      else hipLaunchKernelGGL((k_conv_gemm_dma_big<false, 5, BM, BN, MODE>), grid, dim3(256), 0, s, p);
       return;
     }
     if (st == 4) {
-      if (is1x1) hipLaunchKernelGGL((k_conv_gemm_dma_big<true, 4, BM, BN, 1>), grid, dim3(256), 0, s, p);
-      else hipLaunchKernelGGL((k_conv_gemm_dma_big<false, 4, BM, BN, 1>), grid, dim3(256), 0, s, p);
+      if (is1x1) hipLaunchKernelGGL((k_conv_gemm_dma_big<true, 4, BM, BN, MODE>), grid, dim3(256), 0, s, p);
+      else hipLaunchKernelGGL((k_conv_gemm_dma_big<false, 4, BM, BN, MODE>), grid, dim3(256), 0, s, p);
       return;
     }
   }
   if (st == 3) {
-    if (is1x1) hipLaunchKernelGGL((k_conv_gemm_dma_big<true, 3, BM, BN, 1>), grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((k_conv_gemm_dma_big<false, 3, BM, BN, 1>), grid, dim3(256), 0, s, p);
+    if (is1x1) hipLaunchKernelGGL((k_conv_gemm_dma_big<true, 3, BM, BN, MODE>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((k_conv_gemm_dma_big<false, 3, BM, BN, MODE>), grid, dim3(256), 0, s, p);
   } else if (st == 2) {
-    if (is1x1) hipLaunchKernelGGL((k_conv_gemm_dma_big<true, 2, BM, BN, 1>), grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((k_conv_gemm_dma_big<false, 2, BM, BN, 1>), grid, dim3(256), 0, s, p);
+    if (is1x1) hipLaunchKernelGGL((k_conv_gemm_dma_big<true, 2, BM, BN, MODE>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((k_conv_gemm_dma_big<false, 2, BM, BN, MODE>), grid, dim3(256), 0, s, p);
   } else {
-    if (is1x1) hipLaunchKernelGGL((k_conv_gemm_dma_big<true, 1, BM, BN, 1>), grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((k_conv_gemm_dma_big<false, 1, BM, BN, 1>), grid, dim3(256), 0, s, p);
+    if (is1x1) hipLaunchKernelGGL((k_conv_gemm_dma_big<true, 1, BM, BN, MODE>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((k_conv_gemm_dma_big<false, 1, BM, BN, MODE>), grid, dim3(256), 0, s, p);
   }
 }
 
@@ -920,6 +920,19 @@ extern "C" int RMEM_API(rmem_conv2d_nhwc)(const rmem_conv_desc* d, const void* x
       const long t128 = (long)((p.M + 127) / 128) * ((p.Cout + 127) / 128);
       static const int deep_st = getenv("RMEM_GEMM_BIG_DEEP_ST") ? atoi(getenv("RMEM_GEMM_BIG_DEEP_ST")) : 3;
       launch_big<128, 128>(p, is1x1, (t128 <= big_deep && p.K >= 512) ? deep_st : big_st, s);
+      return rmem_check_launch("rmem_conv2d_nhwc");
+    }
+    // row-run problems on the larger tiles: their k-loop is all global -> LDS traffic as well.  Measured (16 images / 8 clips per
+    // launch): the id bank (17x17x16 -> 256, 85 k-steps) 105.8 -> 81.2 us on 128x128 tiles with a 3-deep ring (bit 0, the default);
+    // the stem (7x7x8 -> 64) on 128x64 tiles (bit 1) 213.8 -> 195.2 us alone with a single buffer but no faster end to end: off
+    static const int rr_big = getenv("RMEM_GEMM_ROWRUN_BIG") ? atoi(getenv("RMEM_GEMM_ROWRUN_BIG")) : 1;
+    static const int rr_st = getenv("RMEM_GEMM_ROWRUN_ST") ? atoi(getenv("RMEM_GEMM_ROWRUN_ST")) : 3;
+    if (splits == 1 && p.fast_ok == 2 && (rr_big & 1) && p.Cout >= 128) {
+      launch_big<128, 128, 2>(p, false, rr_st, s);
+      return rmem_check_launch("rmem_conv2d_nhwc");
+    }
+    if (splits == 1 && p.fast_ok == 2 && (rr_big & 2) && p.Cout <= 64) {
+      launch_big<128, 64, 2>(p, false, rr_st > 3 ? 3 : rr_st, s);
       return rmem_check_launch("rmem_conv2d_nhwc");
     }
     static const int big64 = getenv("RMEM_GEMM_BIG64") ? atoi(getenv("RMEM_GEMM_BIG64")) : 0;

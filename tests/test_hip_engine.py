@@ -357,6 +357,86 @@ def test_full_geometry_cfg3_cfg4_engine():
     assert np.array_equal(np.stack(outs), runs[1][0]), 'hipGraph replay differs from direct launches at HW = 2442, T -> 30'
 
 
+def test_group_engine_cfg3_geometry_new_object_vs_oracle():
+    """BASELINE cfg 3 protocol at cfg 3 / 4 GEOMETRY on the throughput path: 720x1280 video -> network size 577x1041 (HW = 2442), restricted
+    bank N = 8 (1 + 7), two clips in lockstep on one GroupEngine (hipGraphs, look-ahead encoder, chain kernels), a new object's mask
+    arriving at frame 5 of clip 1 only (managers/evaluator.py:484-508).  No reference fixture exists at this size, so the fp32 oracle runs
+    both clips (shared prefix, then with / without the new object) and its labels are fed back: logits, labels and the bank index trace
+    of every frame and clip against the oracle, through bank fill, four evictions (gap 1) and the restarted bank of clip 1 (kept below
+    N: at the first eviction after a re-added reference frame the reference itself raises, test_oracle_golden.py)."""
+    import copy
+    from oracle import ref_cpu as O
+    from rmem_ocu_amd import build_vos_model, get_config
+    from rmem_ocu_amd.clip_runner import GroupSlot
+    from rmem_ocu_amd.networks.engines.group_engine import GroupEngine
+    from rmem_ocu_amd.synth import make_clip, network_size
+    from rmem_ocu_amd.weights import synth_state_dict
+    dev = torch.device('cuda', 0)
+    vh, vw = 720, 1280
+    h, w = network_size(vh, vw)
+    n, objs, inj = 12, 2, 5        # clip 1 ends with 7 entries: the reference raises at the first eviction after a re-added reference frame
+    frames, mask = make_clip(303, n, h, w, objs)
+    new = torch.zeros(vh, vw, dtype=torch.uint8)
+    new[vh // 2:vh // 2 + vh // 4, vw // 8:vw // 8 + vw // 5] = objs + 1
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+
+    def oracle_frames(eng, lo, inject):
+        out = []
+        with torch.no_grad():
+            for i in range(lo, n):
+                logit = eng.match_propogate_one_frame(frames[i:i + 1], (vh, vw))
+                own = torch.argmax(logit, dim=1, keepdim=True).float()
+                label = own
+                if inject and i == inj:
+                    label = torch.where(new[None, None] > 0, new[None, None].float(), own)
+                    eng.add_reference_frame(frames[i:i + 1], F.interpolate(label, size=(h, w), mode='nearest'), i)
+                else:
+                    eng.update_memory(F.interpolate(label, size=(h, w), mode='nearest'))
+                out.append((own[0, 0].to(torch.uint8), logit[0, :, ::16, ::16].clone(), list(eng.long_memories_indexes)))
+                if i + 1 == inj and not inject:
+                    return out
+        return out
+
+    ora = O.OracleEngine(synth_state_dict(0), 1, 7, 1)
+    ora.long_term_mem_gap = 1
+    ora.add_reference_frame(frames[0:1], mask, 0)
+    prefix = oracle_frames(ora, 1, False)                     # frames 1 .. inj - 1, common to both clips
+    assert len(prefix) == inj - 1
+    refs = [prefix + oracle_frames(copy.deepcopy(ora), inj, False), prefix + oracle_frames(ora, inj, True)]
+
+    cfg = get_config('pre_vost', 'test', 'r50_aotl')
+    cfg.FORMER_MEM_LEN, cfg.LATTER_MEM_LEN = 1, 7
+    model = build_vos_model(cfg.MODEL_VOS, cfg).cuda(0)
+    model.load_state_dict(synth_state_dict(0))
+    ge = GroupEngine(model, 2, 0, 1, lookahead=2)
+    assert ge.use_graphs
+    gs = GroupSlot(ge, (vh, vw), dev)
+    fd = frames.to(dev)
+    gs.start([fd, fd], [mask.to(dev)] * 2, objs, new_objects={1: (inj, new.to(dev))})
+    ge.long_term_mem_gap = 1
+    gold = torch.stack([torch.stack([refs[c][i][0] for c in range(2)]) for i in range(n - 1)]).to(dev)   # [n - 1, 2, vh, vw]
+    torch.cuda.synchronize()
+    rt = ge.rt
+    worst, banks = 0.0, []
+    while not gs.done:
+        i = gs.cursor
+        gs.step(feed=gold[i - 1])
+        ge.synchronize()
+        lg = rt.logits.view(2, rt.H4, rt.W4, 16)[..., :11].permute(0, 3, 1, 2)
+        up = F.interpolate(lg, size=(vh, vw), mode='bilinear', align_corners=True)[:, :, ::16, ::16].cpu()
+        banks.append([len(sl) for sl in rt.slots])
+        for c in range(2):
+            own, ref, trace = refs[c][i - 1]
+            err = (up[c] - ref).abs().max().item() / ref.std().item()
+            worst = max(worst, err)
+            agree = (gs.labels[c, i].cpu() == own).float().mean().item()
+            assert list(ge.long_memories_indexes(c)) == trace, (c, i, list(ge.long_memories_indexes(c)), trace)
+            assert err < 0.065 and agree > 0.97, (c, i, err, agree)
+    print(f'577x1041 group, N = 8, new object at frame {inj} of clip 1: worst max |dlogit| / std {worst:.4f}; bank sizes per frame {banks}')
+    # clip 0 filled its bank at frame 7 and evicted since (a slot list holds 9 entries while an eviction is pending); clip 1 restarted at frame 5
+    assert banks[inj - 1] == [inj + 1, 1] and banks[-1][0] in (8, 9) and banks[-1][1] == n - inj and len(refs[0][-1][2]) == 8
+
+
 def test_full_geometry_cfg5_swin_engine():
     """BASELINE cfg 5 geometry on the engine: Swin-B at 720x1280 (HW = 45 x 80 = 3600 tokens), bank N = 12 (1 + 11), fp16 as the
     config names it: 16 frames with gap 1 fill the bank and evict; graph replay bit-identical to direct launches, logits finite,
