@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define RMEM_ABI_VERSION 7
+#define RMEM_ABI_VERSION 8
 
 int rmem_abi_version(void);
 const char* rmem_last_error_string(void);
@@ -83,6 +83,18 @@ int rmem_linear_grouped(const rmem_conv_desc* desc, int n, const void* const* x,
  * Cin and Cin2 must be multiples of 64. */
 int rmem_conv1x1_dual_nhwc(const rmem_conv_desc* desc, const void* x, const void* x2, int H2, int W2, int Cin2, int stride2,
                            const void* w_cat, const float* bias, void* y, void* stream);
+
+/* The tail of a ResNet bottleneck chained into the FIRST 1x1 convolution of the following block, one launch
+ * (encoders/resnet.py:62-68 of block i, then :48-50 of block i + 1 -- or of the next layer's first block):
+ *   y  = relu(b . w3^T + bias3 + res)      b [M][K1] (the 3x3 conv's output), w3 [Cout = 256][K1], res / y [M][256], M = batch * Ho * Wo
+ *   a2 = relu(y . w1^T + bias1)            w1 [N2][256], a2 [M][N2], N2 = 64 or 128
+ * y is stored (later blocks need it as their shortcut) but never read back: its 64-row tile stays in LDS, rounded as stored, as the
+ * A operand of the second GEMM.  Dual form (x2 != NULL, res == NULL; the block with the strided 1x1 shortcut, as
+ * rmem_conv1x1_dual_nhwc): y = relu([b | x2 sampled at stride2] . w3^T + bias3) with w3 [256][K1 + Cin2], x2 NHWC [batch][H2][W2][Cin2].
+ * Bit-identical to rmem_conv2d_nhwc (or rmem_conv1x1_dual_nhwc) followed by rmem_conv2d_nhwc.  K1, Cin2 multiples of 64. */
+typedef struct rmem_bneck_chain_desc { int batch, Ho, Wo, K1, Cout, N2, H2, W2, Cin2, stride2; } rmem_bneck_chain_desc;
+int rmem_bneck_chain(const rmem_bneck_chain_desc* desc, const void* b, const void* x2, const void* w3, const float* bias3, const void* res,
+                     void* y, const void* w1, const float* bias1, void* a2, void* stream);
 
 /* ------------------------------------------------------------------ memory-read attention
  * out[q, 32h:32h+32] = softmax_k( (Q[q,h]+pe_cur[h]) . (K[k,h]+pe_mem[slot(k),h]) / sqrt(32) ) V[k,h]
@@ -449,6 +461,7 @@ int rmem_lstt_chain_a_f16(const rmem_chain_a_desc* d, void* stream);
 int rmem_lstt_chain_b_f16(const rmem_chain_b_desc* d, void* stream);
 int rmem_lstt_chain_c_f16(const rmem_chain_c_desc* d, void* stream);
 int rmem_layernorm256_pair_f16(const void* a0, const void* b0, void* y0, const void* a1, const void* b1, void* y1, const float* gamma, const float* beta, float eps, int M, void* stream);
+int rmem_bneck_chain_f16(const rmem_bneck_chain_desc* desc, const void* b, const void* x2, const void* w3, const float* bias3, const void* res, void* y, const void* w1, const float* bias1, void* a2, void* stream);
 int rmem_conv1x1_dual_nhwc_f16(const rmem_conv_desc* desc, const void* x, const void* x2, int H2, int W2, int Cin2, int stride2, const void* w_cat, const float* bias, void* y, void* stream);
 int rmem_linear_grouped_f16(const rmem_conv_desc* desc, int n, const void* const* x, const void* const* w, const float* const* bias, const void* const* residual, void* const* y, void* stream);
 int rmem_groupnorm_nhwc_f16(const void* x, int M, int C, int groups, const float* gamma, const float* beta, float eps, int act, void* y, float* workspace, void* stream);

@@ -11,7 +11,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('RMEM_LIB_PATH') or os.path.join(_HERE, 'librmem_hip.so')   # override: kernel experiments only
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class RmemError(RuntimeError):
@@ -22,6 +22,10 @@ class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int) for n in ('H', 'W', 'Cin', 'Ho', 'Wo', 'Cout', 'KH', 'KW', 'stride', 'pad',
                                        'ldo', 'ldr', 'ld2', 'relu', 'out_f32', 'res_f32', 'ldx', 'batch', 'act_begin',
                                        'res_up_h', 'res_up_w', 'res_up_align')]
+
+
+class BneckChainDesc(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ('batch', 'Ho', 'Wo', 'K1', 'Cout', 'N2', 'H2', 'W2', 'Cin2', 'stride2')]
 
 
 class AttnChunk(C.Structure):
@@ -69,6 +73,7 @@ SIGNATURES = {
     'rmem_lstt_chain_b': (_i, [C.POINTER(ChainB), _vp]),
     'rmem_lstt_chain_c': (_i, [C.POINTER(ChainC), _vp]),
     'rmem_conv1x1_dual_nhwc': (_i, [C.POINTER(ConvDesc), _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    'rmem_bneck_chain': (_i, [C.POINTER(BneckChainDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'rmem_linear_grouped': (_i, [C.POINTER(ConvDesc), _i, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), _vp]),
     'rmem_groupnorm_workspace_bytes': (C.c_size_t, [_i]),
     'rmem_groupnorm_nhwc': (_i, [_vp, _i, _i, _i, _vp, _vp, _f, _i, _vp, _vp, _vp]),
@@ -120,7 +125,7 @@ SIGNATURES = {
 
 # entry points with 16-bit operands exist twice: <name> (bfloat16) and <name>_f16 (IEEE half), same signature (include/rmem.h)
 F16_TWINS = ('rmem_conv2d_nhwc', 'rmem_mem_read_attn', 'rmem_mem_read_attn_clips', 'rmem_lstt_attn_pair_clips', 'rmem_layernorm256', 'rmem_layernorm', 'rmem_patch_merge_ln',
-             'rmem_window_attn', 'rmem_window_attn_images', 'rmem_patch_merge_ln_images', 'rmem_add16', 'rmem_add16_grouped', 'rmem_layernorm256_pair', 'rmem_lstt_chain_a', 'rmem_lstt_chain_b', 'rmem_lstt_chain_c', 'rmem_conv1x1_dual_nhwc', 'rmem_linear_grouped',
+             'rmem_window_attn', 'rmem_window_attn_images', 'rmem_patch_merge_ln_images', 'rmem_add16', 'rmem_add16_grouped', 'rmem_layernorm256_pair', 'rmem_lstt_chain_a', 'rmem_lstt_chain_b', 'rmem_lstt_chain_c', 'rmem_conv1x1_dual_nhwc', 'rmem_bneck_chain', 'rmem_linear_grouped',
              'rmem_groupnorm_nhwc', 'rmem_groupnorm_f32_nhwc', 'rmem_groupnorm_nhwc_images', 'rmem_groupnorm_head_nhwc_images',
              'rmem_gn_act_dwconv5x5_nhwc_images', 'rmem_gn_act_dwconv5x5_prestats_nhwc_images', 'rmem_gn_act_dwconv5x5_nhwc', 'rmem_dwconv5x5_nhwc', 'rmem_image_to_nhwc8',
              'rmem_image_to_nhwc8_images', 'rmem_image_ptrs_to_nhwc8', 'rmem_ingest_rgb8', 'rmem_maxpool3x3s2_nhwc', 'rmem_maxpool3x3s2_nhwc_images', 'rmem_bilinear_nhwc',

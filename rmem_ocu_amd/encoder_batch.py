@@ -9,6 +9,7 @@ every output row from the same operands in the same order.
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, Tuple
 
 import torch
@@ -91,25 +92,42 @@ class BatchEncoder(_PtrInput):
         o.append(ops.maxpool3x3s2(self.stem, self.pool, H=self.H2, W=self.W2, C=64, images=B))
         x, (h, w), cin = self.pool, (self.H4, self.W4), 64
         outs = [self.x4, self.x8, self.x16]
-        for li, (nblk, stride) in enumerate(zip(R50_BLOCKS, R50_STRIDES), start=1):
+        # layer 1 (256-channel maps at stride 4: HBM-bound at these batch sizes): a block's conv3 + shortcut is chained into the NEXT
+        # block's conv1 in one launch (rmem_bneck_chain), so the 256-channel map is written once and not read back by that conv1
+        chain_on = os.environ.get('RMEM_NO_BNECK_CHAIN', '0') != '1'
+        blocks = [(li, bi) for li, nblk in enumerate(R50_BLOCKS, start=1) for bi in range(nblk)]
+        conv1_done = False
+        for idx, (li, bi) in enumerate(blocks):
+            stride = R50_STRIDES[li - 1]
             planes = 64 * 2 ** (li - 1)
-            for bi in range(nblk):
-                p = f'encoder.layer{li}.{bi}'
-                s = stride if bi == 0 else 1
-                ho, wo = _out(h, 3, s, 1), _out(w, 3, s, 1)
-                y = outs[li - 1][bi % 2]
-                a = self.mid_a[: B * h * w * planes]
-                bb = self.mid_b[: B * ho * wo * planes]
+            p = f'encoder.layer{li}.{bi}'
+            s = stride if bi == 0 else 1
+            ho, wo = _out(h, 3, s, 1), _out(w, 3, s, 1)
+            y = outs[li - 1][bi % 2]
+            a = self.mid_a[: B * h * w * planes]
+            bb = self.mid_b[: B * ho * wo * planes]
+            if not conv1_done:
                 o.append(self._conv(x, P[p + '.conv1.w'], P[p + '.conv1.b'], a, H=h, W=w, Cin=cin, Cout=planes, relu=True))
-                o.append(self._conv(a, P[p + '.conv2.w'], P[p + '.conv2.b'], bb, H=h, W=w, Cin=planes, Cout=planes, KH=3, KW=3,
-                                    stride=s, pad=1, relu=True))
-                if (p + '.c3ds.w') in P:     # conv3 + strided 1x1 shortcut as one GEMM: the shortcut tensor never exists
-                    o.append(ops.conv1x1_dual(bb, x, P[p + '.c3ds.w'], P[p + '.c3ds.b'], y, H=ho, W=wo, Cin=planes, Cout=planes * 4,
-                                              H2=h, W2=w, Cin2=cin, stride2=s, relu=True, batch=B))
-                else:
-                    o.append(self._conv(bb, P[p + '.conv3.w'], P[p + '.conv3.b'], y, H=ho, W=wo, Cin=planes, Cout=planes * 4,
-                                        residual=x, relu=True))
-                x, (h, w), cin = y, (ho, wo), planes * 4
+            conv1_done = False
+            o.append(self._conv(a, P[p + '.conv2.w'], P[p + '.conv2.b'], bb, H=h, W=w, Cin=planes, Cout=planes, KH=3, KW=3,
+                                stride=s, pad=1, relu=True))
+            dual = (p + '.c3ds.w') in P
+            nxt = blocks[idx + 1] if idx + 1 < len(blocks) else None
+            if chain_on and li == 1 and nxt is not None:
+                pn = f'encoder.layer{nxt[0]}.{nxt[1]}'
+                n2 = 64 * 2 ** (nxt[0] - 1)
+                a_next = self.mid_a[: B * ho * wo * n2]
+                kw = dict(x2=x, H2=h, W2=w, Cin2=cin, stride2=s) if dual else dict(residual=x)
+                o.append(ops.bneck_chain(bb, P[p + ('.c3ds.w' if dual else '.conv3.w')], P[p + ('.c3ds.b' if dual else '.conv3.b')], y,
+                                         P[pn + '.conv1.w'], P[pn + '.conv1.b'], a_next, H=ho, W=wo, K1=planes, N2=n2, batch=B, **kw))
+                conv1_done = True
+            elif dual:     # conv3 + strided 1x1 shortcut as one GEMM: the shortcut tensor never exists
+                o.append(ops.conv1x1_dual(bb, x, P[p + '.c3ds.w'], P[p + '.c3ds.b'], y, H=ho, W=wo, Cin=planes, Cout=planes * 4,
+                                          H2=h, W2=w, Cin2=cin, stride2=s, relu=True, batch=B))
+            else:
+                o.append(self._conv(bb, P[p + '.conv3.w'], P[p + '.conv3.b'], y, H=ho, W=wo, Cin=planes, Cout=planes * 4,
+                                    residual=x, relu=True))
+            x, (h, w), cin = y, (ho, wo), planes * 4
         self._prog = o
         return o
 

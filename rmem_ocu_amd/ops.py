@@ -114,6 +114,23 @@ def conv1x1_dual(x, x2, w_cat, bias, y, *, H, W, Cin, Cout, H2, W2, Cin2, stride
     return Op(_fn('rmem_conv1x1_dual_nhwc', dt), args, 'rmem_conv1x1_dual_nhwc', (d, x, x2, w_cat, bias, y))
 
 
+def bneck_chain(b, w3, bias3, y, w1, bias1, a2, *, H, W, K1, N2, residual=None, x2=None, H2=0, W2=0, Cin2=0, stride2=1, batch=1) -> Op:
+    """y = relu(b @ w3^T + bias3 + residual) and a2 = relu(y @ w1^T + bias1) in one launch (bottleneck tail + the next block's conv1);
+    with x2 instead of residual: y = relu([b | x2 sampled at stride2] @ w3^T + bias3).  b [batch*H*W, K1], y [.., 256], a2 [.., N2]."""
+    _dev(b, w3, bias3, y, w1, bias1, a2, residual, x2)
+    dt = w3.dtype
+    M = batch * H * W
+    assert (residual is None) != (x2 is None)
+    assert all(t.dtype == dt for t in (b, y, w1, a2)) and bias3.dtype == F32 and bias1.dtype == F32
+    assert w3.is_contiguous() and w1.is_contiguous() and w3.numel() == 256 * (K1 + (Cin2 if x2 is not None else 0)) and w1.numel() == N2 * 256
+    assert b.numel() >= M * K1 and y.numel() >= M * 256 and a2.numel() >= M * N2 and bias3.numel() == 256 and bias1.numel() == N2
+    assert residual is None or (residual.dtype == dt and residual.numel() >= M * 256)
+    assert x2 is None or (x2.dtype == dt and x2.numel() >= batch * H2 * W2 * Cin2)
+    d = _lib.BneckChainDesc(batch, H, W, K1, 256, N2, H2, W2, Cin2, stride2)
+    args = (C.byref(d), _ptr(b), _ptr(x2), _ptr(w3), _ptr(bias3), _ptr(residual), _ptr(y), _ptr(w1), _ptr(bias1), _ptr(a2))
+    return Op(_fn('rmem_bneck_chain', dt), args, 'rmem_bneck_chain', (d, b, x2, w3, bias3, residual, y, w1, bias1, a2))
+
+
 def linear(x, w, bias, y, *, M, K, N, residual=None, y2=None, relu=False, ldo=None, ldr=None, ld2=None, ws=None, ldx=0,
            act_begin=0) -> Op:
     """y[M, N] = x[M, K] @ w[N, K]^T + bias: the 1x1 case of conv2d (x rows of stride ldx, default K)."""

@@ -654,6 +654,55 @@ def test_conv1x1_dual_bottleneck_tail(dev, B, H2, W2, K1, K2, Cout, stride):
     assert_close(y, ref.permute(0, 2, 3, 1).reshape(B * Ho * Wo, Cout), 1e-2, 'conv3 + shortcut')
 
 
+@pytest.mark.parametrize('dt', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('N2', [64, 128])
+@pytest.mark.parametrize('dual', [False, True])
+def test_bneck_chain_is_bit_identical(dev, dual, N2, dt):
+    """rmem_bneck_chain: a bottleneck's conv3 + shortcut + ReLU chained into the next block's conv1 in one launch (the 256-channel tile
+    never returns from HBM; encoders/resnet.py:62-68, 48-50) against the launches it replaces -- rmem_conv2d_nhwc with a residual (or
+    rmem_conv1x1_dual_nhwc for the block with the strided 1x1 shortcut) followed by rmem_conv2d_nhwc: both outputs bit for bit, with a
+    ragged last row tile (M = 2 * 37 * 41 rows), and against fp32 torch on the rounded operands."""
+    from rmem_ocu_amd import ops
+    B, Ho, Wo, K1, stride = 2, 37, 41, 64, 2 if dual else 1
+    H2, W2 = (Ho - 1) * stride + 1, (Wo - 1) * stride + 2
+    M = B * Ho * Wo
+    rt = lambda t: t.to(dt).float()       # noqa: E731
+    b = rt(seeded(61, (M, K1)))
+    w3 = rt(seeded(62, (256, K1), 1.0 / K1 ** 0.5))
+    b3 = seeded(63, (256,), 0.1)
+    w1 = rt(seeded(64, (N2, 256), 1.0 / 16))
+    b1 = seeded(65, (N2,), 0.1)
+    bd = b.to(dt).to(dev)
+    if dual:
+        x2 = rt(seeded(66, (B, H2, W2, 64)))
+        wd = rt(seeded(67, (256, 64), 1.0 / 8))
+        w3d = torch.cat([w3, wd], 1).contiguous().to(dt).to(dev)
+        x2d = x2.to(dt).to(dev)
+        ref_y = F.relu(b @ w3.t() + x2[:, ::stride, ::stride][:, :Ho, :Wo].reshape(M, 64) @ wd.t() + b3)
+    else:
+        res = rt(seeded(68, (M, 256)))
+        w3d = w3.to(dt).to(dev)
+        resd = res.to(dt).to(dev)
+        ref_y = F.relu(b @ w3.t() + b3 + res)
+    w1d = w1.to(dt).to(dev)
+    y0, y1 = (torch.zeros(M, 256, dtype=dt, device=dev) for _ in range(2))
+    a0, a1 = (torch.zeros(M, N2, dtype=dt, device=dev) for _ in range(2))
+    if dual:
+        ops.run(ops.conv1x1_dual(bd, x2d, w3d, b3.to(dev), y0, H=Ho, W=Wo, Cin=K1, Cout=256, H2=H2, W2=W2, Cin2=64, stride2=stride, relu=True, batch=B))
+        chain = ops.bneck_chain(bd, w3d, b3.to(dev), y1, w1d, b1.to(dev), a1, H=Ho, W=Wo, K1=K1, N2=N2, x2=x2d, H2=H2, W2=W2, Cin2=64,
+                                stride2=stride, batch=B)
+    else:
+        ops.run(ops.conv2d(bd, w3d, b3.to(dev), y0, H=Ho, W=Wo, Cin=K1, Cout=256, residual=resd, relu=True, batch=B))
+        chain = ops.bneck_chain(bd, w3d, b3.to(dev), y1, w1d, b1.to(dev), a1, H=Ho, W=Wo, K1=K1, N2=N2, residual=resd, batch=B)
+    ops.run(ops.conv2d(y0, w1d, b1.to(dev), a0, H=Ho, W=Wo, Cin=256, Cout=N2, relu=True, batch=B))
+    ops.run(chain)
+    torch.cuda.synchronize()
+    assert torch.equal(y0, y1), f'y differs in {(y0 != y1).sum().item()} elements'
+    assert torch.equal(a0, a1), f'a2 differs in {(a0 != a1).sum().item()} elements'
+    assert_close(y1, ref_y, 1e-2, 'chained y')
+    assert_close(a1, F.relu(y1.float().cpu() @ w1.t() + b1), 1e-2, 'chained a2')
+
+
 @pytest.mark.parametrize('align', [True, False])
 def test_conv_resized_residual_is_bit_identical(dev, align):
     """rmem_conv_desc.res_up_*: the residual is a lower-resolution map resized on the fly in the GEMM epilogue
