@@ -364,6 +364,16 @@ int rmem_image_to_nhwc8_images(const float* img_chw, void* out, int images, int 
 /* The same with the images named by a DEVICE table of `images` pointers (fp32 [3][H][W] each): the frames of several clips go into
  * one encoder batch from wherever the caller keeps them, without a staging copy (models/aot.py:116-134: the encoder's input). */
 int rmem_image_ptrs_to_nhwc8(const float* const* img_ptrs, void* out, int images, int H, int W, void* stream);
+/* ResNet stem without im2col traffic (encoders/resnet.py:131-135: conv1 7x7 stride 2 pad 3, bn1 folded, ReLU).
+ * rmem_stem_padded_size: the frame layout the kernel reads -- NHWC with 4 channels (r, g, b, 0) inside a zero border: [images][Hp][Wp][4],
+ *   pixel (y, x) at row y + 3, column x + 3; the caller zeroes the buffer ONCE, rmem_image_ptrs_to_nhwc4p writes only the interior.
+ * rmem_stem7x7s2: y [images][Ho][Wo][64] = relu(conv + bias), Ho = (H - 1) / 2 + 1; w is [64][8][8][4] (ky, kx, c; zero where ky = 7,
+ *   kx = 7 or c = 3), i.e. K = 256.  A persistent workgroup keeps the weights in registers and copies each 64-output window block
+ *   (8 rows x 134 pixels) to LDS once; MFMA B fragments are read from it in place.  Same products as rmem_conv2d_nhwc on the 8-channel
+ *   layout, summed in another order (fp32). */
+int rmem_stem_padded_size(int H, int W, int* Hp, int* Wp);
+int rmem_image_ptrs_to_nhwc4p(const float* const* img_ptrs, void* out_padded, int images, int H, int W, void* stream);
+int rmem_stem7x7s2(const void* x_padded, int images, int H, int W, const void* w, const float* bias, void* y, void* stream);
 /* Frame ingest: decoded uint8 RGB [Hs][Ws][3] -> bicubic resize to the network size (OpenCV INTER_CUBIC semantics) ->
  * ImageNet normalise -> fp32 [3][Hd][Wd] (the engine API's input) and/or bf16 [Hd][Wd][8] (the encoder's input).
  * Replaces dataloaders/video_transforms.py:648-652 (cv2.resize) + 676-680 (normalise) on the host. */
@@ -472,6 +482,8 @@ int rmem_gn_act_dwconv5x5_nhwc_images_f16(const void* x, int images, int H, int 
 int rmem_gn_act_dwconv5x5_prestats_nhwc_images_f16(const void* x, int images, int H, int W, int C, int groups, const float* gamma, const float* beta, float eps, int act, const float* w_t, void* y, const float* stats, void* stream);
 int rmem_gn_act_dwconv5x5_nhwc_f16(const void* x, int H, int W, int C, int groups, const float* gamma, const float* beta, float eps, int act, const float* w_t, void* y, float* workspace, void* stream);
 int rmem_dwconv5x5_nhwc_f16(const void* x, const float* w_t, void* y, int H, int W, int C, void* stream);
+int rmem_image_ptrs_to_nhwc4p_f16(const float* const* img_ptrs, void* out_padded, int images, int H, int W, void* stream);
+int rmem_stem7x7s2_f16(const void* x_padded, int images, int H, int W, const void* w, const float* bias, void* y, void* stream);
 int rmem_image_ptrs_to_nhwc8_f16(const float* const* img_ptrs, void* out, int images, int H, int W, void* stream);
 int rmem_image_to_nhwc8_f16(const float* img_chw, void* out, int H, int W, void* stream);
 int rmem_image_to_nhwc8_images_f16(const float* img_chw, void* out, int images, int H, int W, void* stream);

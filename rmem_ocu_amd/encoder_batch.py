@@ -66,7 +66,14 @@ class BatchEncoder(_PtrInput):
         e = lambda *shape, dt=None: torch.empty(*shape, dtype=dt or dt16, device=device)  # noqa: E731
         self.img_in = e(B, 3, H, W, dt=F32)
         self._init_ptrs(B, device)
-        self.img8 = e(B, H * W, 8)
+        # stem input: NHWC4 frames inside the zero border rmem_stem7x7s2 reads (zeroed once here, only the interior is ever written);
+        # RMEM_STEM=rowrun keeps the 8-channel layout and the generic row-run GEMM form (experiments)
+        self.stem4 = os.environ.get('RMEM_STEM', 'direct') != 'rowrun' and 'stem.w4' in P
+        if self.stem4:
+            hp, wp = ops.stem_padded_size(H, W)
+            self.img4 = torch.zeros(B, hp, wp, 4, dtype=dt16, device=device)
+        else:
+            self.img8 = e(B, H * W, 8)
         self.stem = e(B, self.H2 * self.W2, 64)
         self.pool = e(B, M4, 64)
         self.x4 = [e(B, M4, 256), e(B, M4, 256)]
@@ -86,9 +93,13 @@ class BatchEncoder(_PtrInput):
         if self._prog is not None:
             return self._prog
         P, B, o = self.P, self.B, []
-        o.append(self._input_op())
-        o.append(self._conv(self.img8, P['stem.w'], P['stem.b'], self.stem, H=self.H, W=self.W, Cin=8, Cout=64, KH=7, KW=7, stride=2,
-                            pad=3, relu=True))
+        if self.stem4:
+            o.append(ops.image_ptrs_to_nhwc4p(self.img_ptrs, self.img4, H=self.H, W=self.W, images=B))
+            o.append(ops.stem7x7s2(self.img4, P['stem.w4'], P['stem.b'], self.stem, H=self.H, W=self.W, images=B))
+        else:
+            o.append(self._input_op())
+            o.append(self._conv(self.img8, P['stem.w'], P['stem.b'], self.stem, H=self.H, W=self.W, Cin=8, Cout=64, KH=7, KW=7, stride=2,
+                                pad=3, relu=True))
         o.append(ops.maxpool3x3s2(self.stem, self.pool, H=self.H2, W=self.W2, C=64, images=B))
         x, (h, w), cin = self.pool, (self.H4, self.W4), 64
         outs = [self.x4, self.x8, self.x16]

@@ -397,6 +397,34 @@ def image_ptrs_to_nhwc8(ptr_table, out, *, H, W, images) -> Op:
     return Op(_fn('rmem_image_ptrs_to_nhwc8', dt), (_ptr(ptr_table), _ptr(out), images, H, W), 'rmem_image_ptrs_to_nhwc8', (ptr_table, out))
 
 
+def stem_padded_size(H: int, W: int):
+    """(Hp, Wp) of the zero-bordered NHWC4 frame layout rmem_stem7x7s2 reads"""
+    hp, wp = C.c_int(0), C.c_int(0)
+    if _lib.lib().rmem_stem_padded_size(H, W, C.byref(hp), C.byref(wp)):
+        raise RmemError('rmem_stem_padded_size: bad argument')
+    return hp.value, wp.value
+
+
+def image_ptrs_to_nhwc4p(ptr_table, out, *, H, W, images) -> Op:
+    """device int64 table of `images` pointers to fp32 [3, H, W] frames -> the interior of 16-bit [images, Hp, Wp, 4] (border kept zero)"""
+    _dev(ptr_table, out)
+    dt = out.dtype
+    hp, wp = stem_padded_size(H, W)
+    assert ptr_table.dtype == torch.int64 and ptr_table.numel() >= images and out.is_contiguous() and out.numel() >= images * hp * wp * 4
+    return Op(_fn('rmem_image_ptrs_to_nhwc4p', dt), (_ptr(ptr_table), _ptr(out), images, H, W), 'rmem_image_ptrs_to_nhwc4p', (ptr_table, out))
+
+
+def stem7x7s2(x_padded, w4, bias, y, *, H, W, images) -> Op:
+    """y [images, Ho*Wo, 64] = relu(conv7x7 stride 2 of the padded NHWC4 frames + bias); w4 [64, 8, 8, 4]"""
+    _dev(x_padded, w4, bias, y)
+    dt = w4.dtype
+    hp, wp = stem_padded_size(H, W)
+    ho, wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    assert x_padded.dtype == dt and y.dtype == dt and bias.dtype == F32 and w4.is_contiguous() and w4.numel() == 64 * 256 and bias.numel() == 64
+    assert x_padded.numel() >= images * hp * wp * 4 and y.numel() >= images * ho * wo * 64
+    return Op(_fn('rmem_stem7x7s2', dt), (_ptr(x_padded), images, H, W, _ptr(w4), _ptr(bias), _ptr(y)), 'rmem_stem7x7s2', (x_padded, w4, bias, y))
+
+
 def ingest_rgb8(rgb, *, Hs, Ws, Hd, Wd, out_chw=None, out_nhwc8=None) -> Op:
     """uint8 RGB [Hs, Ws, 3] device tensor -> resized, normalised fp32 [3, Hd, Wd] and/or bf16 [Hd*Wd, 8]."""
     _dev(rgb, out_chw, out_nhwc8)

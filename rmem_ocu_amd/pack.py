@@ -153,6 +153,9 @@ def _pack_state_dict(sd: Dict[str, torch.Tensor], device, num_lstt: int) -> Dict
     else:
         w, b = _fold_bn(sd, 'encoder.conv1.weight', 'encoder.bn1', cin_pad=8)
         put('stem.w', w); put('stem.b', b)
+        w4 = torch.zeros(w.shape[0], 8, 8, 4, dtype=w.dtype)         # rmem_stem7x7s2: [64][ky 8][kx 8][c 4], zero tail (K = 256)
+        w4[:, :7, :7, :3] = w.view(w.shape[0], 7, 7, 8)[..., :3]
+        put('stem.w4', w4)
     for li, nblk in enumerate(() if swin else R50_BLOCKS, start=1):
         for bi in range(nblk):
             p = f'encoder.layer{li}.{bi}'

@@ -655,6 +655,41 @@ def test_conv1x1_dual_bottleneck_tail(dev, B, H2, W2, K1, K2, Cout, stride):
 
 
 @pytest.mark.parametrize('dt', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('B,H,W', [(2, 97, 129), (1, 480, 854), (3, 50, 262), (2, 481, 849)])
+def test_stem7x7s2_direct(dev, B, H, W, dt):
+    """rmem_stem7x7s2 (+ rmem_image_ptrs_to_nhwc4p): the ResNet stem (encoders/resnet.py:131-135, BatchNorm folded) read straight from the
+    zero-bordered NHWC4 frames -- against fp32 F.conv2d on the rounded operands, and against the generic row-run GEMM form on the
+    8-channel layout (same products, another summation order: equal up to the output rounding).  Odd and even sizes, ragged last
+    tile of a row, several images, persistent workgroups that take several tiles each."""
+    from rmem_ocu_amd import ops
+    imgs = [seeded(70 + b, (3, H, W)).to(dev) for b in range(B)]
+    w = seeded(75, (64, 3, 7, 7), 1.0 / 147 ** 0.5).to(dt).float()
+    bias = seeded(76, (64,), 0.1)
+    x = torch.stack([i.cpu() for i in imgs]).to(dt).float()
+    ref = F.relu(F.conv2d(x, w, bias, stride=2, padding=3))
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    ptrs = torch.tensor([i.data_ptr() for i in imgs], dtype=torch.int64, device=dev)
+    hp, wp = ops.stem_padded_size(H, W)
+    x4 = torch.zeros(B, hp, wp, 4, dtype=dt, device=dev)
+    w4 = torch.zeros(64, 8, 8, 4, dtype=dt)
+    w4[:, :7, :7, :3] = w.permute(0, 2, 3, 1).to(dt)
+    y = torch.zeros(B, Ho * Wo, 64, dtype=dt, device=dev)
+    for _ in range(2):                 # twice: the border must still be zero after the first pass
+        ops.run([ops.image_ptrs_to_nhwc4p(ptrs, x4, H=H, W=W, images=B), ops.stem7x7s2(x4, w4.to(dev), bias.to(dev), y, H=H, W=W, images=B)])
+    torch.cuda.synchronize()
+    assert_close(y.view(B, Ho, Wo, 64), ref.permute(0, 2, 3, 1), 1e-2, 'stem')
+    x8 = torch.zeros(B, H * W, 8, dtype=dt, device=dev)
+    w8 = F.pad(w.permute(0, 2, 3, 1), (0, 5)).contiguous().to(dt).to(dev)
+    y8 = torch.zeros_like(y)
+    ops.run([ops.image_ptrs_to_nhwc8(ptrs, x8, H=H, W=W, images=B),
+             ops.conv2d(x8, w8, bias.to(dev), y8, H=H, W=W, Cin=8, Cout=64, KH=7, KW=7, stride=2, pad=3, relu=True, batch=B)])
+    torch.cuda.synchronize()
+    d = (y.float() - y8.float()).abs()
+    assert d.max().item() <= 2.0 ** (-7 if dt == torch.bfloat16 else -10) * max(1.0, y8.float().abs().max().item()), d.max().item()
+    assert (d > 0).float().mean().item() < 0.02        # a different summation order moves a rounding now and then, no more
+
+
+@pytest.mark.parametrize('dt', [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize('N2', [64, 128])
 @pytest.mark.parametrize('dual', [False, True])
 def test_bneck_chain_is_bit_identical(dev, dual, N2, dt):
