@@ -425,6 +425,15 @@ def stem7x7s2(x_padded, w4, bias, y, *, H, W, images) -> Op:
     return Op(_fn('rmem_stem7x7s2', dt), (_ptr(x_padded), images, H, W, _ptr(w4), _ptr(bias), _ptr(y)), 'rmem_stem7x7s2', (x_padded, w4, bias, y))
 
 
+def conv3x3_c64_direct(x, w, bias, y, *, H, W, images) -> Op:
+    """y = relu(conv3x3(x) + bias), 64 -> 64 channels, stride 1, pad 1; x / y [images*H*W, 64], w [64, 3, 3, 64]"""
+    _dev(x, w, bias, y)
+    dt = w.dtype
+    assert x.dtype == dt and y.dtype == dt and bias.dtype == F32 and w.is_contiguous() and w.numel() == 64 * 576 and bias.numel() == 64
+    assert x.numel() >= images * H * W * 64 and y.numel() >= images * H * W * 64
+    return Op(_fn('rmem_conv3x3_c64_direct', dt), (_ptr(x), images, H, W, _ptr(w), _ptr(bias), _ptr(y)), 'rmem_conv3x3_c64_direct', (x, w, bias, y))
+
+
 def ingest_rgb8(rgb, *, Hs, Ws, Hd, Wd, out_chw=None, out_nhwc8=None) -> Op:
     """uint8 RGB [Hs, Ws, 3] device tensor -> resized, normalised fp32 [3, Hd, Wd] and/or bf16 [Hd*Wd, 8]."""
     _dev(rgb, out_chw, out_nhwc8)
