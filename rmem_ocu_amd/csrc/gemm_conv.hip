@@ -911,7 +911,9 @@ extern "C" int RMEM_API(rmem_conv2d_nhwc)(const rmem_conv_desc* d, const void* x
     // enough tiles to balance 256 CUs.  Measured per layer with 8 images / 4 clips per launch: 121x213 3x3 128->128 563 -> 662
     // TFLOP/s, 512->1024 stride 2 393 -> 470; shallow-K 1x1 layers (64->256, 128->512) lose 20-40 % and stay on 64x64.
     static const int big_thr = getenv("RMEM_GEMM_BIG") ? atoi(getenv("RMEM_GEMM_BIG")) : 128;
-    static const int big_k = getenv("RMEM_GEMM_BIG_K") ? atoi(getenv("RMEM_GEMM_BIG_K")) : 256;
+    // (round 3, 16 images / 8 clips per launch, measured in the whole pipeline where other streams' kernels share the CUs: K = 256
+    // layers -- layer-3 conv3, the decoder's 1x1s -- are better off on 64x64 tiles: 3276 -> 3315 frames/s, three A/B pairs)
+    static const int big_k = getenv("RMEM_GEMM_BIG_K") ? atoi(getenv("RMEM_GEMM_BIG_K")) : 512;
     static const int big_st = getenv("RMEM_GEMM_BIG_ST") ? atoi(getenv("RMEM_GEMM_BIG_ST")) : 1;
     if (splits == 1 && big_thr > 0 && p.fast_ok == 1 && p.Cout >= 128 && p.K >= big_k &&
         (long)((p.M + 127) / 128) * ((p.Cout + 127) / 128) >= big_thr) {
