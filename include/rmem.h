@@ -374,9 +374,11 @@ int rmem_image_ptrs_to_nhwc8(const float* const* img_ptrs, void* out, int images
 int rmem_stem_padded_size(int H, int W, int* Hp, int* Wp);
 int rmem_image_ptrs_to_nhwc4p(const float* const* img_ptrs, void* out_padded, int images, int H, int W, void* stream);
 int rmem_stem7x7s2(const void* x_padded, int images, int H, int W, const void* w, const float* bias, void* y, void* stream);
-/* 3x3 stride-1 pad-1 convolution, 64 -> 64 channels, + bias + ReLU (the second conv of the ResNet layer-1 bottlenecks,
- * encoders/resnet.py:52-56) read in place from an LDS patch: x NHWC [images][H][W][64], w [64][3][3][64] (rmem_conv2d_nhwc's layout),
- * y [images][H][W][64].  Bit-identical to rmem_conv2d_nhwc (same k order, same epilogue); weights stay in registers. */
+/* 3x3 stride-1 pad-1 convolution with C input and C output channels (C = 64 or 128) + bias (+ ReLU), read in place from rows kept in
+ * LDS with the weights in registers: the second conv of the ResNet layer-1 / layer-2 bottlenecks (encoders/resnet.py:52-56) and the
+ * decoder's conv_4x (decoders/fpn.py:54-58).  x NHWC [images][H][W][C], w [C][3][3][C] (rmem_conv2d_nhwc's layout), y like x.
+ * Bit-identical to rmem_conv2d_nhwc (same k order, same epilogue).  rmem_conv3x3_c64_direct = C 64 with ReLU. */
+int rmem_conv3x3_direct(const void* x, int images, int H, int W, int C, const void* w, const float* bias, int relu, void* y, void* stream);
 int rmem_conv3x3_c64_direct(const void* x, int images, int H, int W, const void* w, const float* bias, void* y, void* stream);
 /* Frame ingest: decoded uint8 RGB [Hs][Ws][3] -> bicubic resize to the network size (OpenCV INTER_CUBIC semantics) ->
  * ImageNet normalise -> fp32 [3][Hd][Wd] (the engine API's input) and/or bf16 [Hd][Wd][8] (the encoder's input).
@@ -487,6 +489,7 @@ int rmem_gn_act_dwconv5x5_prestats_nhwc_images_f16(const void* x, int images, in
 int rmem_gn_act_dwconv5x5_nhwc_f16(const void* x, int H, int W, int C, int groups, const float* gamma, const float* beta, float eps, int act, const float* w_t, void* y, float* workspace, void* stream);
 int rmem_dwconv5x5_nhwc_f16(const void* x, const float* w_t, void* y, int H, int W, int C, void* stream);
 int rmem_image_ptrs_to_nhwc4p_f16(const float* const* img_ptrs, void* out_padded, int images, int H, int W, void* stream);
+int rmem_conv3x3_direct_f16(const void* x, int images, int H, int W, int C, const void* w, const float* bias, int relu, void* y, void* stream);
 int rmem_conv3x3_c64_direct_f16(const void* x, int images, int H, int W, const void* w, const float* bias, void* y, void* stream);
 int rmem_stem7x7s2_f16(const void* x_padded, int images, int H, int W, const void* w, const float* bias, void* y, void* stream);
 int rmem_image_ptrs_to_nhwc8_f16(const float* const* img_ptrs, void* out, int images, int H, int W, void* stream);

@@ -106,7 +106,9 @@ class BatchEncoder(_PtrInput):
         # layer 1 (256-channel maps at stride 4: HBM-bound at these batch sizes): a block's conv3 + shortcut is chained into the NEXT
         # block's conv1 in one launch (rmem_bneck_chain), so the 256-channel map is written once and not read back by that conv1
         chain_on = os.environ.get('RMEM_NO_BNECK_CHAIN', '0') != '1'
-        direct3 = os.environ.get('RMEM_NO_DIRECT_CONV3', '0') != '1'
+        # layer 1 (64 channels); the 128-channel form (layer 2) is faster alone (57.3 -> 43.5 us) but takes a whole CU's LDS per workgroup
+        # and measured neutral in the pipeline: opt-in (RMEM_DIRECT_CONV3_128=1)
+        direct3 = () if os.environ.get('RMEM_NO_DIRECT_CONV3', '0') == '1' else ((64, 128) if os.environ.get('RMEM_DIRECT_CONV3_128') == '1' else (64,))
         blocks = [(li, bi) for li, nblk in enumerate(R50_BLOCKS, start=1) for bi in range(nblk)]
         conv1_done = False
         for idx, (li, bi) in enumerate(blocks):
@@ -121,8 +123,8 @@ class BatchEncoder(_PtrInput):
             if not conv1_done:
                 o.append(self._conv(x, P[p + '.conv1.w'], P[p + '.conv1.b'], a, H=h, W=w, Cin=cin, Cout=planes, relu=True))
             conv1_done = False
-            if direct3 and planes == 64 and s == 1:     # read in place from an LDS patch, weights in registers (bit-identical)
-                o.append(ops.conv3x3_c64_direct(a, P[p + '.conv2.w'], P[p + '.conv2.b'], bb, H=h, W=w, images=B))
+            if planes in direct3 and s == 1:     # read in place from rows kept in LDS, weights in registers (bit-identical)
+                o.append(ops.conv3x3_direct(a, P[p + '.conv2.w'], P[p + '.conv2.b'], bb, H=h, W=w, C=planes, images=B, relu=True))
             else:
                 o.append(self._conv(a, P[p + '.conv2.w'], P[p + '.conv2.b'], bb, H=h, W=w, Cin=planes, Cout=planes, KH=3, KW=3,
                                     stride=s, pad=1, relu=True))

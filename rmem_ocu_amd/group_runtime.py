@@ -384,8 +384,11 @@ class GroupRuntime:
         else:
             o.append(ops.bilinear(d8d, self.d4a, Hi=self.H8, Wi=self.W8, Ho=self.H4, Wo=self.W4, C=128, align_corners=self.align, images=B))
             o.append(lin(enc1, 'dec.adapter_4x', self.d4b, M4, c4, 128, residual=self.d4a))
-        o.append(self._conv(self.d4b, P['dec.conv_4x.w'], P['dec.conv_4x.b'], self.d4a, H=self.H4, W=self.W4, Cin=128, Cout=128, KH=3,
-                            KW=3, pad=1))
+        if os.environ.get('RMEM_DIRECT_CONV3_128') == '1':   # rows kept in LDS, weights in registers (bit-identical; 97 -> 75 us alone, neutral in the pipeline: opt-in)
+            o.append(ops.conv3x3_direct(self.d4b, P['dec.conv_4x.w'], P['dec.conv_4x.b'], self.d4a, H=self.H4, W=self.W4, C=128, images=B))
+        else:
+            o.append(self._conv(self.d4b, P['dec.conv_4x.w'], P['dec.conv_4x.b'], self.d4a, H=self.H4, W=self.W4, Cin=128, Cout=128, KH=3,
+                                KW=3, pad=1))
         if os.environ.get('RMEM_NO_HEADFUSE'):               # timing experiments only
             o.append(gn(self.d4a, 'dec.conv_4x', self.d4b, M4, 128))
             o.append(lin(self.d4b, 'dec.conv_out', self.logits, M4, 128, self.nc, ldo=16))

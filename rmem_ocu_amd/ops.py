@@ -434,6 +434,15 @@ def conv3x3_c64_direct(x, w, bias, y, *, H, W, images) -> Op:
     return Op(_fn('rmem_conv3x3_c64_direct', dt), (_ptr(x), images, H, W, _ptr(w), _ptr(bias), _ptr(y)), 'rmem_conv3x3_c64_direct', (x, w, bias, y))
 
 
+def conv3x3_direct(x, w, bias, y, *, H, W, C, images, relu=False) -> Op:
+    """y = act(conv3x3(x) + bias), C -> C channels (C = 64 or 128), stride 1, pad 1; x / y [images*H*W, C], w [C, 3, 3, C]"""
+    _dev(x, w, bias, y)
+    dt = w.dtype
+    assert C in (64, 128) and x.dtype == dt and y.dtype == dt and bias.dtype == F32 and w.is_contiguous() and w.numel() == 9 * C * C and bias.numel() == C
+    assert x.numel() >= images * H * W * C and y.numel() >= images * H * W * C
+    return Op(_fn('rmem_conv3x3_direct', dt), (_ptr(x), images, H, W, C, _ptr(w), _ptr(bias), int(relu), _ptr(y)), 'rmem_conv3x3_direct', (x, w, bias, y))
+
+
 def ingest_rgb8(rgb, *, Hs, Ws, Hd, Wd, out_chw=None, out_nhwc8=None) -> Op:
     """uint8 RGB [Hs, Ws, 3] device tensor -> resized, normalised fp32 [3, Hd, Wd] and/or bf16 [Hd*Wd, 8]."""
     _dev(rgb, out_chw, out_nhwc8)

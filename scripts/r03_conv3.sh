@@ -2,15 +2,14 @@
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/r03c3
 mkdir -p $O
-timeout -k 10 300 python -m pytest tests/test_hip_ops.py -m gpu -q -x -k "conv3x3_c64" > $O/t.log 2>&1 || { grep -v "^$" $O/t.log | tail -30 | cut -c1-300; exit 1; }
+timeout -k 10 300 python -m pytest tests/test_hip_ops.py -m gpu -q -x -k "conv3x3_direct" > $O/t.log 2>&1 || { grep -v "^$" $O/t.log | tail -30 | cut -c1-300; exit 1; }
 tail -2 $O/t.log
 timeout -k 10 200 python scripts/conv3_bench.py > $O/conv3_bench.txt 2>&1 || { tail -20 $O/conv3_bench.txt; exit 1; }
-grep frames $O/conv3_bench.txt
-RMEM_CONV3_WGS=768 timeout -k 10 200 python scripts/conv3_bench.py 2>&1 | grep direct
-RMEM_CONV3_WGS=1024 timeout -k 10 200 python scripts/conv3_bench.py 2>&1 | grep direct
-timeout -k 10 600 python -m pytest tests/test_hip_engine.py -m gpu -q -x -k "bench_path or encoder" > $O/t2.log 2>&1 || { grep -v "^$" $O/t2.log | tail -30 | cut -c1-300; exit 1; }
+grep "us " $O/conv3_bench.txt
+RMEM_CONV3_WGS128=512 timeout -k 10 200 python scripts/conv3_bench.py 2>&1 | grep "direct" | grep -v "layer 1"
+timeout -k 10 600 python -m pytest tests/test_hip_engine.py -m gpu -q -x -k "bench_path or encoder or matches_per_clip" > $O/t2.log 2>&1 || { grep -v "^$" $O/t2.log | tail -30 | cut -c1-300; exit 1; }
 tail -2 $O/t2.log
-for env in "RMEM_NO_DIRECT_CONV3=1" "X=0" "RMEM_NO_DIRECT_CONV3=1" "X=0"; do
+for env in "RMEM_NO_DIRECT_CONV3=128" "X=0" "RMEM_NO_DIRECT_CONV3=128" "X=0"; do
   echo "== $env"
   env $env timeout -k 10 200 python bench.py --no-cpu-baseline --roofline-launches 4 | cut -c1-140
 done

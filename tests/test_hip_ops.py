@@ -690,21 +690,24 @@ def test_stem7x7s2_direct(dev, B, H, W, dt):
 
 
 @pytest.mark.parametrize('dt', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('C,relu', [(64, True), (128, False), (128, True)])
 @pytest.mark.parametrize('B,H,W', [(2, 31, 54), (1, 121, 213), (3, 17, 64), (2, 9, 130), (1, 3, 1)])
-def test_conv3x3_c64_direct(dev, B, H, W, dt):
-    """rmem_conv3x3_c64_direct (the 3x3 conv of the ResNet layer-1 bottlenecks read in place from an LDS patch, weights in registers,
-    encoders/resnet.py:52-56) against rmem_conv2d_nhwc: BIT-IDENTICAL (same k order and epilogue), and against fp32 F.conv2d.  Widths
-    that are a multiple of the 64-pixel tile, ragged, and narrower than a tile; image borders; several tiles per persistent workgroup."""
+def test_conv3x3_direct(dev, B, H, W, C, relu, dt):
+    """rmem_conv3x3_direct (3x3 convs with C = 64 / 128 channels read in place from rows kept in LDS, weights in registers: the ResNet
+    layer-1 / layer-2 bottlenecks, encoders/resnet.py:52-56, and the decoder's conv_4x, decoders/fpn.py:54-58) against rmem_conv2d_nhwc:
+    BIT-IDENTICAL (same k order and epilogue), and against fp32 F.conv2d.  Widths that are a multiple of the 62-pixel strip, ragged,
+    and narrower than a strip; image borders; several rows and runs per workgroup; with and without ReLU."""
     from rmem_ocu_amd import ops
-    x = seeded(80, (B, 64, H, W)).to(dt).float()
-    w = seeded(81, (64, 64, 3, 3), 1.0 / 24).to(dt).float()
-    bias = seeded(82, (64,), 0.1)
-    ref = F.relu(F.conv2d(x, w, bias, padding=1)).permute(0, 2, 3, 1).reshape(B * H * W, 64)
-    xd = x.permute(0, 2, 3, 1).reshape(B * H * W, 64).contiguous().to(dt).to(dev)
+    x = seeded(80, (B, C, H, W)).to(dt).float()
+    w = seeded(81, (C, C, 3, 3), 1.0 / (3 * C ** 0.5)).to(dt).float()
+    bias = seeded(82, (C,), 0.1)
+    ref = F.conv2d(x, w, bias, padding=1)
+    ref = (F.relu(ref) if relu else ref).permute(0, 2, 3, 1).reshape(B * H * W, C)
+    xd = x.permute(0, 2, 3, 1).reshape(B * H * W, C).contiguous().to(dt).to(dev)
     wd = w.permute(0, 2, 3, 1).contiguous().to(dt).to(dev)
-    y0, y1 = (torch.zeros(B * H * W, 64, dtype=dt, device=dev) for _ in range(2))
-    ops.run(ops.conv2d(xd, wd, bias.to(dev), y0, H=H, W=W, Cin=64, Cout=64, KH=3, KW=3, stride=1, pad=1, relu=True, batch=B))
-    ops.run(ops.conv3x3_c64_direct(xd, wd, bias.to(dev), y1, H=H, W=W, images=B))
+    y0, y1 = (torch.zeros(B * H * W, C, dtype=dt, device=dev) for _ in range(2))
+    ops.run(ops.conv2d(xd, wd, bias.to(dev), y0, H=H, W=W, Cin=C, Cout=C, KH=3, KW=3, stride=1, pad=1, relu=relu, batch=B))
+    ops.run(ops.conv3x3_direct(xd, wd, bias.to(dev), y1, H=H, W=W, C=C, images=B, relu=relu))
     torch.cuda.synchronize()
     assert_close(y1, ref, 1e-2, 'direct 3x3')
     assert torch.equal(y0, y1), f'{(y0 != y1).sum().item()} elements differ from rmem_conv2d_nhwc'
