@@ -11,7 +11,7 @@
 //   * the whole weight tensor of this wave's 32 output channels (2 x 18 fragments, K = 9 taps x 64) lives in REGISTERS for the life
 //     of a workgroup: the weights are the A operand, so a lane's accumulators are 4 consecutive channels of a pixel.
 // The k order (tap-major, then input channel) and the epilogue arithmetic are those of rmem_conv2d_nhwc: results are bit-identical
-// (tests/test_hip_ops.py::test_conv3x3_c64_direct).  256 threads = 2 (channel halves) x 2 (pixel halves) waves, the next input row in flight
+// (tests/test_hip_ops.py::test_conv3x3_direct).  256 threads = 2 (channel halves) x 2 (pixel halves) waves, the next input row in flight
 // behind a counted vmcnt, one shared object and raw barriers (see stem.hip for why).
 #include "common.h"
 #include "../../include/rmem.h"
