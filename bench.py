@@ -47,6 +47,9 @@ The single JSON line also carries
                   built now (sha256 match), else null.
   cpu_baseline -- oracle/ref_cpu.py (fp32 port of the reference path) timed on this host's cores on a
                   bounded sample of the same workload (rank 0, N = 1 only).
+  check        -- (with cpu_baseline) the masks of the timed path against the checker: the first clip group re-runs the clip the
+                  oracle just ran, same protocol (gap 1, 16 frames: the bank fills and evicts), free-running; per-pixel label
+                  agreement with the oracle's masks (the line is withheld below 0.97; near-ties of the synthetic weights flip ~0.3 %).
 """
 from __future__ import annotations
 
@@ -101,15 +104,37 @@ def cpu_baseline(frames, mask, video_hw, n_timed=8):
     with torch.no_grad():
         eng.add_reference_frame(frames[0:1], mask, 0)
         t0 = None
+        labels = []
         for i in range(1, 9 + n_timed):
             if i == 9:
                 t0 = time.time()
             logit = eng.match_propogate_one_frame(frames[i:i + 1], video_hw)
             label = torch.argmax(torch.softmax(logit, 1), 1, keepdim=True).float()
             eng.update_memory(F.interpolate(label, size=eng.input_size_2d, mode='nearest'))
+            labels.append(label[0, 0].to(torch.uint8))
         dt = time.time() - t0
     return {'value': round(n_timed / dt, 4), 'unit': 'frames/s', 'cores': threads, 'kind': 'port',
-            'sample': f'{n_timed} propagated frames at 481x849, bank T=8 (steady state of the 80-frame clip), fp32, after 9 untimed frames'}
+            'sample': f'{n_timed} propagated frames at 481x849, bank T=8 (steady state of the 80-frame clip), fp32, after 9 untimed frames'}, torch.stack(labels), list(eng.long_memories_indexes)
+
+
+def check_against_oracle(slot, frames_dev, mask_dev, num_objs, oracle_labels, oracle_indexes):
+    """The timed path against the checker: the first group slot runs the clip the CPU oracle just ran (every clip of the group is that
+    clip), same protocol (gap 1: the bank fills to N = 8 and evicts), free-running, and its delivered masks are compared with the
+    oracle's frame by frame.  Outside every timed region; a line whose masks disagree is not printed."""
+    G, n = slot.B, int(oracle_labels.shape[0])
+    slot.start([frames_dev[:n + 1]] * G, [mask_dev] * G, num_objs)
+    slot.engine.long_term_mem_gap = 1
+    while not slot.done:
+        slot.step()
+    slot.engine.synchronize()
+    got = slot.labels[:, 1:n + 1].cpu()
+    agree = [float((got[c] == oracle_labels).float().mean()) for c in range(G)]
+    per_frame = (got[0] == oracle_labels).float().flatten(1).mean(1)
+    if min(agree) < 0.97 or any(not torch.equal(got[0], got[c]) for c in range(1, G)):
+        raise SystemExit(f'bench.py: the HIP path disagrees with the oracle (label agreement per clip {agree})')
+    return {'against': 'oracle/ref_cpu.py (fp32 CPU port), same clip and protocol, free-running', 'frames': n, 'clips': G,
+            'label_agreement': round(min(agree), 5), 'worst_frame': round(float(per_frame.min()), 5),
+            'bank_indexes': list(slot.engine.long_memories_indexes(0)), 'bank_indexes_equal_the_oracles': list(slot.engine.long_memories_indexes(0)) == oracle_indexes}
 
 
 def attention_source_sha256() -> str:
@@ -451,7 +476,9 @@ def main():
                          **({'by_T': by_T} if len(by_T) > 1 else {})},
         }
         if world == 1 and not args.no_cpu_baseline and args.workload == 'davis17_480p_r50_N8':
-            out['cpu_baseline'] = cpu_baseline(*clips_host[0], VIDEO_HW)
+            out['cpu_baseline'], oracle_labels, oracle_indexes = cpu_baseline(*clips_host[0], VIDEO_HW)
+            if G > 1 and not args.host_frames:
+                out['check'] = check_against_oracle(slots[0], clips[0][0], clips[0][1], NUM_OBJS, oracle_labels, oracle_indexes)
         else:
             out['cpu_baseline'] = None
         print(json.dumps(out), flush=True)

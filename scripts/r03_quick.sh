@@ -1,5 +1,5 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-for a in "X=0" "RMEM_GEMM_DEEP_WGS=512" "RMEM_GEMM_DEEP_WGS=2048" "RMEM_GEMM_DEEP_WGS=0" "RMEM_GEMM_BIG=256" "RMEM_GEMM_BIG=64" "RMEM_GEMM_BIG_DEEP=0" "RMEM_GEMM_BIG_DEEP=128" "RMEM_GEMM_ROWRUN_BIG=0" "X=0"; do
-  echo "== $a: $(env $a timeout -k 10 200 python bench.py --no-cpu-baseline --roofline-launches 0 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'])" 2>&1 | tail -1)"
-done
+timeout -k 10 300 python bench.py --steps 20 --warmup 5 > gpurun_out/bench_check.json 2> gpurun_out/bench_check.err || { tail -20 gpurun_out/bench_check.err; exit 1; }
+python -c "
+import json; d=json.loads(open('gpurun_out/bench_check.json').read().strip().splitlines()[-1]); print(d['value'], d['check'], d['cpu_baseline'])"
