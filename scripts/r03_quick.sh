@@ -1,5 +1,8 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-timeout -k 10 300 python bench.py --steps 20 --warmup 5 > gpurun_out/bench_check.json 2> gpurun_out/bench_check.err || { tail -20 gpurun_out/bench_check.err; exit 1; }
-python -c "
-import json; d=json.loads(open('gpurun_out/bench_check.json').read().strip().splitlines()[-1]); print(d['value'], d['check'], d['cpu_baseline'])"
+for a in "X=0" "RMEM_NO_CHAIN=1" "X=0" "RMEM_NO_CHAIN=1"; do
+  echo "== swin $a: $(env $a timeout -k 10 300 python bench.py --no-cpu-baseline --roofline-launches 0 --workload lvos_720p_swinb_N12 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'])" 2>&1 | tail -1)"
+done
+for a in "X=0" "RMEM_NO_CHAIN=1"; do
+  echo "== cfg3 $a: $(env $a timeout -k 10 300 python bench.py --no-cpu-baseline --roofline-launches 0 --workload ytvos_720p_r50_N8_inject 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'])" 2>&1 | tail -1)"
+done
