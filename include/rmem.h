@@ -374,6 +374,9 @@ int rmem_image_ptrs_to_nhwc8(const float* const* img_ptrs, void* out, int images
 int rmem_stem_padded_size(int H, int W, int* Hp, int* Wp);
 int rmem_image_ptrs_to_nhwc4p(const float* const* img_ptrs, void* out_padded, int images, int H, int W, void* stream);
 int rmem_stem7x7s2(const void* x_padded, int images, int H, int W, const void* w, const float* bias, void* y, void* stream);
+/* The same followed by the 3x3 stride-2 pad-1 max-pool (encoders/resnet.py:136) in ONE pass: y_pooled [images][HP][WP][64], HP = (Ho - 1) / 2 + 1;
+ * the half-resolution map is never written.  Bit-identical to rmem_stem7x7s2 + rmem_maxpool3x3s2_nhwc_images. */
+int rmem_stem7x7s2_pool(const void* x_padded, int images, int H, int W, const void* w, const float* bias, void* y_pooled, void* stream);
 /* 3x3 stride-1 pad-1 convolution with C input and C output channels (C = 64 or 128) + bias (+ ReLU), read in place from rows kept in
  * LDS with the weights in registers: the second conv of the ResNet layer-1 / layer-2 bottlenecks (encoders/resnet.py:52-56) and the
  * decoder's conv_4x (decoders/fpn.py:54-58).  x NHWC [images][H][W][C], w [C][3][3][C] (rmem_conv2d_nhwc's layout), y like x.
@@ -491,6 +494,7 @@ int rmem_dwconv5x5_nhwc_f16(const void* x, const float* w_t, void* y, int H, int
 int rmem_image_ptrs_to_nhwc4p_f16(const float* const* img_ptrs, void* out_padded, int images, int H, int W, void* stream);
 int rmem_conv3x3_direct_f16(const void* x, int images, int H, int W, int C, const void* w, const float* bias, int relu, void* y, void* stream);
 int rmem_conv3x3_c64_direct_f16(const void* x, int images, int H, int W, const void* w, const float* bias, void* y, void* stream);
+int rmem_stem7x7s2_pool_f16(const void* x_padded, int images, int H, int W, const void* w, const float* bias, void* y_pooled, void* stream);
 int rmem_stem7x7s2_f16(const void* x_padded, int images, int H, int W, const void* w, const float* bias, void* y, void* stream);
 int rmem_image_ptrs_to_nhwc8_f16(const float* const* img_ptrs, void* out, int images, int H, int W, void* stream);
 int rmem_image_to_nhwc8_f16(const float* img_chw, void* out, int H, int W, void* stream);

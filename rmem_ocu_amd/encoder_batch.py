@@ -68,7 +68,7 @@ class BatchEncoder(_PtrInput):
         self._init_ptrs(B, device)
         # stem input: NHWC4 frames inside the zero border rmem_stem7x7s2 reads (zeroed once here, only the interior is ever written);
         # RMEM_STEM=rowrun keeps the 8-channel layout and the generic row-run GEMM form (experiments)
-        self.stem4 = os.environ.get('RMEM_STEM', 'direct') != 'rowrun' and 'stem.w4' in P
+        self.stem4 = os.environ.get('RMEM_STEM', 'pool') != 'rowrun' and 'stem.w4' in P          # RMEM_STEM = pool (default) | direct | rowrun
         if self.stem4:
             hp, wp = ops.stem_padded_size(H, W)
             self.img4 = torch.zeros(B, hp, wp, 4, dtype=dt16, device=device)
@@ -93,14 +93,18 @@ class BatchEncoder(_PtrInput):
         if self._prog is not None:
             return self._prog
         P, B, o = self.P, self.B, []
-        if self.stem4:
+        if self.stem4 and os.environ.get('RMEM_STEM', 'pool') == 'pool':     # stem + max-pool in one pass: the half-resolution map is never written
+            o.append(ops.image_ptrs_to_nhwc4p(self.img_ptrs, self.img4, H=self.H, W=self.W, images=B))
+            o.append(ops.stem7x7s2_pool(self.img4, P['stem.w4'], P['stem.b'], self.pool, H=self.H, W=self.W, images=B))
+        elif self.stem4:
             o.append(ops.image_ptrs_to_nhwc4p(self.img_ptrs, self.img4, H=self.H, W=self.W, images=B))
             o.append(ops.stem7x7s2(self.img4, P['stem.w4'], P['stem.b'], self.stem, H=self.H, W=self.W, images=B))
+            o.append(ops.maxpool3x3s2(self.stem, self.pool, H=self.H2, W=self.W2, C=64, images=B))
         else:
             o.append(self._input_op())
             o.append(self._conv(self.img8, P['stem.w'], P['stem.b'], self.stem, H=self.H, W=self.W, Cin=8, Cout=64, KH=7, KW=7, stride=2,
                                 pad=3, relu=True))
-        o.append(ops.maxpool3x3s2(self.stem, self.pool, H=self.H2, W=self.W2, C=64, images=B))
+            o.append(ops.maxpool3x3s2(self.stem, self.pool, H=self.H2, W=self.W2, C=64, images=B))
         x, (h, w), cin = self.pool, (self.H4, self.W4), 64
         outs = [self.x4, self.x8, self.x16]
         # layer 1 (256-channel maps at stride 4: HBM-bound at these batch sizes): a block's conv3 + shortcut is chained into the NEXT

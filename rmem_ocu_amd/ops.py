@@ -434,6 +434,19 @@ def conv3x3_c64_direct(x, w, bias, y, *, H, W, images) -> Op:
     return Op(_fn('rmem_conv3x3_c64_direct', dt), (_ptr(x), images, H, W, _ptr(w), _ptr(bias), _ptr(y)), 'rmem_conv3x3_c64_direct', (x, w, bias, y))
 
 
+def stem7x7s2_pool(x_padded, w4, bias, y_pooled, *, H, W, images) -> Op:
+    """y_pooled [images, HP*WP, 64] = maxpool3x3s2(relu(conv7x7 stride 2 of the padded NHWC4 frames + bias)) in one pass"""
+    _dev(x_padded, w4, bias, y_pooled)
+    dt = w4.dtype
+    hp, wp = stem_padded_size(H, W)
+    ho, wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    hq, wq = (ho - 1) // 2 + 1, (wo - 1) // 2 + 1
+    assert x_padded.dtype == dt and y_pooled.dtype == dt and bias.dtype == F32 and w4.is_contiguous() and w4.numel() == 64 * 256 and bias.numel() == 64
+    assert x_padded.numel() >= images * hp * wp * 4 and y_pooled.numel() >= images * hq * wq * 64
+    return Op(_fn('rmem_stem7x7s2_pool', dt), (_ptr(x_padded), images, H, W, _ptr(w4), _ptr(bias), _ptr(y_pooled)), 'rmem_stem7x7s2_pool',
+              (x_padded, w4, bias, y_pooled))
+
+
 def conv3x3_direct(x, w, bias, y, *, H, W, C, images, relu=False) -> Op:
     """y = act(conv3x3(x) + bias), C -> C channels (C = 64 or 128), stride 1, pad 1; x / y [images*H*W, C], w [C, 3, 3, C]"""
     _dev(x, w, bias, y)

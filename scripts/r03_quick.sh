@@ -1,8 +1,6 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-for a in "X=0" "RMEM_NO_CHAIN=1" "X=0" "RMEM_NO_CHAIN=1"; do
-  echo "== swin $a: $(env $a timeout -k 10 300 python bench.py --no-cpu-baseline --roofline-launches 0 --workload lvos_720p_swinb_N12 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'])" 2>&1 | tail -1)"
-done
-for a in "X=0" "RMEM_NO_CHAIN=1"; do
-  echo "== cfg3 $a: $(env $a timeout -k 10 300 python bench.py --no-cpu-baseline --roofline-launches 0 --workload ytvos_720p_r50_N8_inject 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'])" 2>&1 | tail -1)"
+for w in 1024 1536 2048; do echo "WGS=$w: $(RMEM_STEM_POOL_WGS=$w timeout -k 10 200 python scripts/stem_bench.py 2>&1 | grep 'one pass')"; done
+for a in "X=0" "RMEM_STEM_POOL_WGS=1024" "RMEM_STEM_POOL_WGS=1536" "X=0" "RMEM_STEM_POOL_WGS=1024"; do
+  echo "== $a: $(env $a timeout -k 10 200 python bench.py --no-cpu-baseline --roofline-launches 0 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'])" 2>&1 | tail -1)"
 done

@@ -31,7 +31,7 @@ def main():
     w4 = w4.to(dev)
     bias = torch.randn(64, generator=g).to(dev)
     hp, wp = ops.stem_padded_size(H, W)
-    new, old, conv_new, conv_old = [], [], [], []
+    new, old, conv_new, conv_old, fused, two = [], [], [], [], [], []
     for _ in range(args.sets):
         imgs = [torch.randn(3, H, W, generator=g).to(dev) for _ in range(B)]
         ptrs = torch.tensor([i.data_ptr() for i in imgs], dtype=torch.int64, device=dev)
@@ -41,10 +41,15 @@ def main():
         a = [ops.image_ptrs_to_nhwc4p(ptrs, x4, H=H, W=W, images=B), ops.stem7x7s2(x4, w4, bias, y, H=H, W=W, images=B)]
         b = [ops.image_ptrs_to_nhwc8(ptrs, x8, H=H, W=W, images=B),
              ops.conv2d(x8, w8, bias, y, H=H, W=W, Cin=8, Cout=64, KH=7, KW=7, stride=2, pad=3, relu=True, batch=B)]
+        Hq, Wq = (Ho - 1) // 2 + 1, (Wo - 1) // 2 + 1
+        yp = torch.empty(B, Hq * Wq, 64, dtype=bf, device=dev)
+        fused.append([ops.stem7x7s2_pool(x4, w4, bias, yp, H=H, W=W, images=B)])
+        two.append([a[1], ops.maxpool3x3s2(y, yp, H=Ho, W=Wo, C=64, images=B)])
         new.append(a); old.append(b); conv_new.append(a[1:]); conv_old.append(b[1:])
         new[-1].append(imgs)            # keep the frames alive
     for name, sets in (('layout + row-run GEMM (8 channels, K = 448)', old), ('  its GEMM alone', conv_old),
-                       ('layout + rmem_stem7x7s2 (4 channels, K = 256)', new), ('  rmem_stem7x7s2 alone', conv_new)):
+                       ('layout + rmem_stem7x7s2 (4 channels, K = 256)', new), ('  rmem_stem7x7s2 alone', conv_new),
+                       ('rmem_stem7x7s2 + rmem_maxpool3x3s2', two), ('rmem_stem7x7s2_pool (one pass)', fused)):
         sets = [[o for o in s if not isinstance(o, list)] for s in sets]
         for s in sets:
             ops.run(s)

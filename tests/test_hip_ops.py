@@ -690,6 +690,35 @@ def test_stem7x7s2_direct(dev, B, H, W, dt):
 
 
 @pytest.mark.parametrize('dt', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('B,H,W', [(2, 97, 129), (1, 480, 854), (3, 50, 262), (2, 481, 849), (1, 33, 15)])
+def test_stem_pool_fused(dev, B, H, W, dt):
+    """rmem_stem7x7s2_pool: the ResNet stem and its 3x3 stride-2 max-pool in one pass (encoders/resnet.py:131-136; the half-resolution
+    map is never written) against rmem_stem7x7s2 followed by rmem_maxpool3x3s2_nhwc: BIT-IDENTICAL, and against fp32 torch.  Odd / even
+    sizes, several strips and runs, a last strip narrower than a strip, a map narrower than one strip."""
+    from rmem_ocu_amd import ops
+    imgs = [seeded(90 + b, (3, H, W)).to(dev) for b in range(B)]
+    w = seeded(95, (64, 3, 7, 7), 1.0 / 147 ** 0.5).to(dt).float()
+    bias = seeded(96, (64,), 0.1)
+    x = torch.stack([i.cpu() for i in imgs]).to(dt).float()
+    conv = F.relu(F.conv2d(x, w, bias, stride=2, padding=3)).to(dt).float()
+    ref = F.max_pool2d(conv, 3, 2, 1)
+    Ho, Wo, Hq, Wq = conv.shape[2], conv.shape[3], ref.shape[2], ref.shape[3]
+    ptrs = torch.tensor([i.data_ptr() for i in imgs], dtype=torch.int64, device=dev)
+    hp, wp = ops.stem_padded_size(H, W)
+    x4 = torch.zeros(B, hp, wp, 4, dtype=dt, device=dev)
+    w4 = torch.zeros(64, 8, 8, 4, dtype=dt)
+    w4[:, :7, :7, :3] = w.permute(0, 2, 3, 1).to(dt)
+    w4 = w4.to(dev)
+    y = torch.zeros(B, Ho * Wo, 64, dtype=dt, device=dev)
+    p0, p1 = (torch.zeros(B, Hq * Wq, 64, dtype=dt, device=dev) for _ in range(2))
+    ops.run([ops.image_ptrs_to_nhwc4p(ptrs, x4, H=H, W=W, images=B), ops.stem7x7s2(x4, w4, bias.to(dev), y, H=H, W=W, images=B),
+             ops.maxpool3x3s2(y, p0, H=Ho, W=Wo, C=64, images=B), ops.stem7x7s2_pool(x4, w4, bias.to(dev), p1, H=H, W=W, images=B)])
+    torch.cuda.synchronize()
+    assert_close(p1.view(B, Hq, Wq, 64), ref.permute(0, 2, 3, 1), 1e-2, 'stem + pool')
+    assert torch.equal(p0, p1), f'{(p0 != p1).sum().item()} elements differ from stem7x7s2 + maxpool'
+
+
+@pytest.mark.parametrize('dt', [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize('C,relu', [(64, True), (128, False), (128, True)])
 @pytest.mark.parametrize('B,H,W', [(2, 31, 54), (1, 121, 213), (3, 17, 64), (2, 9, 130), (1, 3, 1)])
 def test_conv3x3_direct(dev, B, H, W, C, relu, dt):
