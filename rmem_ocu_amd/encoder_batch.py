@@ -74,7 +74,8 @@ class BatchEncoder(_PtrInput):
             self.img4 = torch.zeros(B, hp, wp, 4, dtype=dt16, device=device)
         else:
             self.img8 = e(B, H * W, 8)
-        self.stem = e(B, self.H2 * self.W2, 64)
+        self.stem_pool = self.stem4 and os.environ.get('RMEM_STEM', 'pool') == 'pool'
+        self.stem = None if self.stem_pool else e(B, self.H2 * self.W2, 64)      # (stem + max-pool in one pass: the half-resolution map does not exist)
         self.pool = e(B, M4, 64)
         self.x4 = [e(B, M4, 256), e(B, M4, 256)]
         self.x8 = [e(B, M8, 512), e(B, M8, 512)]
@@ -93,7 +94,7 @@ class BatchEncoder(_PtrInput):
         if self._prog is not None:
             return self._prog
         P, B, o = self.P, self.B, []
-        if self.stem4 and os.environ.get('RMEM_STEM', 'pool') == 'pool':     # stem + max-pool in one pass: the half-resolution map is never written
+        if self.stem_pool:     # stem + max-pool in one pass: the half-resolution map is never written
             o.append(ops.image_ptrs_to_nhwc4p(self.img_ptrs, self.img4, H=self.H, W=self.W, images=B))
             o.append(ops.stem7x7s2_pool(self.img4, P['stem.w4'], P['stem.b'], self.pool, H=self.H, W=self.W, images=B))
         elif self.stem4:
