@@ -94,62 +94,102 @@ class BatchEncoder(_PtrInput):
         if self._prog is not None:
             return self._prog
         P, B, o = self.P, self.B, []
-        if self.stem_pool:     # stem + max-pool in one pass: the half-resolution map is never written
-            o.append(ops.image_ptrs_to_nhwc4p(self.img_ptrs, self.img4, H=self.H, W=self.W, images=B))
-            o.append(ops.stem7x7s2_pool(self.img4, P['stem.w4'], P['stem.b'], self.pool, H=self.H, W=self.W, images=B))
-        elif self.stem4:
-            o.append(ops.image_ptrs_to_nhwc4p(self.img_ptrs, self.img4, H=self.H, W=self.W, images=B))
-            o.append(ops.stem7x7s2(self.img4, P['stem.w4'], P['stem.b'], self.stem, H=self.H, W=self.W, images=B))
-            o.append(ops.maxpool3x3s2(self.stem, self.pool, H=self.H2, W=self.W2, C=64, images=B))
-        else:
-            o.append(self._input_op())
-            o.append(self._conv(self.img8, P['stem.w'], P['stem.b'], self.stem, H=self.H, W=self.W, Cin=8, Cout=64, KH=7, KW=7, stride=2,
-                                pad=3, relu=True))
-            o.append(ops.maxpool3x3s2(self.stem, self.pool, H=self.H2, W=self.W2, C=64, images=B))
-        x, (h, w), cin = self.pool, (self.H4, self.W4), 64
-        outs = [self.x4, self.x8, self.x16]
-        # layer 1 (256-channel maps at stride 4: HBM-bound at these batch sizes): a block's conv3 + shortcut is chained into the NEXT
-        # block's conv1 in one launch (rmem_bneck_chain), so the 256-channel map is written once and not read back by that conv1
+        # RMEM_ENC_FRONT_SPLIT = n (experiment): stem and layer 1 run depth-first over n sub-batches of B / n frames (their maps are 211 MB
+        # per 16 frames: a sub-batch's maps may stay in the Infinity Cache between producer and consumer), layers 2-3 over all B frames
+        nsplit = int(os.environ.get('RMEM_ENC_FRONT_SPLIT', '1'))
+        if nsplit < 1 or B % nsplit:
+            nsplit = 1
         chain_on = os.environ.get('RMEM_NO_BNECK_CHAIN', '0') != '1'
         # layer 1 (64 channels); the 128-channel form (layer 2) is faster alone (57.3 -> 43.5 us) but takes a whole CU's LDS per workgroup
         # and measured neutral in the pipeline: opt-in (RMEM_DIRECT_CONV3_128=1)
         direct3 = () if os.environ.get('RMEM_NO_DIRECT_CONV3', '0') == '1' else ((64, 128) if os.environ.get('RMEM_DIRECT_CONV3_128') == '1' else (64,))
         blocks = [(li, bi) for li, nblk in enumerate(R50_BLOCKS, start=1) for bi in range(nblk)]
-        conv1_done = False
-        for idx, (li, bi) in enumerate(blocks):
-            stride = R50_STRIDES[li - 1]
-            planes = 64 * 2 ** (li - 1)
-            p = f'encoder.layer{li}.{bi}'
-            s = stride if bi == 0 else 1
-            ho, wo = _out(h, 3, s, 1), _out(w, 3, s, 1)
-            y = outs[li - 1][bi % 2]
-            a = self.mid_a[: B * h * w * planes]
-            bb = self.mid_b[: B * ho * wo * planes]
-            if not conv1_done:
-                o.append(self._conv(x, P[p + '.conv1.w'], P[p + '.conv1.b'], a, H=h, W=w, Cin=cin, Cout=planes, relu=True))
-            conv1_done = False
-            if planes in direct3 and s == 1:     # read in place from rows kept in LDS, weights in registers (bit-identical)
-                o.append(ops.conv3x3_direct(a, P[p + '.conv2.w'], P[p + '.conv2.b'], bb, H=h, W=w, C=planes, images=B, relu=True))
+        outs = [self.x4, self.x8, self.x16]
+        M4 = self.H4 * self.W4
+        if nsplit > 1 and getattr(self, 'mid_a128', None) is None:
+            self.mid_a128 = torch.empty(B * M4 * 128, dtype=self.pool.dtype, device=self.dev)     # layer 2's first conv1 output (see below)
+
+        def sub(t, per_image, b0, nb):            # images b0 .. b0 + nb of a [B, ...] buffer stored image-major
+            return t.reshape(-1)[b0 * per_image:(b0 + nb) * per_image]
+
+        def stem(b0, nb):
+            q = []
+            conv = lambda *a_, **kw: ops.conv2d(*a_, ws=self.conv_ws, batch=nb, **kw)       # noqa: E731
+            pool = sub(self.pool, M4 * 64, b0, nb)
+            if self.stem4:
+                hp, wp = ops.stem_padded_size(self.H, self.W)
+                img4 = sub(self.img4, hp * wp * 4, b0, nb)
+                q.append(ops.image_ptrs_to_nhwc4p(self.img_ptrs[b0:], img4, H=self.H, W=self.W, images=nb))
+                if self.stem_pool:     # stem + max-pool in one pass: the half-resolution map is never written
+                    q.append(ops.stem7x7s2_pool(img4, P['stem.w4'], P['stem.b'], pool, H=self.H, W=self.W, images=nb))
+                else:
+                    st = sub(self.stem, self.H2 * self.W2 * 64, b0, nb)
+                    q.append(ops.stem7x7s2(img4, P['stem.w4'], P['stem.b'], st, H=self.H, W=self.W, images=nb))
+                    q.append(ops.maxpool3x3s2(st, pool, H=self.H2, W=self.W2, C=64, images=nb))
             else:
-                o.append(self._conv(a, P[p + '.conv2.w'], P[p + '.conv2.b'], bb, H=h, W=w, Cin=planes, Cout=planes, KH=3, KW=3,
-                                    stride=s, pad=1, relu=True))
-            dual = (p + '.c3ds.w') in P
-            nxt = blocks[idx + 1] if idx + 1 < len(blocks) else None
-            if chain_on and li == 1 and nxt is not None:
-                pn = f'encoder.layer{nxt[0]}.{nxt[1]}'
-                n2 = 64 * 2 ** (nxt[0] - 1)
-                a_next = self.mid_a[: B * ho * wo * n2]
-                kw = dict(x2=x, H2=h, W2=w, Cin2=cin, stride2=s) if dual else dict(residual=x)
-                o.append(ops.bneck_chain(bb, P[p + ('.c3ds.w' if dual else '.conv3.w')], P[p + ('.c3ds.b' if dual else '.conv3.b')], y,
-                                         P[pn + '.conv1.w'], P[pn + '.conv1.b'], a_next, H=ho, W=wo, K1=planes, N2=n2, batch=B, **kw))
-                conv1_done = True
-            elif dual:     # conv3 + strided 1x1 shortcut as one GEMM: the shortcut tensor never exists
-                o.append(ops.conv1x1_dual(bb, x, P[p + '.c3ds.w'], P[p + '.c3ds.b'], y, H=ho, W=wo, Cin=planes, Cout=planes * 4,
-                                          H2=h, W2=w, Cin2=cin, stride2=s, relu=True, batch=B))
-            else:
-                o.append(self._conv(bb, P[p + '.conv3.w'], P[p + '.conv3.b'], y, H=ho, W=wo, Cin=planes, Cout=planes * 4,
-                                    residual=x, relu=True))
-            x, (h, w), cin = y, (ho, wo), planes * 4
+                img8 = sub(self.img8, self.H * self.W * 8, b0, nb)
+                st = sub(self.stem, self.H2 * self.W2 * 64, b0, nb)
+                q.append(ops.image_ptrs_to_nhwc8(self.img_ptrs[b0:], img8, H=self.H, W=self.W, images=nb))
+                q.append(conv(img8, P['stem.w'], P['stem.b'], st, H=self.H, W=self.W, Cin=8, Cout=64, KH=7, KW=7, stride=2, pad=3, relu=True))
+                q.append(ops.maxpool3x3s2(st, pool, H=self.H2, W=self.W2, C=64, images=nb))
+            return q
+
+        def run_blocks(idxs, b0, nb, x, hw, cin, conv1_done):
+            """the bottleneck blocks blocks[i], i in idxs, over images b0 .. b0 + nb; x: their input map (whole-batch buffer)"""
+            q = []
+            conv = lambda *a_, **kw: ops.conv2d(*a_, ws=self.conv_ws, batch=nb, **kw)       # noqa: E731
+            h, w = hw
+            for idx in idxs:
+                li, bi = blocks[idx]
+                stride = R50_STRIDES[li - 1]
+                planes = 64 * 2 ** (li - 1)
+                p = f'encoder.layer{li}.{bi}'
+                s = stride if bi == 0 else 1
+                ho, wo = _out(h, 3, s, 1), _out(w, 3, s, 1)
+                xs = sub(x, h * w * cin, b0, nb)
+                y = sub(outs[li - 1][bi % 2], ho * wo * planes * 4, b0, nb)
+                # (layer 2's first conv1 output lives in its own buffer when the front is split: the 128-channel rows of sub-batch 0
+                # would overlap the 64-channel rows of sub-batch 1 in mid_a)
+                abuf = self.mid_a128 if (nsplit > 1 and li == 2 and bi == 0) else self.mid_a
+                a = sub(abuf, h * w * planes, b0, nb)
+                bb = sub(self.mid_b, ho * wo * planes, b0, nb)
+                if not conv1_done:
+                    q.append(conv(xs, P[p + '.conv1.w'], P[p + '.conv1.b'], a, H=h, W=w, Cin=cin, Cout=planes, relu=True))
+                conv1_done = False
+                if planes in direct3 and s == 1:     # read in place from rows kept in LDS, weights in registers (bit-identical)
+                    q.append(ops.conv3x3_direct(a, P[p + '.conv2.w'], P[p + '.conv2.b'], bb, H=h, W=w, C=planes, images=nb, relu=True))
+                else:
+                    q.append(conv(a, P[p + '.conv2.w'], P[p + '.conv2.b'], bb, H=h, W=w, Cin=planes, Cout=planes, KH=3, KW=3, stride=s, pad=1,
+                                  relu=True))
+                dual = (p + '.c3ds.w') in P
+                nxt = blocks[idx + 1] if idx + 1 < len(blocks) else None
+                if chain_on and li == 1 and nxt is not None:
+                    # layer 1 (256-channel maps at stride 4: HBM-bound at these batch sizes): a block's conv3 + shortcut is chained into the
+                    # NEXT block's conv1 in one launch (rmem_bneck_chain): the 256-channel map is written once, not read back by that conv1
+                    pn = f'encoder.layer{nxt[0]}.{nxt[1]}'
+                    n2 = 64 * 2 ** (nxt[0] - 1)
+                    nbuf = self.mid_a128 if (nsplit > 1 and nxt == (2, 0)) else self.mid_a
+                    a_next = sub(nbuf, ho * wo * n2, b0, nb)
+                    kw = dict(x2=xs, H2=h, W2=w, Cin2=cin, stride2=s) if dual else dict(residual=xs)
+                    q.append(ops.bneck_chain(bb, P[p + ('.c3ds.w' if dual else '.conv3.w')], P[p + ('.c3ds.b' if dual else '.conv3.b')], y,
+                                             P[pn + '.conv1.w'], P[pn + '.conv1.b'], a_next, H=ho, W=wo, K1=planes, N2=n2, batch=nb, **kw))
+                    conv1_done = True
+                elif dual:     # conv3 + strided 1x1 shortcut as one GEMM: the shortcut tensor never exists
+                    q.append(ops.conv1x1_dual(bb, xs, P[p + '.c3ds.w'], P[p + '.c3ds.b'], y, H=ho, W=wo, Cin=planes, Cout=planes * 4,
+                                              H2=h, W2=w, Cin2=cin, stride2=s, relu=True, batch=nb))
+                else:
+                    q.append(conv(bb, P[p + '.conv3.w'], P[p + '.conv3.b'], y, H=ho, W=wo, Cin=planes, Cout=planes * 4, residual=xs, relu=True))
+                x, (h, w), cin = outs[li - 1][bi % 2], (ho, wo), planes * 4
+            return q, x, (h, w), cin, conv1_done
+
+        n1 = R50_BLOCKS[0]
+        nb = B // nsplit
+        for k in range(nsplit):
+            o += stem(k * nb, nb)
+            q, x, hw, cin, c1 = run_blocks(range(n1), k * nb, nb, self.pool, (self.H4, self.W4), 64, False)
+            o += q
+        q, x, hw, cin, c1 = run_blocks(range(n1, len(blocks)), 0, B, x, hw, cin, c1)
+        o += q
         self._prog = o
         return o
 
