@@ -186,8 +186,9 @@ class GroupRuntime:
 
     def mem_read_probe(self, T: int, layer: int = 0):
         """The long-term memory read of ``layer`` at bank size T as a stand-alone Op over this runtime's own buffers (bench.py's
-        roofline leg): same shapes, chunk plan, kernel and launch as prog_lstt's, but with its own chunk table (bank slots
-        0 .. T-1 of every clip in logical order) so the engine's device state is untouched.  Returns (op, algorithmic FLOPs)."""
+        roofline leg): same shapes, chunk plan and kernel as prog_lstt's (there the launch also carries the short-term attention's
+        workgroups, rmem_lstt_attn_pair_clips: not here, so that the timed launch does exactly the FLOPs returned), but with its own chunk
+        table (bank slots 0 .. T-1 of every clip in logical order) so the engine's device state is untouched.  Returns (op, algorithmic FLOPs)."""
         if not 1 <= T <= self.S:
             raise ops.RmemError(f'mem_read_probe: T = {T} outside 1..{self.S}')
         rows, n = self._chunk_rows([list(range(T)) for _ in range(self.B)])

@@ -2,7 +2,8 @@
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/r03y
 mkdir -p $O
-timeout -k 10 900 python -m pytest tests/test_hip_engine.py -m gpu -q -x -s -k "cfg5_swin" > $O/t.log 2>&1
+timeout -k 10 1000 python -m pytest tests -m gpu -q > $O/gpu_tests_head.log 2>&1
 rc=$?
-grep -v "^$" $O/t.log | tail -12 | cut -c1-300
-exit $rc
+tail -3 $O/gpu_tests_head.log
+[ $rc -ne 0 ] && exit $rc
+timeout -k 10 300 python bench.py --steps 20 --warmup 5 | cut -c1-120
