@@ -402,6 +402,17 @@ int rmem_logits_post(const float* logits_nhwc, int ldl, int num_classes, int kee
 int rmem_logits_post_images(const float* logits_nhwc, int images, int ldl, int num_classes, int keep_max_id, int Hi, int Wi,
                             int Ho, int Wo, int align_corners, float* out_nchw, unsigned char* label_u8,
                             float* label_f32, void* stream);
+/* Identity-bank embedding straight from a label map, without the one-hot tensor (models/aot.py:139-147 patch_wise_id_bank applied to
+ * one_hot(mask), engines/aot_engine.py:208-232): label [images][Hs][Ws] (uint8, or fp32 with label_is_f32) is resized to the network
+ * size H x W (nearest, as rmem_label_to_onehot16 does) into the INTERIOR of label_scratch_u8 [images][Hpd][Wpd] (rmem_label_id_embed_scratch_size:
+ * a border of `pad` pixels all round and one more row below, which the caller fills with 255 ONCE and which is never written), then
+ *   out[pos][0..255] = bias + sum over the KH x KW window of pos of w[:, ky, kx, label]      (stride, pad as the conv; labels >= num_classes: 0)
+ * with w [256][KH][KW][16] (rmem_conv2d_nhwc's layout of the Cin-padded weight).  The one-hot MFMA operand is built in registers from
+ * the label bytes.  Same products as rmem_label_to_onehot16 + rmem_conv2d_nhwc, summed in another order (fp32). */
+int rmem_label_id_embed_scratch_size(int H, int W, int pad, int* Hpd, int* Wpd);
+int rmem_label_id_embed(const void* label, int label_is_f32, int images, int Hs, int Ws, int H, int W, int KH, int KW, int stride, int pad,
+                        int num_classes, const void* w, const float* bias, void* label_scratch_u8, void* out, void* stream);
+
 /* label map (uint8 or fp32) -> nearest resize -> one-hot + ignore channel, bf16 [Hd][Wd][16]
  * (utils/image.py:69-74; engines/aot_engine.py:208-224; managers/evaluator.py:518-522). */
 int rmem_label_to_onehot16(const void* label, int label_is_f32, int Hs, int Ws, int Hd, int Wd,
@@ -504,6 +515,7 @@ int rmem_maxpool3x3s2_nhwc_f16(const void* x, void* y, int H, int W, int C, void
 int rmem_maxpool3x3s2_nhwc_images_f16(const void* x, void* y, int images, int H, int W, int C, void* stream);
 int rmem_bilinear_nhwc_f16(const void* x, void* y, int Hi, int Wi, int Ho, int Wo, int C, int align_corners, void* stream);
 int rmem_bilinear_nhwc_images_f16(const void* x, void* y, int images, int Hi, int Wi, int Ho, int Wo, int C, int align_corners, void* stream);
+int rmem_label_id_embed_f16(const void* label, int label_is_f32, int images, int Hs, int Ws, int H, int W, int KH, int KW, int stride, int pad, int num_classes, const void* w, const float* bias, void* label_scratch_u8, void* out, void* stream);
 int rmem_label_to_onehot16_f16(const void* label, int label_is_f32, int Hs, int Ws, int Hd, int Wd, int num_classes, void* out, void* stream);
 int rmem_label_to_onehot16_images_f16(const void* label, int label_is_f32, int images, int Hs, int Ws, int Hd, int Wd, int num_classes, void* out, void* stream);
 int rmem_gated_attn_f16(const void* q, int ldq, const void* k_bank, long long k_slot_stride, int ldk, const void* v_bank, long long v_slot_stride, int ldv, const rmem_attn_chunk* chunks, int nchunks, int frames, int keys_per_frame, const float* pe_cur, const float* pe_mem, int Lq, int DV, const void* u_a, int ldua, const void* u_b, int ldub, int usplit, void* out, int ldo, float* attn_mass, const float* dw_w_t, int H, int W, void* workspace, void* stream);

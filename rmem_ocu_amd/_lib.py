@@ -104,6 +104,8 @@ SIGNATURES = {
     'rmem_logits_post': (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     'rmem_logits_post_images': (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     'rmem_label_to_onehot16': (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    'rmem_label_id_embed_scratch_size': (_i, [_i, _i, _i, C.POINTER(_i), C.POINTER(_i)]),
+    'rmem_label_id_embed': (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     'rmem_label_to_onehot16_images': (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     'rmem_evict_scores': (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp]),
     'rmem_resize_nearest_flip_f32': (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _vp]),
@@ -131,7 +133,7 @@ SIGNATURES = {
 
 # entry points with 16-bit operands exist twice: <name> (bfloat16) and <name>_f16 (IEEE half), same signature (include/rmem.h)
 F16_TWINS = ('rmem_conv2d_nhwc', 'rmem_mem_read_attn', 'rmem_mem_read_attn_clips', 'rmem_lstt_attn_pair_clips', 'rmem_layernorm256', 'rmem_layernorm', 'rmem_patch_merge_ln',
-             'rmem_window_attn', 'rmem_window_attn_images', 'rmem_patch_merge_ln_images', 'rmem_add16', 'rmem_add16_grouped', 'rmem_layernorm256_pair', 'rmem_lstt_chain_a', 'rmem_lstt_chain_b', 'rmem_lstt_chain_c', 'rmem_conv1x1_dual_nhwc', 'rmem_bneck_chain', 'rmem_image_ptrs_to_nhwc4p', 'rmem_stem7x7s2', 'rmem_stem7x7s2_pool', 'rmem_conv3x3_c64_direct', 'rmem_conv3x3_direct', 'rmem_linear_grouped',
+             'rmem_window_attn', 'rmem_window_attn_images', 'rmem_patch_merge_ln_images', 'rmem_add16', 'rmem_add16_grouped', 'rmem_layernorm256_pair', 'rmem_lstt_chain_a', 'rmem_lstt_chain_b', 'rmem_lstt_chain_c', 'rmem_conv1x1_dual_nhwc', 'rmem_bneck_chain', 'rmem_label_id_embed', 'rmem_image_ptrs_to_nhwc4p', 'rmem_stem7x7s2', 'rmem_stem7x7s2_pool', 'rmem_conv3x3_c64_direct', 'rmem_conv3x3_direct', 'rmem_linear_grouped',
              'rmem_groupnorm_nhwc', 'rmem_groupnorm_f32_nhwc', 'rmem_groupnorm_nhwc_images', 'rmem_groupnorm_head_nhwc_images',
              'rmem_gn_act_dwconv5x5_nhwc_images', 'rmem_gn_act_dwconv5x5_prestats_nhwc_images', 'rmem_gn_act_dwconv5x5_nhwc', 'rmem_dwconv5x5_nhwc', 'rmem_image_to_nhwc8',
              'rmem_image_to_nhwc8_images', 'rmem_image_ptrs_to_nhwc8', 'rmem_ingest_rgb8', 'rmem_maxpool3x3s2_nhwc', 'rmem_maxpool3x3s2_nhwc_images', 'rmem_bilinear_nhwc',

@@ -22,6 +22,8 @@ from __future__ import annotations
 
 from typing import Dict, List, Optional, Tuple
 
+import os
+
 import torch
 
 from . import ops
@@ -406,9 +408,16 @@ class GroupRuntime:
             return self._prog[key]
         P, B = self.P, self.B
         k, s, p = (17, 16, 8) if self.align else (16, 16, 0)
-        o = [ops.label_to_onehot16(labels, self.onehot, Hs=hs, Ws=ws, Hd=self.H, Wd=self.W, ncls=self.nc, images=B)]
-        o.append(self._conv(self.onehot, P['idbank.w'], P['idbank.b'], self.id_emb, H=self.H, W=self.W, Cin=16, Cout=D_MODEL,
-                            KH=k, KW=k, stride=s, pad=p))
+        if os.environ.get('RMEM_NO_LABEL_EMBED', '0') != '1':
+            # the one-hot operand of the id bank's conv is built in registers from the label bytes (csrc/idbank.hip): no one-hot tensor
+            if getattr(self, 'lab_net', None) is None:
+                self.lab_net = ops.label_id_embed_scratch(B, self.H, self.W, p, self.dev)
+            o = [ops.label_id_embed(labels, P['idbank.w'], P['idbank.b'], self.lab_net, self.id_emb, Hs=hs, Ws=ws, H=self.H, W=self.W, K=k,
+                                    stride=s, pad=p, ncls=self.nc, images=B)]
+        else:
+            o = [ops.label_to_onehot16(labels, self.onehot, Hs=hs, Ws=ws, Hd=self.H, Wd=self.W, ncls=self.nc, images=B)]
+            o.append(self._conv(self.onehot, P['idbank.w'], P['idbank.b'], self.id_emb, H=self.H, W=self.W, Cin=16, Cout=D_MODEL,
+                                KH=k, KW=k, stride=s, pad=p))
         self._prog[key] = o
         return o
 

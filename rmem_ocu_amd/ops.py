@@ -502,6 +502,27 @@ def label_to_onehot16(label, out, *, Hs, Ws, Hd, Wd, ncls=11, images=1) -> Op:
     return Op(_fn('rmem_label_to_onehot16_images', dt), args, 'rmem_label_to_onehot16', (label, out))
 
 
+def label_id_embed_scratch(images: int, H: int, W: int, pad: int, device) -> torch.Tensor:
+    """the bordered uint8 label map rmem_label_id_embed works in: [images, Hpd, Wpd], filled with 255 (the border stays that way)"""
+    hp, wp = C.c_int(0), C.c_int(0)
+    if _lib.lib().rmem_label_id_embed_scratch_size(H, W, pad, C.byref(hp), C.byref(wp)):
+        raise RmemError('rmem_label_id_embed_scratch_size: bad argument')
+    return torch.full((images, hp.value, wp.value), 255, dtype=torch.uint8, device=device)
+
+
+def label_id_embed(label, w, bias, scratch_u8, out, *, Hs, Ws, H, W, K, stride, pad, ncls=11, images=1) -> Op:
+    """label [images, Hs, Ws] uint8 / fp32 -> id embedding [images * Ho * Wo, 256] = bias + conv(one_hot(label at H x W), w) without the one-hot
+    tensor; w [256, K, K, 16]; scratch_u8 from label_id_embed_scratch(images, H, W, pad)"""
+    _dev(label, w, bias, scratch_u8, out)
+    dt = w.dtype
+    ho, wo = (H + 2 * pad - K) // stride + 1, (W + 2 * pad - K) // stride + 1
+    assert label.dtype in (torch.uint8, F32) and label.is_contiguous() and label.numel() >= images * Hs * Ws
+    assert w.is_contiguous() and w.numel() == 256 * K * K * 16 and bias.dtype == F32 and bias.numel() == 256 and out.dtype == dt
+    assert scratch_u8.dtype == torch.uint8 and scratch_u8.numel() >= images * (H + 2 * pad + 1) * (W + 2 * pad) and out.numel() >= images * ho * wo * 256
+    args = (_ptr(label), int(label.dtype == F32), images, Hs, Ws, H, W, K, K, stride, pad, ncls, _ptr(w), _ptr(bias), _ptr(scratch_u8), _ptr(out))
+    return Op(_fn('rmem_label_id_embed', dt), args, 'rmem_label_id_embed', (label, w, bias, scratch_u8, out))
+
+
 def resize_nearest_flip(src, dst, *, flip: bool) -> Op:
     """fp32 [..., Hs, Ws] -> nearest resize to dst's [..., Hd, Wd] (same leading planes), optionally flipped along W."""
     _dev(src, dst)

@@ -507,6 +507,45 @@ def test_label_onehot_and_id_bank(dev, synth_weights):
     assert_close(emb, ref, 1.5e-2, 'id emb')
 
 
+@pytest.mark.parametrize('dt', [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('images,hs,ws,H,W,K,stride,pad', [(1, 96, 128, 97, 129, 17, 16, 8), (3, 480, 854, 481, 849, 17, 16, 8), (2, 64, 96, 64, 96, 16, 16, 0),
+                                                          (8, 120, 160, 121, 161, 17, 16, 8)])
+def test_label_id_embed_without_onehot_tensor(dev, images, hs, ws, H, W, K, stride, pad, dt):
+    """rmem_label_id_embed: the id bank's conv with its one-hot operand built in registers from the label bytes (models/aot.py:139-147,
+    engines/aot_engine.py:208-232) against the two launches it replaces (rmem_label_to_onehot16 + rmem_conv2d_nhwc: the same
+    products in another summation order: equal up to the output rounding) and against fp32 torch; uint8 and fp32 labels, the ignore
+    label 255, labels beyond the class count, the Swin geometry (16 x 16, stride 16, no padding), several images."""
+    from rmem_ocu_amd import ops
+    g = torch.Generator().manual_seed(123)
+    lab = torch.randint(0, 11, (images, hs, ws), generator=g)
+    lab[:, : hs // 3, : ws // 2] = torch.randint(0, 4, (images, hs // 3, ws // 2), generator=g)
+    lab[:, 0:5, 0:7] = 255
+    lab[:, -3:, -9:] = 13                      # beyond the class count: contributes nothing
+    w = (seeded(130, (256, 11, K, K), 1.0 / K)).to(dt).float()
+    bias = seeded(131, (256,), 0.1)
+    near = F.interpolate(lab[:, None].float(), size=(H, W), mode='nearest')[:, 0].long()
+    onehot = torch.zeros(images, 11, H, W)
+    for c in range(11):
+        onehot[:, c] = (near == c).float()
+    ref = F.conv2d(onehot, w, bias, stride=stride, padding=pad)
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    ref = ref.permute(0, 2, 3, 1).reshape(images * Ho * Wo, 256)
+    wd = F.pad(w.permute(0, 2, 3, 1), (0, 5)).contiguous().to(dt).to(dev)
+    for labels in (lab.to(torch.uint8).to(dev), lab.float().to(dev)):
+        scratch = ops.label_id_embed_scratch(images, H, W, pad, dev)
+        out = torch.zeros(images * Ho * Wo, 256, dtype=dt, device=dev)
+        ops.run(ops.label_id_embed(labels, wd, bias.to(dev), scratch, out, Hs=hs, Ws=ws, H=H, W=W, K=K, stride=stride, pad=pad, images=images))
+        oh16 = torch.zeros(images * H * W, 16, dtype=dt, device=dev)
+        out2 = torch.zeros_like(out)
+        ops.run([ops.label_to_onehot16(labels, oh16, Hs=hs, Ws=ws, Hd=H, Wd=W, images=images),
+                 ops.conv2d(oh16, wd, bias.to(dev), out2, H=H, W=W, Cin=16, Cout=256, KH=K, KW=K, stride=stride, pad=pad, batch=images)])
+        torch.cuda.synchronize()
+        assert torch.equal(scratch[:, pad:pad + H, pad:pad + W].cpu().long(), near.clamp(max=255)) and int(scratch[:, -1].min()) == 255
+        assert_close(out, ref, 1e-2, 'id embedding')
+        d = (out.float() - out2.float()).abs()
+        assert d.max().item() <= 2.0 ** (-7 if dt == torch.bfloat16 else -10) * max(1.0, out2.float().abs().max().item()), d.max().item()
+
+
 def test_evict_scores(dev):
     from rmem_ocu_amd import ops
     lg = seeded(95, (1, 11, 25, 33))
