@@ -1,12 +1,14 @@
 #!/bin/bash
-# PMC passes over the direct 3x3 / stem kernels (where do the cycles of a tile go?)
+# PMC passes over one of the round-3 kernels (where do the cycles go?): usage r03_pmc_conv3.sh <bench script> <kernel name substring>
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/pmc3
 export TMPDIR=/tmp
-run() {  # name, counters, script, kernel
-  timeout -k 10 200 rocprofv3 --kernel-trace --pmc $2 --output-format csv -d gpurun_out/pmc3/$1 -o p -- python3 $3 --iters 2 --reps 3 > gpurun_out/pmc3/$1.log 2>&1 || { echo "pass $1 failed"; tail -5 gpurun_out/pmc3/$1.log; return 1; }
+S=${1:-scripts/idbank_bench.py}
+K=${2:-k_idbank_labels}
+run() {  # name, counters
+  timeout -k 10 200 rocprofv3 --kernel-trace --pmc $2 --output-format csv -d gpurun_out/pmc3/$1 -o p -- python3 $S > gpurun_out/pmc3/$1.log 2>&1 || { echo "pass $1 failed"; tail -5 gpurun_out/pmc3/$1.log; return 1; }
   f=$(find gpurun_out/pmc3/$1 -name "*counter_collection.csv" | head -1)
-  python3 - "$f" "$1" "$4" <<'PY'
+  python3 - "$f" "$1" "$K" <<'PY'
 import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 acc = collections.defaultdict(list)
@@ -19,9 +21,6 @@ for k, v in acc.items():
 PY
   rm -rf gpurun_out/pmc3/$1
 }
-for k in "scripts/conv3_bench.py k_conv3x3_c64" "scripts/stem_bench.py k_stem7x7s2"; do
-  set -- $k
-  run sq1 "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_LDS" $1 $2 &&
-  run sq2 "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU" $1 $2 &&
-  run grbm "GRBM_GUI_ACTIVE GRBM_COUNT" $1 $2 || exit 1
-done
+run sq1 "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_LDS" &&
+run sq2 "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU" &&
+run grbm "GRBM_GUI_ACTIVE GRBM_COUNT"
