@@ -1,4 +1,6 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-timeout -k 10 300 python -m pytest tests/test_hip_ops.py -m gpu -q -x -k "label_id_embed" 2>&1 | tail -2
-timeout -k 10 200 python scripts/idbank_bench.py 2>&1 | grep clips
+timeout -k 10 200 python scripts/idbank_bench.py 2>&1 | grep "id_embed"
+RMEM_IDB_PANEL_MAJOR=1 timeout -k 10 200 python scripts/idbank_bench.py 2>&1 | grep "id_embed"
+timeout -k 10 200 python scripts/idbank_bench.py 2>&1 | grep "id_embed"
+RMEM_IDB_PANEL_MAJOR=1 timeout -k 10 200 python scripts/idbank_bench.py 2>&1 | grep "id_embed"
