@@ -369,9 +369,15 @@ __device__ inline void buf_load_lds16(rsrc_t, lptr_t, int, int) {}
 // goes in soffset, and a lane whose tap is padding (or whose row is >= M) passes an out-of-range voffset, which the hardware
 // range check turns into a zero fill.  This removes ~90 of the ~110 instructions per k-step that the general form spends
 // on 64-bit address arithmetic and divergent tap bookkeeping (PMC: VALU busy 55 % vs MFMA busy 15 % on the 3x3 layers).
-template <bool IS1X1, bool SPLITK, int ST = 1, int BM = 64, int BN = 64, int MODE = 0>
+//
+// PC (producer / consumer, 512 threads): waves 4..7 only issue the DMA pieces and count them in, waves 0..3 only read fragments
+// and run the MFMAs.  An LDS-DMA piece costs its issuing wave ~176 cycles of issue time in a mixed phase (idbank.hip ablation),
+// 8 pieces per wave and k-step at 128x128 -- as much as the 512 MFMA cycles they feed; on separate waves the two overlap.
+template <bool IS1X1, bool SPLITK, int ST = 1, int BM = 64, int BN = 64, int MODE = 0, bool PC = false>
 __device__ __forceinline__ void conv_gemm_dma_body(const ConvParams& p, const int zslice) {
   constexpr bool FAST = MODE != 0;
+  constexpr int NT = PC ? 512 : 256;
+  static_assert(!PC || ST >= 2, "the producer / consumer form needs a ring");
   constexpr bool DUAL = MODE == 3;        // Y = act([x | x2 sampled] * Wcat^T + b): a bottleneck's conv3 and its strided 1x1 shortcut as one GEMM
   constexpr bool ROWRUN = MODE == 2;      // Cin % 64 != 0 (stem 7x7x8, id bank 17x17x16): the KW * Cin elements of one filter row are
                                           // contiguous in NHWC, so a filter row is walked as spr = ceil(KW * Cin / 64) k-steps
@@ -383,7 +389,9 @@ __device__ __forceinline__ void conv_gemm_dma_body(const ConvParams& p, const in
   __shared__ __attribute__((aligned(16))) char smem[ST * STAGE_BYTES];   // the ONLY shared object (epilogue staging aliases it)
 
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: LDS-DMA destinations stay in SGPRs
+  const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: LDS-DMA destinations stay in SGPRs
+  const bool loader = PC && wave_all >= 4;
+  const int wave = PC ? (wave_all & 3) : wave_all;      // index inside the role: piece rows for a loader, tile for a consumer
   const int wm = wave >> 1, wn = wave & 1;
   int tbx, tby;
   if (!tile_of_block(p, BM, tbx, tby)) return;          // (workgroup-uniform: surplus block of the XCD-aware grid)
@@ -566,30 +574,18 @@ __device__ __forceinline__ void conv_gemm_dma_body(const ConvParams& p, const in
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int fr = lane & 15, fc = lane >> 4;
-#pragma unroll
-  for (int i = 0; i < ST - 1; ++i)
-    if (kt0 + i < kt1) issue(kt0 + i, i);
-  int stage = 0;
-  for (int kt = kt0; kt < kt1; ++kt) {
-    if (ST == 1) {                                    // single buffer: other resident workgroups hide the load
-      if (kt > kt0) __builtin_amdgcn_s_barrier();     // everyone finished reading tile kt-1
-      if (!(p.debug & 2) || kt == kt0) issue(kt, 0);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-    } else {
-      // tile kt has landed once only the NA + NB DMA pieces per later tile (at most ST - 2 of them) are still outstanding for this wave
-      static_assert((ST - 2) * (NA + NB) <= 63, "vmcnt is a 6-bit counter");
-      switch (min(ST - 2, kt1 - 1 - kt)) {
-        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-        case 1: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA + NB) : "memory"); break;
-        case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (NA + NB)) : "memory"); break;
-        case 3: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ST >= 5 ? 3 * (NA + NB) : 0) : "memory"); break;
-        default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ST >= 6 ? 4 * (NA + NB) : 0) : "memory"); break;
-      }
-      __builtin_amdgcn_s_barrier();                     // everyone's pieces of tile kt landed; everyone finished reading tile kt-1
-      const int nxt = stage == 0 ? ST - 1 : stage - 1;  // slot of tile kt+ST-1 == slot of tile kt-1
-      if (kt + ST - 1 < kt1 && !(p.debug & 2)) issue(kt + ST - 1, nxt);
+  // tile kt has landed once only the NA + NB DMA pieces per later tile (at most ST - 2 of them) are still outstanding for this wave
+  auto wait_tile = [&](int kt) {
+    static_assert((ST - 2) * (NA + NB) <= 63, "vmcnt is a 6-bit counter");
+    switch (min(ST - 2, kt1 - 1 - kt)) {
+      case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+      case 1: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA + NB) : "memory"); break;
+      case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (NA + NB)) : "memory"); break;
+      case 3: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ST >= 5 ? 3 * (NA + NB) : 0) : "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ST >= 6 ? 4 * (NA + NB) : 0) : "memory"); break;
     }
+  };
+  auto compute = [&](int stage) {
     const e16* As = reinterpret_cast<const e16*>(smem + stage * STAGE_BYTES);
     const e16* Bs = As + BM * BK;
 #pragma unroll
@@ -612,7 +608,49 @@ __device__ __forceinline__ void conv_gemm_dma_body(const ConvParams& p, const in
           acc[i][j] = RMEM_MFMA_16x16x32(af[i], bfr[j], acc[i][j], 0, 0, 0);
       }
     }
+  };
+  if constexpr (PC) {
+    // both roles pass the same kt1 - kt0 barriers: barrier kt = "tile kt landed, tile kt-1 is no longer read"
+    if (loader) {
+#pragma unroll
+      for (int i = 0; i < ST - 1; ++i)
+        if (kt0 + i < kt1) issue(kt0 + i, i);
+      int stage = 0;
+      for (int kt = kt0; kt < kt1; ++kt) {
+        wait_tile(kt);
+        __builtin_amdgcn_s_barrier();
+        const int nxt = stage == 0 ? ST - 1 : stage - 1;
+        if (kt + ST - 1 < kt1) issue(kt + ST - 1, nxt);
+        stage = stage == ST - 1 ? 0 : stage + 1;
+      }
+    } else {
+      int stage = 0;
+      for (int kt = kt0; kt < kt1; ++kt) {
+        __builtin_amdgcn_s_barrier();
+        compute(stage);
+        stage = stage == ST - 1 ? 0 : stage + 1;
+      }
+    }
+  } else {
+#pragma unroll
+  for (int i = 0; i < ST - 1; ++i)
+    if (kt0 + i < kt1) issue(kt0 + i, i);
+  int stage = 0;
+  for (int kt = kt0; kt < kt1; ++kt) {
+    if (ST == 1) {                                    // single buffer: other resident workgroups hide the load
+      if (kt > kt0) __builtin_amdgcn_s_barrier();     // everyone finished reading tile kt-1
+      if (!(p.debug & 2) || kt == kt0) issue(kt, 0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    } else {
+      wait_tile(kt);
+      __builtin_amdgcn_s_barrier();                     // everyone's pieces of tile kt landed; everyone finished reading tile kt-1
+      const int nxt = stage == 0 ? ST - 1 : stage - 1;  // slot of tile kt+ST-1 == slot of tile kt-1
+      if (kt + ST - 1 < kt1 && !(p.debug & 2)) issue(kt + ST - 1, nxt);
+    }
+    compute(stage);
     stage = stage == ST - 1 ? 0 : stage + 1;
+  }
   }
   __syncthreads();                                     // all DMA drained (vmcnt(0) above) and all fragment reads done
   if (p.debug & 4) {                                   // timing experiment: keep the accumulators alive, store nothing
@@ -629,7 +667,7 @@ __device__ __forceinline__ void conv_gemm_dma_body(const ConvParams& p, const in
   constexpr int PPW = TM / 2;                          // passes per wave row
 #pragma unroll
   for (int pass = 0; pass < 2 * PPW; ++pass) {
-    if (wm == pass / PPW) {
+    if (!loader && wm == pass / PPW) {
 #pragma unroll
       for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
@@ -639,7 +677,7 @@ __device__ __forceinline__ void conv_gemm_dma_body(const ConvParams& p, const in
             Cs[(ii * 16 + fc * 4 + r) * CP + wn * (BN / 2) + j * 16 + fr] = acc[2 * (pass % PPW) + ii][j][r];
     }
     __syncthreads();
-    for (int vi = tid; vi < 32 * VPR; vi += 256) {
+    for (int vi = tid; vi < 32 * VPR; vi += NT) {
       const int row = vi / VPR, cv = vi - row * VPR;
       const int m = m0 + (pass / PPW) * (BM / 2) + (pass % PPW) * 32 + row;
       const int n = n0 + cv * 8;
@@ -674,6 +712,11 @@ __global__ __launch_bounds__(256) void k_conv_gemm_dma(ConvParams p) {
 template <bool IS1X1, int ST, int BM, int BN, int MODE>
 __global__ __launch_bounds__(256) void k_conv_gemm_dma_big(ConvParams p) {
   conv_gemm_dma_body<IS1X1, false, ST, BM, BN, MODE>(p, 0);
+}
+
+template <bool IS1X1, int ST, int MODE>
+__global__ __launch_bounds__(512) void k_conv_gemm_dma_pc(ConvParams p) {
+  conv_gemm_dma_body<IS1X1, false, ST, 128, 128, MODE, true>(p, 0);
 }
 
 // up to 4 GEMMs of identical shape (different operands) as ONE launch: blockIdx.z selects the operand set.  The per-layer
@@ -777,6 +820,28 @@ void launch_big(const ConvParams& pin, bool is1x1, int st, hipStream_t s) {
   if (xcd_on && grid.y > 1 && grid.x >= 16) {
     p.xcd_ny = (int)grid.y;
     grid = dim3(8 * ((grid.x + 7) / 8) * grid.y, 1, 1);
+  }
+  if constexpr (BM == 128 && BN == 128 && MODE == 1) {
+    // producer / consumer form (loader waves + MFMA waves), ring depth RMEM_GEMM_PC (0 = off).  Measured, 16 images / 8 clips per
+    // launch, bit-identical outputs: a 2-deep ring (64 KB, two workgroups = 16 waves per CU) takes the K >= 512 layers from
+    // 70.3 / 46.4 / 58.0 / 66.1 / 50.7 / 27.5 / 49.9 us to 57.7 / 38.7 / 49.6 / 60.6 / 42.9 / 21.1 / 44.2 us alone and the whole
+    // pipeline from 3371 to 3404 frames/s (three A/B pairs); 3- and 4-deep rings (one workgroup per CU) are as fast alone but
+    // lose 3 % in the pipeline, where the other streams' kernels want the LDS
+    static const int pc_env = getenv("RMEM_GEMM_PC") ? atoi(getenv("RMEM_GEMM_PC")) : 2;
+    const int pc = pc_env == 1 ? (st >= 3 ? 3 : 2) : pc_env;     // 1 = by shape: the few-tile deep-K problems keep the 3-deep ring
+    if (pc >= 2) {
+      if (pc >= 4) {
+        if (is1x1) hipLaunchKernelGGL((k_conv_gemm_dma_pc<true, 4, 1>), grid, dim3(512), 0, s, p);
+        else hipLaunchKernelGGL((k_conv_gemm_dma_pc<false, 4, 1>), grid, dim3(512), 0, s, p);
+      } else if (pc == 3) {
+        if (is1x1) hipLaunchKernelGGL((k_conv_gemm_dma_pc<true, 3, 1>), grid, dim3(512), 0, s, p);
+        else hipLaunchKernelGGL((k_conv_gemm_dma_pc<false, 3, 1>), grid, dim3(512), 0, s, p);
+      } else {
+        if (is1x1) hipLaunchKernelGGL((k_conv_gemm_dma_pc<true, 2, 1>), grid, dim3(512), 0, s, p);
+        else hipLaunchKernelGGL((k_conv_gemm_dma_pc<false, 2, 1>), grid, dim3(512), 0, s, p);
+      }
+      return;
+    }
   }
   if constexpr (BM == 128 && BN == 128) {
     if (st == 5) {        // 160 KB of LDS: one workgroup per CU with four k-steps (128 KB) in flight
@@ -972,7 +1037,10 @@ extern "C" int RMEM_API(rmem_conv1x1_dual_nhwc)(const rmem_conv_desc* d, const v
   if (big_thr > 0 && p.Cout >= 128 && p.K >= 256 && (long)((p.M + 127) / 128) * ((p.Cout + 127) / 128) >= big_thr) {
     dim3 grid((p.M + 127) / 128, (p.Cout + 127) / 128, 1);
     if (xcd_on && grid.y > 1 && grid.x >= 16) { p.xcd_ny = (int)grid.y; grid = dim3(8 * ((grid.x + 7) / 8) * grid.y, 1, 1); }
-    hipLaunchKernelGGL((k_conv_gemm_dma_big<true, 1, 128, 128, 3>), grid, dim3(256), 0, s, p);
+    static const int pc = getenv("RMEM_GEMM_PC_DUAL") ? atoi(getenv("RMEM_GEMM_PC_DUAL")) : 0;   // producer / consumer form, as launch_big
+    if (pc >= 3) hipLaunchKernelGGL((k_conv_gemm_dma_pc<true, 3, 3>), grid, dim3(512), 0, s, p);
+    else if (pc == 2) hipLaunchKernelGGL((k_conv_gemm_dma_pc<true, 2, 3>), grid, dim3(512), 0, s, p);
+    else hipLaunchKernelGGL((k_conv_gemm_dma_big<true, 1, 128, 128, 3>), grid, dim3(256), 0, s, p);
   } else {
     dim3 grid((p.M + 63) / 64, (p.Cout + 63) / 64, 1);
     if (xcd_on && grid.y > 1 && grid.x >= 16) { p.xcd_ny = (int)grid.y; grid = dim3(8 * ((grid.x + 7) / 8) * grid.y, 1, 1); }
