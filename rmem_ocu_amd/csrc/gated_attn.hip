@@ -397,12 +397,18 @@ __device__ __forceinline__ void pv_mma(const PvFrags& f, f32x16 (&acc)[2][4]) {
 // (chunk c of key row k at slot c ^ ((k & 3) << 2): the 32 lanes of a transposed-read half -- 4 key rows x 2 column groups
 // x 4 pieces of 8 bytes -- then cover all 64 banks once).  The swizzles are applied to the per-lane SOURCE address, the LDS side of a DMA is linear.
 // Waves = (query half qh) x (column half ch), 64 x 128 outputs each = 8 accumulator tiles of 32 x 32.
-template <int MODE, bool TIMED>
-__global__ __launch_bounds__(256) void k_gp_pv(GpParams p) {
+// PC (producer / consumer, 512 threads): waves 4..7 only issue the DMA pieces (12 per wave and tile) and count them in, waves 0..3
+// only read fragments and run the MFMAs -- with one workgroup per CU the issue time of the pieces otherwise comes straight out of
+// the MFMA waves' time (see gemm_conv.hip, k_conv_gemm_dma_pc).
+template <int MODE, bool TIMED, bool PC = false>
+__global__ __launch_bounds__(PC ? 512 : 256) void k_gp_pv(GpParams p) {
   constexpr int ST = 3, PB = QT * KT * 2, VB = KT * CW * 2, SB = PB + VB;
   __shared__ __attribute__((aligned(16))) char smem[ST * SB];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool loader = PC && wave_all >= 4;
+  const int wave = PC ? (wave_all & 3) : wave_all;      // index inside the role
   const int qh = wave >> 1, ch = wave & 1, lq = lane & 31, kg = lane >> 5;
   // XCD-aware decode (hardware deals block ids round-robin over 8 XCDs): ids congruent mod 8 walk (group, query tile,
   // value slice) with the value slice fastest, so one XCD's L2 sees few distinct P and V tiles at a time
@@ -514,15 +520,7 @@ __global__ __launch_bounds__(256) void k_gp_pv(GpParams p) {
     vbase[c] = (8 * kg + tq) * (CW * 2) + ((((col >> 3) ^ (tq << 2)) << 4) | ((col & 7) << 1));
   }
 
-  if (ntl > 0) issue(0);
-  if (ntl > 1) issue(1);
-  int stage = 0;
-  for (int j = 0; j < ntl; ++j) {
-    if (j + 1 < ntl) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    const int nxt = stage == 0 ? 2 : stage - 1;
-    if (j + 2 < ntl && !(p.debug & 2)) issue(nxt);
+  auto compute = [&](int stage) {
     const unsigned sb = smem_base + stage * SB;
     PvFrags fa, fb;
     pv_load<0>(sb, pa_off, vbase, fa);
@@ -534,7 +532,42 @@ __global__ __launch_bounds__(256) void k_gp_pv(GpParams p) {
     pv_load<3>(sb, pa_off, vbase, fb);
     pv_wait<10>(fa); if (mm) pv_mma(fa, acc);
     pv_wait<0>(fb); if (mm) pv_mma(fb, acc);
+  };
+  if constexpr (PC) {
+    // both roles pass the same ntl barriers: barrier j = "tile j landed, tile j - 1 is no longer read"
+    if (loader) {
+      if (ntl > 0) issue(0);
+      if (ntl > 1) issue(1);
+      int stage = 0;
+      for (int j = 0; j < ntl; ++j) {
+        if (j + 1 < ntl) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const int nxt = stage == 0 ? 2 : stage - 1;
+        if (j + 2 < ntl) issue(nxt);
+        stage = stage == 2 ? 0 : stage + 1;
+      }
+      return;
+    }
+    int stage = 0;
+    for (int j = 0; j < ntl; ++j) {
+      __builtin_amdgcn_s_barrier();
+      compute(stage);
+      stage = stage == 2 ? 0 : stage + 1;
+    }
+  } else {
+  if (ntl > 0) issue(0);
+  if (ntl > 1) issue(1);
+  int stage = 0;
+  for (int j = 0; j < ntl; ++j) {
+    if (j + 1 < ntl) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const int nxt = stage == 0 ? 2 : stage - 1;
+    if (j + 2 < ntl && !(p.debug & 2)) issue(nxt);
+    compute(stage);
     stage = stage == 2 ? 0 : stage + 1;
+  }
   }
 
   // slab[g][q][c]: accumulator row (r & 3) + 8 (r >> 2) + 4 kg is the query, the lane is the column
@@ -747,11 +780,16 @@ void launch_all(GpParams& p, const GpPlan& g, GpCombine& c, bool timed, double f
   const dim3 pg(p.nq * p.ncs * p.groups * p.nclips);
   constexpr int PM = MODE == 1 ? 1 : 0;
   const int slot = timed ? rmem_prof_begin(RMEM_PROF_GATED_PV, s, flops) : -1;      // rmem_gated_profile_start: bench.py's DeAOT roofline leg
+  // loader waves + MFMA waves (default; RMEM_GP_PC=0: every wave does both).  Measured at cfg 2, T = 9, 8 clips per launch: 610 -> 479 us
+  // per launch (671 -> 858 TFLOP/s), the DeAOT workload 1670 -> 1735 frames/s; same MFMA order, so the outputs are bit-identical
+  static const bool pc = !(getenv("RMEM_GP_PC") && atoi(getenv("RMEM_GP_PC")) == 0);
   if (slot >= 0) {
-    hipLaunchKernelGGL((k_gp_pv<PM, true>), pg, dim3(256), 0, s, p);
+    if (pc) hipLaunchKernelGGL((k_gp_pv<PM, true, true>), pg, dim3(512), 0, s, p);
+    else hipLaunchKernelGGL((k_gp_pv<PM, true>), pg, dim3(256), 0, s, p);
     rmem_prof_end(RMEM_PROF_GATED_PV, slot, s);
   } else {
-    hipLaunchKernelGGL((k_gp_pv<PM, false>), pg, dim3(256), 0, s, p);
+    if (pc) hipLaunchKernelGGL((k_gp_pv<PM, false, true>), pg, dim3(512), 0, s, p);
+    else hipLaunchKernelGGL((k_gp_pv<PM, false>), pg, dim3(256), 0, s, p);
   }
   if (c.dw) hipLaunchKernelGGL(k_gp_combine_dwconv, dim3(((c.W + CT_W - 1) / CT_W) * ((c.H + CT_H - 1) / CT_H), c.DV / CT_C, p.nclips), dim3(256), 0, s, c);
   else hipLaunchKernelGGL(k_gp_combine, dim3((unsigned)(((long)c.Lq * (c.DV / 8) + 255) / 256), 1, p.nclips), dim3(256), 0, s, c);
