@@ -889,7 +889,12 @@ extern "C" int RMEM_API(rmem_local_gated_attn_clips)(const void* q, int ldq, con
   GpParams p = {};
   p.q = (const e16*)q; p.ldq = ldq; p.k = (const e16*)k; p.ldk = ldk; p.v = (const e16*)v; p.ldv = ldv;
   p.lk = L;
-  const int want = 8;
+  // key ranges (= score workgroups per query tile and clip): 8 for a single clip; with several clips per launch the grid is full
+  // anyway and a workgroup's fixed prologue (Q fragments, window coordinates) is spread over more key tiles
+  // (8 clips, cfg 2: 8 -> 4 ranges, DeAOT workload 1757 -> 1782 frames/s)
+  static const int rows_env = getenv("RMEM_GP_LOCAL_ROWS") ? atoi(getenv("RMEM_GP_LOCAL_ROWS")) : 0;      // kernel experiments only
+  const int tiles_q = ((L + QT - 1) / QT) * nclips;
+  const int want = rows_env > 0 ? rows_env : max(2, min(8, (448 + tiles_q - 1) / tiles_q));
   p.per = ((L + want - 1) / want + KT - 1) / KT * KT;
   p.nrows = (L + p.per - 1) / p.per;
   const GpPlan g = plan(L, DV, 1, L, p.nrows, nclips);

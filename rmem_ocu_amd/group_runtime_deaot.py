@@ -19,6 +19,7 @@ The per-op arithmetic is DeAOTRuntime's (layers/transformer.py:1011-1249; citati
 """
 from __future__ import annotations
 
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -66,7 +67,11 @@ class GroupRuntimeDeAOT(GroupRuntime):
     def chunk_plan(self, T: int) -> Tuple[int, int]:
         if T > 32:
             raise ops.RmemError(f'memory bank of {T} frames exceeds the 32 frames the gated attention records mass for')
-        splits = max(1, min(4, 32 // T))
+        # table rows per memory frame: a row is one workgroup per query tile and clip in the score kernels, and every workgroup pays a
+        # fixed prologue (Q fragments, the temporal-PE bias through the matrix pipe, the row maxima) worth ~3 key tiles -- so rows are
+        # cut only as far as filling the GPU needs (~512 workgroups); with 8 clips per launch and T >= 5 a frame stays one row
+        wgs = ((self.L + 127) // 128) * T * self.B
+        splits = max(1, min(4, 32 // T, (512 + wgs - 1) // wgs))
         per = self._keys_per_chunk(splits)
         return splits, T * ((self.L + per - 1) // per)
 
@@ -123,6 +128,9 @@ class GroupRuntimeDeAOT(GroupRuntime):
         R = B * L
         frames = 1 if ref_mode else T
         _, nchunks = self.chunk_plan(frames)
+        # key ranges of the one-frame self-attention (score workgroups per query tile and clip): as few as still fill the GPU
+        tiles_q = ((L + 127) // 128) * B
+        self_rows = int(os.environ.get('RMEM_GP_SELF_ROWS', max(2, min(8, (448 + tiles_q - 1) // tiles_q))))
         for i in range(self.NL):
             d = f'g{i}'
             xin = self.xc0 if i == 0 else self.xc
@@ -147,7 +155,7 @@ class GroupRuntimeDeAOT(GroupRuntime):
                                       y=self.xn.view(-1)[C:], ldy=2 * C))
             o.append(self._lin(self.xn, d + '.self', self.sqvu, 2 * C, SQVU, relu=3, act_begin=D_ATT))
             o.append(ops.gated_attn(self.sqvu, self.sqvu, self.sqvu.view(-1)[D_ATT:], self.sqvu.view(-1)[D_ATT + E2:], self.g2, self._gp(),
-                                    Lq=L, DV=E2, ldq=SQVU, ldk=SQVU, ldv=SQVU, ldua=SQVU, ldo=E2, nchunks=8, frames=1, keys_per_frame=L,
+                                    Lq=L, DV=E2, ldq=SQVU, ldk=SQVU, ldv=SQVU, ldua=SQVU, ldo=E2, nchunks=self_rows, frames=1, keys_per_frame=L,
                                     dw=P[d + '.self_dw.w'], H=self.H16, W=self.W16, nclips=B))
             o += self._tail(d + '.self', self.xc)
         for c in range(B):      # GroupNorm1D(512, 2) over fp32 rows, statistics per clip (760-808)

@@ -65,6 +65,8 @@ CONV_CASES = [
     (481, 849, 16, 256, 17, 16, 8, False, None, False),      # id bank at cfg-2 size: split-K, K = 4624
     (1674, 1, 256, 256, 1, 1, 0, False, 'f32', True),
     (130, 131, 64, 192, 3, 1, 1, True, None, False),         # 128x128 tiles with a ragged last row tile and a half-empty column tile
+    (130, 131, 512, 192, 1, 1, 0, True, 'bf16', False),      # K >= 512: producer / consumer 128x128 form (loader waves + MFMA waves), 1x1,
+                                                             # ragged last row tile, half-empty column tile, residual epilogue
     (45, 52, 16, 64, 5, 3, 2, False, None, False),           # row-run form with 2 k-steps per filter row (KW * Cin = 80), stride 3
     (37, 41, 24, 64, 3, 2, 1, True, None, False),            # Cin = 24: neither fast form (row run of 72 elements is allowed: spr = 2)
 ]
