@@ -1,3 +1,5 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-timeout -k 10 200 python scripts/idbank_bench.py 2>&1 | grep "id_embed"
+mkdir -p gpurun_out/q
+timeout -k 10 600 python -m pytest tests/test_hip_ops.py -x -q -m gpu -k "producer_consumer or conv2d" > gpurun_out/q/t.txt 2>&1 || { tail -30 gpurun_out/q/t.txt; exit 1; }
+tail -3 gpurun_out/q/t.txt

@@ -1,6 +1,8 @@
 """GPU parity of every librmem_hip.so kernel against the CPU oracle / torch fp32 primitives,
 on the same seeded inputs (inputs are rounded to bf16 first, so the comparison isolates the
 kernel's own arithmetic: bf16 operands, fp32 accumulation, bf16 or fp32 store)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -1368,3 +1370,23 @@ def test_resize_nearest_flip(dev):
             torch.cuda.synchronize()
             ref = F.interpolate(x.flip(3) if fl else x, size=(hd, wd), mode='nearest')
             assert torch.equal(dst.cpu(), ref), (c, hs, ws, hd, wd, fl)
+
+
+def test_producer_consumer_forms_are_bit_identical(dev):
+    """The loader-wave forms of the 128x128 GEMM tile (k_conv_gemm_dma_pc, default for K >= 512 layers) and of the gated attention's
+    P.V kernel keep the one-role kernels' MFMA order: scripts/pc_check.py prints output hashes; the switches are read once per
+    process, so each setting runs in a child process (one at a time)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for name, env in (('one_role', {'RMEM_GEMM_PC': '0', 'RMEM_GP_PC': '0'}), ('default', {}), ('ring3', {'RMEM_GEMM_PC': '3'})):
+        e = dict(os.environ)
+        e.pop('RMEM_GEMM_PC', None), e.pop('RMEM_GP_PC', None)
+        e.update(env)
+        r = subprocess.run([sys.executable, os.path.join(root, 'scripts', 'pc_check.py')], env=e, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[name] = [l for l in r.stdout.splitlines() if l and l[0].isalnum()]
+        assert len(outs[name]) == 9, r.stdout
+    assert outs['default'] == outs['one_role']
+    assert outs['ring3'] == outs['one_role']
