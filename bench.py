@@ -75,8 +75,10 @@ WORKLOADS = {
     # the model the reference's shipped eval_vost.sh runs: R50-DeAOTL, bank 1 + 8 (configs/models/r50_deaotl.py:8-9), cfg-2 geometry
     'davis17_480p_r50deaot_N9': dict(model='r50_deaotl', video=(480, 854), lengths=(80,), clips_per_gpu=64, objs=3, former=1, latter=8, net=None),
     # cfg 5 geometry: 720p, Swin-B, bank N = 12 (1 + 11), align_corners False -> network size = video size (multiple of 16)
+    # (ONE group of 8 clips in flight: the Swin encoder's 16-frame GEMMs fill the GPU by themselves, and three groups' kernels running
+    # side by side slow each other down more than they fill -- 8 / 16 / 24 clips in flight: 529-546 / 476 / 466 frames/s, profiles/r03)
     'lvos_720p_swinb_N12': dict(model='swinb_aotl', video=(720, 1280), lengths=(150,), clips_per_gpu=4, objs=2, former=1, latter=11, net=(720, 1280),
-                                dtype='fp16'),
+                                dtype='fp16', in_flight=8),
     # cfg 2 geometry with a skewed clip list (mixed lengths): exercises the feeder's length buckets and queue
     'davis17_480p_r50_N8_mixed': dict(model='r50_aotl', video=(480, 854), lengths=(100, 80, 60, 40), clips_per_gpu=64, objs=3, former=1, latter=7, net=None),
     # cfg 3 geometry and protocol: 720p -> network size 577x1041 (HW = 2442), 36-frame clips, a NEW OBJECT's mask arrives at frame
@@ -185,7 +187,8 @@ def parse_args(argv=None):
                     help="what one step propagates: 'batch' (default) = one frame of each of the --clips-in-flight clips, the batch this "
                          "engine advances together (24 frames); 'frame' = one frame of one clip (rounds 1-2: --steps 20 is then 5 group steps "
                          'from an idle GPU, a fill / drain transient rather than a rate)')
-    ap.add_argument('--clips-in-flight', type=int, default=int(os.environ.get('RMEM_CLIPS_IN_FLIGHT', 24)))
+    ap.add_argument('--clips-in-flight', type=int, default=None,
+                    help='clips advancing together on this GPU (default: RMEM_CLIPS_IN_FLIGHT, else the workload\'s own, else 24 = three groups of 8)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--workload', default='davis17_480p_r50_N8', choices=sorted(WORKLOADS))
     ap.add_argument('--no-graphs', action='store_true')
@@ -250,6 +253,8 @@ def main():
     model.load_state_dict(synth_state_dict(0, encoder=cfg.MODEL_ENCODER, model='deaot' if deaot else 'aot'))
     net_hw = wl['net'] or network_size(*VIDEO_HW)
 
+    if args.clips_in_flight is None:
+        args.clips_in_flight = int(os.environ.get('RMEM_CLIPS_IN_FLIGHT', wl.get('in_flight', 24)))
     C = max(1, args.clips_in_flight)
     G = args.clips_per_group           # GroupEngine covers R50-AOTL, SwinB-AOTL and R50-DeAOTL
     # ---- the job: clips_per_gpu * world clips, lengths cycling through wl['lengths'] (whole groups per length) ----
