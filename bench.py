@@ -75,10 +75,8 @@ WORKLOADS = {
     # the model the reference's shipped eval_vost.sh runs: R50-DeAOTL, bank 1 + 8 (configs/models/r50_deaotl.py:8-9), cfg-2 geometry
     'davis17_480p_r50deaot_N9': dict(model='r50_deaotl', video=(480, 854), lengths=(80,), clips_per_gpu=64, objs=3, former=1, latter=8, net=None),
     # cfg 5 geometry: 720p, Swin-B, bank N = 12 (1 + 11), align_corners False -> network size = video size (multiple of 16)
-    # (ONE group of 8 clips in flight: the Swin encoder's 16-frame GEMMs fill the GPU by themselves, and three groups' kernels running
-    # side by side slow each other down more than they fill -- 8 / 16 / 24 clips in flight: 529-546 / 476 / 466 frames/s, profiles/r03)
     'lvos_720p_swinb_N12': dict(model='swinb_aotl', video=(720, 1280), lengths=(150,), clips_per_gpu=4, objs=2, former=1, latter=11, net=(720, 1280),
-                                dtype='fp16', in_flight=8),
+                                dtype='fp16'),
     # cfg 2 geometry with a skewed clip list (mixed lengths): exercises the feeder's length buckets and queue
     'davis17_480p_r50_N8_mixed': dict(model='r50_aotl', video=(480, 854), lengths=(100, 80, 60, 40), clips_per_gpu=64, objs=3, former=1, latter=7, net=None),
     # cfg 3 geometry and protocol: 720p -> network size 577x1041 (HW = 2442), 36-frame clips, a NEW OBJECT's mask arrives at frame
