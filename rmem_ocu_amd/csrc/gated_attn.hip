@@ -56,6 +56,9 @@ struct GpParams {
   int DV, nq, ncs, groups, rows_per_group;
   float* slabs;
   int debug;               // kernel experiments only (RMEM_GP_DEBUG): 1 = no MFMA, 2 = no refills after the first stages
+  // softmax reference from a SAMPLE of the keys (see launch_all): sample = pass 0 visits one or two key tiles per table row only;
+  // flag = launch-wide word pass 1 sets when a score exceeds the sampled reference by more than 2^64; gate = run only if *gate != 0
+  int sample; unsigned* flag; const unsigned* gate;
   // several clips of identical shape in one launch: clip c's queries / one-frame keys and values / relative logits sit c * {q, k, v,
   // rel}_cs elements further (the bank is addressed through global slot indexes in the table: k_cs = v_cs = 0 there), its table
   // rows at rows + c * rows_cs, its share of the workspace c * ws_cs BYTES further
@@ -109,6 +112,7 @@ __global__ __launch_bounds__(256) void k_gp_scores(GpParams p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int qh = wave >> 1, kh = wave & 1, lq = lane & 31, kg = lane >> 5;
+  if (p.gate && *p.gate == 0) return;            // exact two-pass redo: only when the sampled reference was too low somewhere
   gp_select_clip(p, blockIdx.z);
   const int q0 = blockIdx.x * QT;
   const GpRow row = get_row<MODE>(p, blockIdx.y);
@@ -195,9 +199,21 @@ __global__ __launch_bounds__(256) void k_gp_scores(GpParams p) {
     if (key_hi <= row.kb || key_lo >= row.kb + row.kn) { t_lo = 0; t_hi = 0; }
     if (t_hi < t_lo) t_hi = t_lo;
   }
+  if (PASS == 0 && p.sample) {
+    if (MODE == 2) {
+      // the two key tiles that hold the query tile's OWN positions: a query's own key is always inside its window, so every
+      // query gets a real score of its own as reference (rows are multiples of 64 keys and q0 of 128)
+      const int s_lo = max(t_lo, (q0 - row.kb) / KT), s_hi = min(t_hi, (q0 + QT - row.kb + KT - 1) / KT);
+      t_lo = q0 + QT > row.kb ? s_lo : t_hi;
+      t_hi = max(t_lo, s_hi);
+    } else {
+      t_hi = min(t_hi, t_lo + 1);                // no mask: the first tile of the row
+    }
+  }
   if (p.debug & 4) t_hi = t_lo;
   e16* Pq = p.P + (long)row.t * p.Lp + row.kb;       // + q * ldp + key index inside the row
   float mx[2][16];       // PASS 0: running maxima of this lane's rows
+  float gmax = NEG_BIG;                  // PASS 1: largest score above the reference this lane has seen (guard of the sampled reference)
   float ls4[4] = {0.f, 0.f, 0.f, 0.f};   // PASS 1: row-sum pieces of rows 16 i + (lane >> 2), keys 8 (lane & 3) .. + 7 of every tile
 #pragma unroll
   for (int b = 0; b < 2; ++b)
@@ -283,7 +299,10 @@ __global__ __launch_bounds__(256) void k_gp_scores(GpParams p) {
           sv += rl[b][r] * LOG2E;
         }
         if (PASS == 0) mx[b][r] = fmaxf(mx[b][r], ok ? sv : NEG_BIG);
-        else pst[r32 * 32 + lq] = (e16)(ok ? __builtin_amdgcn_exp2f(sv) : 0.f);
+        else {
+          pst[r32 * 32 + lq] = (e16)(ok ? __builtin_amdgcn_exp2f(sv) : 0.f);
+          gmax = fmaxf(gmax, ok ? sv : NEG_BIG);
+        }
       }
       if (PASS == 1) {
         // the wave's 32 x 32 block leaves as 16-byte pieces: lane -> (row 16 i + (lane >> 2), keys 8 (lane & 3) .. + 7).
@@ -327,6 +346,9 @@ __global__ __launch_bounds__(256) void k_gp_scores(GpParams p) {
       if (hf == 0) { red[0][rrow] = m; red[1][rrow] = NEG_BIG; }
     }
   } else {
+    // a probability above 2^64 (or a reference nobody sampled: NEG_BIG) means the sampled reference was far too low for fp32 sums:
+    // ask for the exact two-pass redo (the NaN of an inf - inf would not compare, but an inf score does before it gets there)
+    if (p.flag && !(gmax <= 64.f)) atomicOr(p.flag, 1u);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       float v = ls4[i];
@@ -752,7 +774,7 @@ GpPlan plan(int Lq, int DV, int frames, int keys_per_frame, int nrows, int nclip
   g.off_l = al((size_t)nrows * g.Lqp * 4);
   g.off_p = g.off_l + al((size_t)nrows * g.Lqp * 4);
   g.off_s = g.off_p + al((size_t)g.Lqp * g.ldp * 2);
-  g.total = g.off_s + al((size_t)g.groups * g.Lqp * DV * 4);
+  g.total = g.off_s + al((size_t)g.groups * g.Lqp * DV * 4) + 256;      // + the launch-wide guard word (clip 0's block carries it)
   return g;
 }
 
@@ -775,6 +797,23 @@ int check_common(const void* q, int ldq, const void* k, int ldk, const void* v, 
 template <int MODE>
 void launch_all(GpParams& p, const GpPlan& g, GpCombine& c, bool timed, double flops, hipStream_t s) {
   const dim3 sg(p.nq, p.nrows, p.nclips);
+  // Softmax reference.  The exact row maximum costs a whole pass over Q K^T (pass 0: 40 % of the score side).  Softmax is invariant
+  // under the reference, and bf16 / fp32 keep their relative precision whatever the offset, so pass 0 only SAMPLES the keys (one tile
+  // per table row; window mode: the tiles holding the queries' own positions -- always inside their window): P = 2^(S - m_sample) may
+  // exceed 1, which is harmless until it leaves the fp32 range.  Pass 1 raises a flag when any score lies more than 2^64 above the
+  // reference (or no reference was sampled); the exact pass 0 + pass 1 follow in the same stream and return at once unless it is set
+  // (graph-capturable: no host decision).  RMEM_GP_SAMPLE=0: always the exact two passes.
+  static const bool sample = !(getenv("RMEM_GP_SAMPLE") && atoi(getenv("RMEM_GP_SAMPLE")) == 0);
+  unsigned* flag = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(p.mpart) + g.total - 256);
+  if (sample) {
+    (void)hipMemsetAsync(flag, 0, 4, s);      // (a failure surfaces in rmem_check_launch after the launches)
+    GpParams ps = p;
+    ps.sample = 1; ps.flag = flag; ps.gate = nullptr;
+    hipLaunchKernelGGL((k_gp_scores<MODE, 0>), sg, dim3(256), 0, s, ps);
+    hipLaunchKernelGGL((k_gp_scores<MODE, 1>), sg, dim3(256), 0, s, ps);
+    p.gate = flag;
+  }
+  p.sample = 0; p.flag = nullptr;
   hipLaunchKernelGGL((k_gp_scores<MODE, 0>), sg, dim3(256), 0, s, p);
   hipLaunchKernelGGL((k_gp_scores<MODE, 1>), sg, dim3(256), 0, s, p);
   const dim3 pg(p.nq * p.ncs * p.groups * p.nclips);

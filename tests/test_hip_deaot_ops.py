@@ -159,6 +159,35 @@ def test_gated_attn_extreme_logits(dev):
     assert_close(out[7], v[0, 100], 1e-2, 'dominant key row')
 
 
+@pytest.mark.parametrize('scale', [5, 8, 30])
+def test_gated_attn_sampled_reference_and_its_fallback(dev, scale):
+    """The softmax reference comes from a sample of the keys (first tile of every table row).  A dominant key OUTSIDE the sample:
+    scale 5 leaves it 2^58 above the sampled reference (probabilities far above 1, no fallback); scale 8 (2^93) and scale 30 (2^348:
+    the probability itself overflows) are beyond the 2^64 guard, so pass 1 raises the guard word and the exact two-pass redo runs --
+    all must give the softmax of the reference implementation.  Three frames, ragged tiles, with the per-frame probability mass."""
+    from rmem_ocu_amd import ops
+    T, L = 3, 200
+    q, k = rb(seeded(81, (L, 128))), rb(seeded(82, (T, L, 128)))
+    q[11] = k[1, 150] * scale                   # key 150 of frame 1: third tile of its row
+    q[12] = 0
+    v, u = rb(seeded(83, (T, L, 1024))), rb(seeded(84, (L, 1024)))
+    rows = frame_rows(T, L, 1)
+    ws = ops.gated_workspace(L, 1024, T, L, len(rows), dev)
+    out = torch.zeros(L, 1024, dtype=BF16, device=dev)
+    mass = torch.zeros(L, T, dtype=F32, device=dev)
+    ops.run(ops.gated_attn(q.to(BF16).to(dev), k.to(BF16).to(dev), v.to(BF16).to(dev), u.to(BF16).to(dev), out, ws, Lq=L, DV=1024, ldq=128,
+                           ldk=128, ldv=1024, ldua=1024, ldo=1024, k_slot_stride=L * 128, v_slot_stride=L * 1024, chunks=chunk_table(rows, dev),
+                           nchunks=len(rows), frames=T, keys_per_frame=L, mass=mass))
+    torch.cuda.synchronize()
+    ref, mass_ref = ref_gated(q.to(dev), k.to(dev), v.to(dev), u.to(dev))
+    assert torch.isfinite(out.float()).all()
+    assert_close(out, ref, 2e-2, f'sampled reference, scale {scale}')
+    assert_close(out[11], (v[1, 150] * u[11]).to(dev), 2e-2, 'dominant key row')
+    assert (mass - mass_ref).abs().max().item() < 4e-3
+    flag = ws.view(torch.int32)[ops._lib.lib().rmem_gated_attn_workspace_bytes(L, 1024, T, L, len(rows)) // 4 - 64].item()
+    assert flag == (0 if scale == 5 else 1), 'guard word of the sampled reference'
+
+
 def test_self_gated_attn_golden(dev, w, g):
     """The reference's self_attn module (use_linear True): fused [QK | V | U] GEMM with SiLU from column 128 on, attention
     over one key frame without a chunk table, dw_conv + projection."""
