@@ -8,15 +8,16 @@
 // With one head the value side (2 * Lq * Lk * 1024 flop) outweighs the score side (2 * Lq * Lk * 128) eight to one, and
 // one 128 x Lk score matrix serves all 1024 value columns.  So, unlike the d = 32 memory read (attention.hip), the
 // probabilities are materialised ONCE in e16 and the value side runs as a plain tiled GEMM:
-//   k_gp_scores<., 0>  S = Q K^T (+ temporal-PE bias | window mask + relative embedding)  ->  per-chunk row maxima
+//   k_gp_scores<., 0>  S = Q K^T (+ temporal-PE bias | window mask + relative embedding)  ->  per-chunk row maxima (sampled tiles / all)
 //   k_gp_scores<., 1>  same S again (6.5 GFLOP at cfg 2, cheaper than storing fp32 S)     ->  P = exp2(S - max) in e16,
 //                      [Lq][frames * Lp] with every 64-key tile fully written (zeros past a frame's end); per-chunk row sums
 //   k_gp_pv            O = P V: 128 x 256 output tile per workgroup, 4 waves of 64 x 128, 64-key steps, P and V tiles
 //                      through a 3-deep LDS ring filled by global_load_lds (source-side XOR swizzle), V read transposed
 //                      (ds_read_b64_tr_b16); key groups give split-K slabs
 //   k_gp_combine       sum the slabs, 1 / row sum, gate by U, e16 (and the per-memory-frame probability mass)
-// Scores live in the log2 domain (Q pre-scaled by log2(e) / sqrt(128)).  Exact softmax: the maximum is the true row
-// maximum, so P <= 1 and the e16 P keeps 8 significant bits at every magnitude.
+// Scores live in the log2 domain (Q pre-scaled by log2(e) / sqrt(128)).  The softmax reference is a row maximum over a SAMPLE of
+// the keys (launch_all): P = 2^(S - m) keeps its 8 significant bits at every magnitude, may exceed 1, and a guard word triggers the
+// exact two-pass redo (the reference is then the true row maximum, P <= 1) before fp32 could overflow.
 #include "common.h"
 #include "../../include/rmem.h"
 #include <math.h>
