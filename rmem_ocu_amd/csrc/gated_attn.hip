@@ -804,7 +804,13 @@ void launch_all(GpParams& p, const GpPlan& g, GpCombine& c, bool timed, double f
   // exceed 1, which is harmless until it leaves the fp32 range.  Pass 1 raises a flag when any score lies more than 2^64 above the
   // reference (or no reference was sampled); the exact pass 0 + pass 1 follow in the same stream and return at once unless it is set
   // (graph-capturable: no host decision).  RMEM_GP_SAMPLE=0: always the exact two passes.
+#ifdef RMEM_F16
+  // IEEE half holds P only up to 2^16: a sampled reference would need a guard so tight that it fires on ordinary data -- the
+  // half flavour keeps the exact two passes (as its memory read always takes the SAFE pass, attention.hip)
+  static const bool sample = false;
+#else
   static const bool sample = !(getenv("RMEM_GP_SAMPLE") && atoi(getenv("RMEM_GP_SAMPLE")) == 0);
+#endif
   unsigned* flag = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(p.mpart) + g.total - 256);
   if (sample) {
     (void)hipMemsetAsync(flag, 0, 4, s);      // (a failure surfaces in rmem_check_launch after the launches)
