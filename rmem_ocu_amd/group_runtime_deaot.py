@@ -30,6 +30,15 @@ from .runtime import D_MODEL, F32
 from .runtime_deaot import D_ATT, E1, E2, GP_ROWS, QVU, REL_LD, SQVU
 
 
+def rows_per_frame(L: int, T: int, clips: int) -> int:
+    """Key-table rows per memory frame of a group's long-term gated attention.  A row is one workgroup per query tile and clip in the
+    score kernels, and every workgroup pays a fixed prologue (Q fragments, the temporal-PE bias through the matrix pipe, the row
+    maxima) worth ~3 key tiles -- so a frame is cut only as far as filling the GPU needs (~512 workgroups), never into more than 4 rows
+    or more than 32 rows in all (the table the mass output describes); with 8 clips per launch and T >= 5 a frame stays one row."""
+    wgs = ((L + 127) // 128) * T * clips
+    return max(1, min(4, 32 // T, (512 + wgs - 1) // wgs))
+
+
 class GroupRuntimeDeAOT(GroupRuntime):
     deaot = True
     max_rows = GP_ROWS
@@ -67,11 +76,7 @@ class GroupRuntimeDeAOT(GroupRuntime):
     def chunk_plan(self, T: int) -> Tuple[int, int]:
         if T > 32:
             raise ops.RmemError(f'memory bank of {T} frames exceeds the 32 frames the gated attention records mass for')
-        # table rows per memory frame: a row is one workgroup per query tile and clip in the score kernels, and every workgroup pays a
-        # fixed prologue (Q fragments, the temporal-PE bias through the matrix pipe, the row maxima) worth ~3 key tiles -- so rows are
-        # cut only as far as filling the GPU needs (~512 workgroups); with 8 clips per launch and T >= 5 a frame stays one row
-        wgs = ((self.L + 127) // 128) * T * self.B
-        splits = max(1, min(4, 32 // T, (512 + wgs - 1) // wgs))
+        splits = rows_per_frame(self.L, T, self.B)
         per = self._keys_per_chunk(splits)
         return splits, T * ((self.L + per - 1) // per)
 

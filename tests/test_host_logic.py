@@ -148,3 +148,20 @@ def test_pack_frag_layout():
             n = 256 * nb + (256 // nw) * wave + 16 * j + (lane & 15)
             k = 32 * kc + 8 * (lane >> 4) + e
             assert f[nb, wave, kc, j, lane, e].item() == n * 1000 + k
+
+
+def test_deaot_group_key_table_rows_per_frame():
+    """Rows per memory frame of a DeAOT group's key table (group_runtime_deaot.rows_per_frame): one row per frame once the clips fill
+    the GPU, never more than 4 per frame or 32 in all (the table rmem_gated_attn records mass for), at least 1."""
+    from rmem_ocu_amd.group_runtime_deaot import rows_per_frame
+    L = 31 * 54
+    assert rows_per_frame(L, 9, 8) == 1            # the bench shape: 14 query tiles x 9 frames x 8 clips = 1008 workgroups
+    assert rows_per_frame(L, 9, 1) == 3            # single clip: 32 // 9
+    assert rows_per_frame(L, 1, 8) == 4            # first frames of a clip: few keys, cut as far as allowed
+    assert rows_per_frame(L, 4, 8) == 2
+    for T in range(1, 33):
+        for clips in (1, 2, 4, 8, 16):
+            r = rows_per_frame(L, T, clips)
+            assert 1 <= r <= 4 and r * T <= 32
+            if r > 1:                                # cut only while the launch is short of ~512 workgroups
+                assert ((L + 127) // 128) * T * clips * (r - 1) < 512
