@@ -373,10 +373,13 @@ __global__ __launch_bounds__(NT) void k_chain_b(rmem_chain_b_desc d) {
 template <bool FFN2, bool NEXT>
 __global__ __launch_bounds__(NT) void k_chain_c(rmem_chain_c_desc d) {
   constexpr int NPA = FFN2 ? 16 : 4;
-  __shared__ __attribute__((aligned(16))) char smem[NPA * PANEL * 2 + 2 * BM * XS * 4];
+  // with FFN2 the second staging buffer lives in A panels 4 .. 15: they are dead once linear2's GEMM is done (the barrier behind its
+  // dump), and only panels 0 .. 3 are written again (LN1' of the next block) -- 97 KB instead of 130 KB, so the workgroup finds a CU sooner
+  static_assert(!FFN2 || 12 * PANEL * 2 >= BM * XS * 4, "the second staging buffer must fit panels 4 .. 15");
+  __shared__ __attribute__((aligned(16))) char smem[NPA * PANEL * 2 + (FFN2 ? 1 : 2) * BM * XS * 4];
   e16* A16 = reinterpret_cast<e16*>(smem);
   float* Xa = reinterpret_cast<float*>(smem + NPA * PANEL * 2);
-  float* Xb = Xa + BM * XS;
+  float* Xb = FFN2 ? reinterpret_cast<float*>(smem + 4 * PANEL * 2) : Xa + BM * XS;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const Blk blk = my_rows(d.L);
   const int c0 = lane * 4;
